@@ -1,0 +1,612 @@
+#include "io.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+namespace mp {
+
+// =================================================================== BGZF / BAM
+namespace {
+
+struct FileBytes {
+    std::vector<uint8_t> data;
+    explicit FileBytes(const std::string& path) {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) throw Error("cannot open " + path);
+        std::fseek(f, 0, SEEK_END);
+        long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        data.resize(size_t(n));
+        if (n && std::fread(data.data(), 1, size_t(n), f) != size_t(n)) {
+            std::fclose(f);
+            throw Error("short read on " + path);
+        }
+        std::fclose(f);
+    }
+};
+
+// Streaming BGZF inflater: yields the concatenated uncompressed stream block by block.
+class BgzfReader {
+  public:
+    explicit BgzfReader(const std::vector<uint8_t>& file) : f_(file) {}
+    // Append the next block's payload to `out`; false at EOF.
+    bool next_block(std::vector<uint8_t>& out) {
+        if (off_ >= f_.size()) return false;
+        if (off_ + 18 > f_.size()) throw Error("truncated BGZF header");
+        const uint8_t* p = f_.data() + off_;
+        if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) throw Error("not a BGZF block");
+        uint32_t xlen = p[10] | (p[11] << 8);
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t* e = p + 12 + x;
+            uint32_t slen = e[2] | (e[3] << 8);
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2) { bsize = (e[4] | (e[5] << 8)) + 1u; found = true; }
+            x += 4 + slen;
+        }
+        if (!found || off_ + bsize > f_.size()) throw Error("bad BGZF block size");
+        const uint8_t* cdata = p + 12 + xlen;
+        uint32_t clen = bsize - xlen - 12 - 8;
+        uint32_t isize = p[bsize - 4] | (p[bsize - 3] << 8) | (p[bsize - 2] << 16) | (uint32_t(p[bsize - 1]) << 24);
+        size_t old = out.size();
+        out.resize(old + isize);
+        if (isize) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) throw Error("inflateInit2 failed");
+            zs.next_in = const_cast<Bytef*>(cdata);
+            zs.avail_in = clen;
+            zs.next_out = out.data() + old;
+            zs.avail_out = isize;
+            int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) throw Error("BGZF inflate failed");
+        }
+        off_ += bsize;
+        return true;
+    }
+
+  private:
+    const std::vector<uint8_t>& f_;
+    size_t off_ = 0;
+};
+
+inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (uint32_t(p[3]) << 24); }
+inline uint16_t rd16(const uint8_t* p) { return uint16_t(p[0] | (p[1] << 8)); }
+
+}  // namespace
+
+void load_bam(const std::string& path, BamData& out) {
+    FileBytes fb(path);
+    BgzfReader bg(fb.data);
+    std::vector<uint8_t> buf;
+    size_t cur = 0;
+    auto need = [&](size_t n) -> bool {
+        while (buf.size() - cur < n) {
+            if (cur > (1u << 20)) {  // compact
+                buf.erase(buf.begin(), buf.begin() + long(cur));
+                cur = 0;
+            }
+            if (!bg.next_block(buf)) return false;
+        }
+        return true;
+    };
+    if (!need(12)) throw Error("empty BAM " + path);
+    if (std::memcmp(buf.data() + cur, "BAM\1", 4) != 0) throw Error("bad BAM magic in " + path);
+    uint32_t l_text = rd32(buf.data() + cur + 4);
+    cur += 8;
+    if (!need(l_text + 4)) throw Error("truncated BAM header");
+    cur += l_text;
+    uint32_t n_ref = rd32(buf.data() + cur);
+    cur += 4;
+    out.ref_names.clear();
+    out.ref_lens.clear();
+    for (uint32_t i = 0; i < n_ref; i++) {
+        if (!need(4)) throw Error("truncated BAM refs");
+        uint32_t l_name = rd32(buf.data() + cur);
+        cur += 4;
+        if (!need(l_name + 4)) throw Error("truncated BAM refs");
+        out.ref_names.emplace_back(reinterpret_cast<const char*>(buf.data() + cur), l_name ? l_name - 1 : 0);
+        cur += l_name;
+        out.ref_lens.push_back(int64_t(rd32(buf.data() + cur)));
+        cur += 4;
+    }
+    out.reads = ReadStore();
+    std::vector<uint32_t> cig;
+    while (need(4)) {
+        uint32_t bs = rd32(buf.data() + cur);
+        if (!need(4 + size_t(bs))) throw Error("truncated BAM record");
+        const uint8_t* r = buf.data() + cur + 4;
+        int32_t ref_id = int32_t(rd32(r));
+        int32_t pos = int32_t(rd32(r + 4));
+        uint8_t l_read_name = r[8];
+        uint8_t mapq = r[9];
+        uint16_t n_cig = rd16(r + 12);
+        uint16_t flag = rd16(r + 14);
+        uint32_t l_seq = rd32(r + 16);
+        const uint8_t* p = r + 32;
+        const char* name = reinterpret_cast<const char*>(p);
+        p += l_read_name;
+        cig.resize(n_cig);
+        for (uint32_t k = 0; k < n_cig; k++) cig[k] = rd32(p + 4 * k);
+        p += 4 * size_t(n_cig);
+        const uint8_t* seq4 = p;
+        p += (l_seq + 1) / 2;
+        const uint8_t* qual = p;
+        if (ref_id >= 0) out.reads.add(ref_id, pos, mapq, flag, cig.data(), n_cig, seq4, l_seq, qual, name);
+        cur += 4 + size_t(bs);
+    }
+    // tid_begin (file is coordinate sorted: tids ascending)
+    out.tid_begin.assign(n_ref + 1, out.reads.size());
+    {
+        size_t n = out.reads.size();
+        size_t i = 0;
+        for (uint32_t t = 0; t < n_ref; t++) {
+            while (i < n && out.reads.tid[i] < int32_t(t)) i++;
+            out.tid_begin[t] = i;
+        }
+        out.tid_begin[n_ref] = n;
+    }
+}
+
+namespace {
+void bgzf_write_block(FILE* f, const uint8_t* data, size_t n) {
+    std::vector<uint8_t> comp(compressBound(uLong(n)) + 64);
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
+    zs.next_in = const_cast<Bytef*>(data);
+    zs.avail_in = uInt(n);
+    zs.next_out = comp.data();
+    zs.avail_out = uInt(comp.size());
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw Error("deflate failed"); }
+    size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    uint32_t bsize = uint32_t(clen + 12 + 6 + 8);
+    uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 0, 0};
+    hdr[16] = uint8_t((bsize - 1) & 0xFF);
+    hdr[17] = uint8_t((bsize - 1) >> 8);
+    std::fwrite(hdr, 1, 18, f);
+    std::fwrite(comp.data(), 1, clen, f);
+    uint32_t crc = uint32_t(crc32(crc32(0L, Z_NULL, 0), data, uInt(n)));
+    uint8_t tail[8];
+    for (int i = 0; i < 4; i++) tail[i] = uint8_t(crc >> (8 * i));
+    for (int i = 0; i < 4; i++) tail[4 + i] = uint8_t(uint32_t(n) >> (8 * i));
+    std::fwrite(tail, 1, 8, f);
+}
+void put32(std::vector<uint8_t>& b, uint32_t v) {
+    for (int i = 0; i < 4; i++) b.push_back(uint8_t(v >> (8 * i)));
+}
+}  // namespace
+
+void write_bam(const std::string& path, const std::vector<std::string>& ref_names, const std::vector<int64_t>& ref_lens,
+               const ReadStore& reads) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw Error("cannot write " + path);
+    std::vector<uint8_t> b;
+    auto flush = [&](bool force) {
+        size_t off = 0;
+        while (b.size() - off >= 0xff00 || (force && off < b.size())) {
+            size_t n = std::min<size_t>(0xff00, b.size() - off);
+            bgzf_write_block(f, b.data() + off, n);
+            off += n;
+        }
+        b.erase(b.begin(), b.begin() + long(off));
+    };
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (size_t i = 0; i < ref_names.size(); i++)
+        text += "@SQ\tSN:" + ref_names[i] + "\tLN:" + std::to_string(ref_lens[i]) + "\n";
+    b.insert(b.end(), {'B', 'A', 'M', 1});
+    put32(b, uint32_t(text.size()));
+    b.insert(b.end(), text.begin(), text.end());
+    put32(b, uint32_t(ref_names.size()));
+    for (size_t i = 0; i < ref_names.size(); i++) {
+        put32(b, uint32_t(ref_names[i].size() + 1));
+        b.insert(b.end(), ref_names[i].begin(), ref_names[i].end());
+        b.push_back(0);
+        put32(b, uint32_t(ref_lens[i]));
+    }
+    for (size_t i = 0; i < reads.size(); i++) {
+        const char* name = reads.qname(i);
+        size_t nl = std::strlen(name) + 1;
+        uint32_t ncig = reads.n_cigar[i], lseq = reads.l_seq[i];
+        uint32_t bs = uint32_t(32 + nl + 4 * ncig + (lseq + 1) / 2 + lseq);
+        put32(b, bs);
+        put32(b, uint32_t(reads.tid[i]));
+        put32(b, uint32_t(reads.pos[i]));
+        b.push_back(uint8_t(nl));
+        b.push_back(reads.mapq[i]);
+        b.push_back(0x48); b.push_back(0x12);  // bin (unused by our reader)
+        b.push_back(uint8_t(ncig & 0xFF)); b.push_back(uint8_t(ncig >> 8));
+        b.push_back(uint8_t(reads.flag[i] & 0xFF)); b.push_back(uint8_t(reads.flag[i] >> 8));
+        put32(b, lseq);
+        put32(b, 0xFFFFFFFFu);  // next refID
+        put32(b, 0xFFFFFFFFu);  // next pos
+        put32(b, 0);            // tlen
+        b.insert(b.end(), name, name + nl);
+        for (uint32_t k = 0; k < ncig; k++) put32(b, reads.cigar(i)[k]);
+        const uint8_t* s = reads.seq_pool.data() + reads.seq_off[i];
+        b.insert(b.end(), s, s + (lseq + 1) / 2);
+        const uint8_t* q = reads.qual(i);
+        b.insert(b.end(), q, q + lseq);
+        if (b.size() >= (1u << 20)) flush(false);
+    }
+    flush(true);
+    bgzf_write_block(f, nullptr, 0);  // EOF marker
+    std::fclose(f);
+}
+
+// ------------------------------------------------------------------- ReadBuffer
+// Underlying iterator = htslib region iterator created by `reader.fetch(tid, beg, target_len)`:
+// yields, in file order, the records of `tid` whose end position is > beg.
+bool ReadBuffer::next_record(size_t& idx) {
+    if (!iter_valid_) return false;
+    const ReadStore& rs = bam_.reads;
+    while (cursor_ < cursor_end_) {
+        size_t i = cursor_++;
+        int64_t e = rs.end_pos[i];
+        if (e <= rs.pos[i]) e = rs.pos[i] + 1;  // bam_endpos of a record without reference length
+        if (e > iter_beg_) { idx = i; return true; }
+    }
+    return false;
+}
+
+void ReadBuffer::fetch(const std::string& chrom, uint64_t start, uint64_t end) {
+    const ReadStore& rs = bam_.reads;
+    if (has_overflow_) {
+        inner_.push_back(overflow_);
+        has_overflow_ = false;
+    }
+    int tid = bam_.tid_of(chrom);
+    if (tid < 0) throw Error("sequence " + chrom + " not found in BAM header");
+    bool reseek = inner_.empty();
+    if (!reseek) {
+        size_t last = inner_.back();
+        if (uint64_t(rs.pos[last]) < start || rs.tid[last] != tid) reseek = true;
+    }
+    if (reseek) {
+        iter_tid_ = tid;
+        iter_beg_ = int64_t(start);
+        cursor_ = bam_.tid_begin[size_t(tid)];
+        cursor_end_ = bam_.tid_begin[size_t(tid) + 1];
+        iter_valid_ = true;
+        inner_.clear();
+    } else {
+        while (!inner_.empty() && rs.pos[inner_.front()] < int64_t(start)) inner_.pop_front();
+    }
+    size_t idx;
+    while (next_record(idx)) {
+        if (rs.flag[idx] & 0x4) continue;  // is_unmapped
+        if (rs.pos[idx] >= int64_t(end)) {
+            overflow_ = idx;
+            has_overflow_ = true;
+            break;
+        }
+        inner_.push_back(idx);
+    }
+}
+
+// =================================================================== VCF
+namespace {
+std::vector<std::string> split(const std::string& s, char d) {
+    std::vector<std::string> out;
+    size_t a = 0;
+    for (;;) {
+        size_t b = s.find(d, a);
+        if (b == std::string::npos) { out.push_back(s.substr(a)); break; }
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+    return out;
+}
+}  // namespace
+
+void load_vcf(const std::string& path, VcfData& out) {
+    std::ifstream in(path);
+    if (!in) throw Error("cannot open " + path);
+    std::string line;
+    out.contigs.clear();
+    out.records.clear();
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '#') {
+            if (line.rfind("##contig=<", 0) == 0) {
+                size_t a = line.find("ID=");
+                if (a != std::string::npos) {
+                    size_t b = line.find_first_of(",>", a);
+                    out.contigs.push_back(line.substr(a + 3, b - a - 3));
+                }
+            }
+            continue;
+        }
+        auto f = split(line, '\t');
+        if (f.size() < 8) throw Error("malformed VCF line: " + line);
+        VcfRecord r;
+        r.chrom = f[0];
+        r.pos = std::strtoull(f[1].c_str(), nullptr, 10) - 1;
+        r.ref = f[3];
+        r.alts = split(f[4], ',');
+        for (const auto& kv : split(f[7], ';')) {
+            if (kv == "SOMATIC") r.somatic = true;
+            else if (kv.rfind("ANN=", 0) == 0) {
+                std::string v = kv.substr(4);
+                size_t c = v.find(',');
+                r.ann_first = c == std::string::npos ? v : v.substr(0, c);
+            } else if (kv.rfind("SVLEN=", 0) == 0) {
+                r.has_svlen = true;
+                for (const auto& x : split(kv.substr(6), ',')) r.svlen.push_back(x == "." ? INT64_MIN : std::atoll(x.c_str()));
+            }
+        }
+        if (std::find(out.contigs.begin(), out.contigs.end(), r.chrom) == out.contigs.end()) out.contigs.push_back(r.chrom);
+        out.records.push_back(std::move(r));
+    }
+}
+
+static void warn_or_error(const std::string& msg, bool warning_only) {  // common.rs:62-69
+    if (warning_only) std::fprintf(stderr, "%s\n", msg.c_str());
+    else throw Error(msg);
+}
+
+void variants_from_record(const VcfRecord& rec, bool warning_only, std::vector<Variant>& out) {
+    bool is_germline = !rec.somatic;  // common.rs:75
+    // Annotation::new (common.rs:21-35): first '|' field of the first ANN entry that contains "p."
+    std::string prot_change;
+    if (!rec.ann_first.empty()) {
+        for (const auto& e : split(rec.ann_first, '|'))
+            if (e.find("p.") != std::string::npos) { prot_change = e; break; }
+    }
+    const std::string& ref = rec.ref;
+    for (const auto& a : rec.alts) {
+        Variant v;
+        v.pos = rec.pos;
+        v.is_germline = is_germline;
+        v.prot_change = prot_change;
+        if (a.size() == 1 && ref.size() > 1) {  // common.rs:86-92
+            v.kind = VK_DEL;
+            v.len = ref.size() - 1;
+            out.push_back(v);
+        } else if (a.size() > 1 && ref.size() == 1) {
+            if (a[0] == '<') {
+                if (a == "<DEL>") {  // common.rs:95-142
+                    if (!rec.has_svlen || rec.svlen.empty()) {
+                        warn_or_error("Found no 'SVLEN' info tag for <DEL> alternative allele at chr " + rec.chrom + " pos " + std::to_string(rec.pos), warning_only);
+                    } else if (rec.svlen.size() > 1) {
+                        warn_or_error("microphaser does not handle multiallelic records. Please normalize, e.g. with `bcftools norm -m-`.", warning_only);
+                    } else if (rec.svlen[0] == INT64_MIN) {
+                        warn_or_error("Found no 'SVLEN' info tag for <DEL> alternative allele on contig " + rec.chrom + " at pos " + std::to_string(rec.pos), warning_only);
+                    } else {
+                        v.kind = VK_DEL;
+                        v.len = uint64_t(rec.svlen[0] < 0 ? -rec.svlen[0] : rec.svlen[0]);
+                        out.push_back(v);
+                    }
+                } else {
+                    warn_or_error("Alternative allele type '" + a + "' not yet supported, but found on contig " + rec.chrom + " at position " + std::to_string(rec.pos) + ".", warning_only);
+                }
+            } else {  // common.rs:150-156
+                v.kind = VK_INS;
+                v.seq = a;
+                v.len = a.size() - 1;
+                out.push_back(v);
+            }
+        } else if (a.size() == 1 && ref.size() == 1) {  // common.rs:158-164
+            v.kind = VK_SNV;
+            v.alt = uint8_t(a[0]);
+            out.push_back(v);
+        } else {  // common.rs:165-171
+            std::fprintf(stderr, "Unsupported variant %s -> %s\n", ref.c_str(), a.c_str());
+        }
+    }
+}
+
+void gene_variants(const VcfData& vcf, const std::string& chrom, uint64_t start, uint64_t end, bool warning_only,
+                   std::vector<Variant>& out) {
+    // bcf::buffer::RecordBuffer::fetch resolves the contig through the header (name2rid) and errors if unknown
+    if (std::find(vcf.contigs.begin(), vcf.contigs.end(), chrom) == vcf.contigs.end())
+        throw Error("contig " + chrom + " not found in VCF header");
+    std::map<uint64_t, std::vector<Variant>> tree;  // variant_tree.insert(pos, ...) : later record replaces
+    for (const auto& r : vcf.records) {
+        if (r.chrom != chrom || r.pos < start || r.pos > end) continue;
+        std::vector<Variant> vs;
+        variants_from_record(r, warning_only, vs);
+        tree[r.pos] = std::move(vs);
+    }
+    out.clear();
+    for (auto& kv : tree)
+        for (auto& v : kv.second) out.push_back(std::move(v));
+}
+
+// =================================================================== FASTA
+IndexedFasta::IndexedFasta(const std::string& path) : path_(path) {
+    std::ifstream fai(path + ".fai");
+    if (!fai) throw Error("cannot open " + path + ".fai");
+    std::string line;
+    while (std::getline(fai, line)) {
+        if (line.empty()) continue;
+        auto f = split(line, '\t');
+        if (f.size() < 5) throw Error("malformed .fai line");
+        Entry e{std::strtoull(f[1].c_str(), nullptr, 10), std::strtoull(f[2].c_str(), nullptr, 10),
+                std::strtoull(f[3].c_str(), nullptr, 10), std::strtoull(f[4].c_str(), nullptr, 10), 0, 0};
+        e.region_len = e.len;
+        if (f.size() >= 7) {  // region-offset extension (tests/golden mini references): only [start, start+n) is stored
+            e.region_start = std::strtoull(f[5].c_str(), nullptr, 10);
+            e.region_len = std::strtoull(f[6].c_str(), nullptr, 10);
+        }
+        idx_[f[0]] = e;
+    }
+}
+
+void IndexedFasta::ensure_loaded() const {
+    if (!file_.empty()) return;
+    FileBytes fb(path_);
+    file_.swap(fb.data);
+}
+
+void IndexedFasta::fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const {
+    auto it = idx_.find(chrom);
+    if (it == idx_.end()) throw Error("Unknown sequence name: " + chrom);
+    const Entry& e = it->second;
+    if (stop > e.len) throw Error("FASTA read interval was out of bounds");
+    if (start > stop) throw Error("Invalid query interval");
+    ensure_loaded();
+    out.clear();
+    out.reserve(stop - start);
+    for (uint64_t p = start; p < stop; p++) {
+        if (p < e.region_start || p >= e.region_start + e.region_len) { out.push_back('N'); continue; }
+        uint64_t q = p - e.region_start;
+        uint64_t off = e.offset + (q / e.line_bases) * e.line_bytes + (q % e.line_bases);
+        if (off >= file_.size()) throw Error("FASTA file shorter than its index");
+        out.push_back(file_[off]);
+    }
+}
+
+// =================================================================== GTF
+namespace {
+struct GtfRecord {
+    std::string seqname, feature, strand, frame;
+    uint64_t start = 0, end = 0;
+    std::vector<std::pair<std::string, std::string>> attrs;
+    const std::string* get(const char* k) const {
+        for (const auto& a : attrs)
+            if (a.first == k) return &a.second;
+        return nullptr;
+    }
+};
+
+bool parse_gtf_line(const std::string& line, GtfRecord& r) {
+    if (line.empty() || line[0] == '#') return false;
+    auto f = split(line, '\t');
+    if (f.size() < 9) throw Error("malformed GTF line: " + line);
+    r.seqname = f[0];
+    r.feature = f[2];
+    r.start = std::strtoull(f[3].c_str(), nullptr, 10);
+    r.end = std::strtoull(f[4].c_str(), nullptr, 10);
+    r.strand = f[6];
+    r.frame = f[7];
+    r.attrs.clear();
+    // rust-bio GTF2 attribute grammar: \s*key<space>value;  with quotes trimmed from value
+    const std::string& a = f[8];
+    size_t i = 0, n = a.size();
+    while (i < n) {
+        while (i < n && (a[i] == ' ' || a[i] == ';')) i++;
+        size_t ks = i;
+        while (i < n && a[i] != ' ' && a[i] != ';') i++;
+        if (i >= n || a[i] != ' ') break;
+        std::string key = a.substr(ks, i - ks);
+        i++;
+        size_t vs = i;
+        while (i < n && a[i] != ';') i++;
+        std::string val = a.substr(vs, i - vs);
+        while (!val.empty() && (val.front() == '\'' )) val.erase(val.begin());
+        while (!val.empty() && (val.back() == '\'')) val.pop_back();
+        while (!val.empty() && (val.front() == '"')) val.erase(val.begin());
+        while (!val.empty() && (val.back() == '"')) val.pop_back();
+        r.attrs.emplace_back(std::move(key), std::move(val));
+    }
+    return true;
+}
+
+Interval make_interval(uint64_t start, uint64_t end, const std::string& frame) {  // common.rs:329-338
+    Interval iv;
+    iv.start = start;
+    iv.end = end;
+    iv.frame = frame == "." ? 0 : std::strtoull(frame.c_str(), nullptr, 10);
+    return iv;
+}
+}  // namespace
+
+void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gene) {
+    bool have_gene = false;
+    Gene gene;
+    bool start_codon_found = false, three_prime_found = false;
+    std::string last_chrom = "not_yet_set";
+    uint64_t last_start = 0;
+    std::string line;
+    GtfRecord rec;
+    auto need = [&](const char* k, const char* msg) -> const std::string& {
+        const std::string* v = rec.get(k);
+        if (!v) throw Error(msg);
+        return *v;
+    };
+    auto last_tx = [&](const char* msg) -> Transcript& {
+        if (!have_gene) throw Error("no gene record before feature in GTF");
+        if (gene.transcripts.empty()) throw Error(msg);
+        return gene.transcripts.back();
+    };
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!parse_gtf_line(line, rec)) continue;
+        if (rec.feature == "gene") {  // microphasing.rs:1986-2018
+            if (have_gene) {
+                on_gene(gene);
+                last_chrom = gene.chrom;
+                last_start = gene.start();
+            }
+            const std::string& gene_name = need("gene_name", "missing gene_name in GTF");
+            if (last_chrom == rec.seqname && !(last_start <= rec.start)) {
+                throw Error("Your GTF file is not sorted correctly. Gene " + gene_name + " starts at " +
+                            std::to_string(rec.start) + ", while previous gene record started at " + std::to_string(last_start) + ".");
+            }
+            gene = Gene();
+            gene.id = need("gene_id", "missing gene_id in GTF");
+            gene.name = gene_name;
+            gene.chrom = rec.seqname;
+            gene.interval = make_interval(rec.start - 1, rec.end, rec.frame);
+            gene.biotype = need("gene_biotype", "missing gene_biotype in GTF");
+            have_gene = true;
+        } else if (rec.feature == "transcript") {  // :2019-2040
+            start_codon_found = false;
+            three_prime_found = false;
+            if (!have_gene) throw Error("no gene record before transcript in GTF");
+            Transcript t;
+            t.id = need("transcript_id", "missing transcript_id attribute in GTF");
+            t.biotype = need("transcript_biotype", "missing transcript_biotype in GTF");
+            if (rec.strand == "+") t.strand = FORWARD;
+            else if (rec.strand == "-") t.strand = REVERSE;
+            else throw Error("Unsupported Strand orientation! Only Forward (+) and Reverse(-) allowed");
+            gene.transcripts.push_back(std::move(t));
+        } else if (rec.feature == "CDS") {  // :2041-2055
+            last_tx("no transcript record before exon in GTF").exons.push_back(make_interval(rec.start - 1, rec.end, rec.frame));
+        } else if (rec.feature == "start_codon") {  // :2056-2082
+            if (start_codon_found) continue;
+            start_codon_found = true;
+            Transcript& t = last_tx("no transcript record before start codon in GTF");
+            if (t.exons.empty()) throw Error("no exon record before start codon in GTF");
+            if (rec.strand == "+") t.exons.back().start = rec.start - 1;
+            else t.exons.back().end = rec.end;
+        } else if (rec.feature == "three_prime_utr") {  // :2083-2122
+            Transcript& t = last_tx("no transcript record before exon in GTF");
+            if (three_prime_found) {
+                t.exons.push_back(make_interval(rec.start - 1, rec.end, rec.frame));
+            } else {
+                three_prime_found = true;
+                if (t.exons.empty()) throw Error("no exon record before start codon in GTF");
+                if (rec.strand == "+") t.exons.back().end = rec.end;
+                else t.exons.back().start = rec.start - 1;
+            }
+        }
+    }
+    if (have_gene) on_gene(gene);
+}
+
+void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const IndexedFasta& fasta,
+                      bool warning_only, const std::function<void(GeneInput&)>& on_gene) {
+    ReadBuffer rb(bam);
+    stream_gtf(gtf, [&](const Gene& g) {
+        if (g.biotype != "protein_coding") return;  // microphasing.rs:1964
+        GeneInput gi;
+        gi.gene = g;
+        fasta.fetch(g.chrom, g.start(), g.end() + 100, gi.refseq);  // :895-901
+        rb.fetch(g.chrom, g.start(), g.end());                      // :905
+        gi.reads.assign(rb.records().begin(), rb.records().end());
+        gene_variants(vcf, g.chrom, g.start(), g.end(), warning_only, gi.variants);  // :932-942
+        on_gene(gi);
+    });
+}
+
+}  // namespace mp

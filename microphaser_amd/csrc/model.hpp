@@ -1,0 +1,192 @@
+// Shared host-side data model: the types that cross the phase_gene seam.
+//
+// Mirrors the reference's model types (reference: src/common.rs:38-222 Variant,
+// :224-348 Gene/Transcript/Interval/PhasingStrand, :350-373 IDRecord) and the
+// in-memory form of the BAM/VCF/FASTA inputs the reference gets from rust-htslib
+// and rust-bio. Reads are kept in pooled struct-of-arrays form (ReadStore) so the
+// very same pools can be uploaded to HBM unchanged.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mp {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---------------------------------------------------------------- variants
+enum VarKind : uint8_t { VK_SNV = 0, VK_INS = 1, VK_DEL = 2 };
+
+// reference: src/common.rs:38-59 (enum Variant) + accessors :177-221
+struct Variant {
+    VarKind kind = VK_SNV;
+    uint64_t pos = 0;        // 0-based
+    uint8_t alt = 0;         // SNV alt base (as written in the VCF)
+    std::string seq;         // insertion: whole ALT incl. anchor base
+    uint64_t len = 0;        // indel length (ALT-1 for ins, REF-1 / |SVLEN| for del)
+    bool is_germline = true;
+    std::string prot_change;
+
+    uint64_t end_pos() const { return kind == VK_DEL ? pos + len - 1 : pos; }  // common.rs:185-191
+    uint64_t frameshift() const {                                              // common.rs:215-221
+        switch (kind) {
+            case VK_SNV: return 0;
+            case VK_DEL: return len % 3;
+            default: return (3 - ((uint64_t(seq.size()) - 1) % 3)) % 3;
+        }
+    }
+};
+
+// ---------------------------------------------------------------- gene model
+enum Strand : uint8_t { FORWARD = 0, REVERSE = 1 };
+
+struct Interval {  // common.rs:293-338 (0-based half-open)
+    uint64_t start = 0, end = 0, frame = 0;
+};
+
+struct Transcript {  // common.rs:271-291
+    std::string id, biotype;
+    Strand strand = FORWARD;
+    std::vector<Interval> exons;
+    bool is_coding() const { return !exons.empty(); }
+};
+
+struct Gene {  // common.rs:224-253
+    std::string id, name, chrom, biotype;
+    Interval interval;
+    std::vector<Transcript> transcripts;
+    uint64_t start() const { return interval.start; }
+    uint64_t end() const { return interval.end; }
+};
+
+// ---------------------------------------------------------------- reads
+// BAM CIGAR op codes (SAM spec): MIDNSHP=X
+enum CigarOp : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, C_P = 6, C_EQ = 7, C_X = 8 };
+
+// Pooled struct-of-arrays read storage. cigar words are BAM-encoded (len<<4|op),
+// seq is BAM 4-bit packed (two bases per byte, high nibble first), qual is raw phred.
+struct ReadStore {
+    std::vector<int32_t> tid;
+    std::vector<int64_t> pos;
+    std::vector<int64_t> end_pos;  // pos + sum(M,=,X,D,N)   (rust-htslib CigarStringView::end_pos)
+    std::vector<uint8_t> mapq;
+    std::vector<uint16_t> flag;
+    std::vector<uint32_t> l_seq;
+    std::vector<uint32_t> n_cigar;
+    std::vector<uint64_t> cigar_off;  // index into cigar_pool
+    std::vector<uint64_t> seq_off;    // byte index into seq_pool
+    std::vector<uint64_t> qual_off;   // byte index into qual_pool
+    std::vector<uint64_t> qname_off;  // byte index into qname_pool (NUL terminated)
+    std::vector<uint32_t> cigar_pool;
+    std::vector<uint8_t> seq_pool;
+    std::vector<uint8_t> qual_pool;
+    std::vector<char> qname_pool;
+
+    size_t size() const { return pos.size(); }
+    const char* qname(size_t i) const { return &qname_pool[qname_off[i]]; }
+    const uint32_t* cigar(size_t i) const { return cigar_pool.data() + cigar_off[i]; }
+    const uint8_t* qual(size_t i) const { return qual_pool.data() + qual_off[i]; }
+    // decoded upper-case base (rust-htslib Seq::index -> "=ACMGRSVTWYHKDBN")
+    uint8_t base(size_t i, uint32_t k) const {
+        uint8_t b = seq_pool[seq_off[i] + (k >> 1)];
+        return "=ACMGRSVTWYHKDBN"[(k & 1) ? (b & 0xF) : (b >> 4)];
+    }
+    // append one read; returns its index
+    size_t add(int32_t tid_, int64_t pos_, uint8_t mapq_, uint16_t flag_, const uint32_t* cig, uint32_t ncig,
+               const uint8_t* seq4, uint32_t lseq, const uint8_t* q, const char* name) {
+        size_t i = pos.size();
+        tid.push_back(tid_);
+        pos.push_back(pos_);
+        int64_t e = pos_;
+        for (uint32_t k = 0; k < ncig; k++) {
+            uint32_t op = cig[k] & 0xF, l = cig[k] >> 4;
+            if (op == C_M || op == C_EQ || op == C_X || op == C_D || op == C_N) e += l;
+        }
+        end_pos.push_back(e);
+        mapq.push_back(mapq_);
+        flag.push_back(flag_);
+        l_seq.push_back(lseq);
+        n_cigar.push_back(ncig);
+        cigar_off.push_back(cigar_pool.size());
+        cigar_pool.insert(cigar_pool.end(), cig, cig + ncig);
+        seq_off.push_back(seq_pool.size());
+        seq_pool.insert(seq_pool.end(), seq4, seq4 + (lseq + 1) / 2);
+        qual_off.push_back(qual_pool.size());
+        qual_pool.insert(qual_pool.end(), q, q + lseq);
+        qname_off.push_back(qname_pool.size());
+        size_t nl = std::strlen(name);
+        qname_pool.insert(qname_pool.end(), name, name + nl + 1);
+        return i;
+    }
+};
+
+// rust-htslib CigarStringView::read_pos(ref_pos, include_softclips=false, include_dels=false)
+// restated (the crate is not vendored in the reference; call site src/microphasing.rs:106).
+// Returns -1 for None.
+inline int64_t cigar_read_pos(const uint32_t* cig, uint32_t ncig, int64_t read_start, int64_t ref_pos) {
+    int64_t rpos = read_start;  // reference position
+    int64_t qpos = 0;           // position within read
+    uint32_t j = 0;
+    // find the first op that refers to read sequence (M,=,X,I,S); leading H/P are skipped,
+    // a leading D/N is an error in the crate (mapped to "no position" here, as the caller does).
+    for (uint32_t i = 0; i < ncig; i++) {
+        uint32_t op = cig[i] & 0xF;
+        if (op == C_M || op == C_EQ || op == C_X || op == C_I || op == C_S) { j = i; break; }
+        if (op == C_D || op == C_N) return -1;
+        if (op == C_H && i > 0 && i + 1 < ncig) return -1;
+        if (i + 1 == ncig) return -1;  // only pads / hard clips
+    }
+    while (rpos <= ref_pos && j < ncig) {
+        uint32_t op = cig[j] & 0xF;
+        int64_t l = cig[j] >> 4;
+        switch (op) {
+            case C_M: case C_EQ: case C_X:
+                if (rpos <= ref_pos && rpos + l > ref_pos) return qpos + (ref_pos - rpos);
+                rpos += l; qpos += l; j++; break;
+            case C_S: case C_I: qpos += l; j++; break;
+            case C_D: case C_N: rpos += l; j++; break;
+            case C_P: j++; break;
+            case C_H: return -1;  // trailing hard clip (or misplaced one: error -> no position)
+            default: return -1;
+        }
+    }
+    return -1;
+}
+
+// A contig's reference bases, case preserved (bio::io::fasta::IndexedReader::read).
+struct RefContig {
+    std::string name;
+    uint64_t len = 0;
+};
+
+// Everything phase_gene loads for one gene (reference: src/microphasing.rs:895-942).
+struct GeneInput {
+    Gene gene;
+    std::vector<uint8_t> refseq;      // [gene.start, gene.end+100), case preserved
+    std::vector<size_t> reads;        // indices into the ReadStore, BAM file order (mapq NOT yet filtered)
+    std::vector<Variant> variants;    // variant_tree flattened: ascending pos, ALT order within pos
+};
+
+// One output record (reference: src/common.rs:350-373, field order = TSV column order).
+struct IDRecord {
+    std::string id, transcript, gene_id, gene_name, chrom;
+    uint64_t offset = 0, frame = 0;
+    double freq = 0;
+    uint32_t depth = 0, nvar = 0, nsomatic = 0, nvariant_sites = 0, nsomvariant_sites = 0;
+    std::string strand, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
+        germline_aa_change, normal_sequence, mutant_sequence;
+};
+
+// The three output streams of `microphaser somatic` (stdout FASTA, --normal-output FASTA, --tsv).
+struct SomaticOutput {
+    std::string fasta, normal_fasta, tsv;
+    bool tsv_header_written = false;
+    uint64_t n_windows = 0;  // main-ORF print_haplotypes invocations (the benchmark unit)
+};
+
+}  // namespace mp

@@ -1,0 +1,183 @@
+// Small host utilities whose exact output format is part of the parity contract:
+// SHA-1 ids, shortest-round-trip f64 printing (Rust `ryu` pretty format, used by the
+// `csv` crate's serde serializer), FASTA and TSV record writers.
+#pragma once
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "model.hpp"
+
+namespace mp {
+
+// ------------------------------------------------------------------ SHA-1
+// (reference: `sha1 = "0.6"` crate, call sites src/microphasing.rs:667-675, src/common.rs:387-395)
+struct Sha1 {
+    uint32_t h[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+    uint8_t buf[64];
+    uint64_t total = 0;
+    size_t fill = 0;
+    static uint32_t rol(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+    void block(const uint8_t* p) {
+        uint32_t w[80];
+        for (int i = 0; i < 16; i++)
+            w[i] = (uint32_t(p[4 * i]) << 24) | (uint32_t(p[4 * i + 1]) << 16) | (uint32_t(p[4 * i + 2]) << 8) | p[4 * i + 3];
+        for (int i = 16; i < 80; i++) w[i] = rol(w[i - 3] ^ w[i - 8] ^ w[i - 14] ^ w[i - 16], 1);
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+        for (int i = 0; i < 80; i++) {
+            uint32_t f, k;
+            if (i < 20) { f = (b & c) | (~b & d); k = 0x5A827999u; }
+            else if (i < 40) { f = b ^ c ^ d; k = 0x6ED9EBA1u; }
+            else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8F1BBCDCu; }
+            else { f = b ^ c ^ d; k = 0xCA62C1D6u; }
+            uint32_t t = rol(a, 5) + f + e + k + w[i];
+            e = d; d = c; c = rol(b, 30); b = a; a = t;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e;
+    }
+    void update(const void* data, size_t n) {
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        total += n;
+        while (n) {
+            size_t take = 64 - fill < n ? 64 - fill : n;
+            std::memcpy(buf + fill, p, take);
+            fill += take; p += take; n -= take;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    std::string hexdigest() {
+        uint64_t bits = total * 8;
+        uint8_t pad = 0x80;
+        update(&pad, 1);
+        uint8_t z = 0;
+        while (fill != 56) update(&z, 1);
+        uint8_t lenb[8];
+        for (int i = 0; i < 8; i++) lenb[i] = uint8_t(bits >> (56 - 8 * i));
+        update(lenb, 8);
+        char out[41];
+        for (int i = 0; i < 5; i++) std::snprintf(out + 8 * i, 9, "%08x", h[i]);
+        return std::string(out, 40);
+    }
+};
+
+// `format!("{:?}{}{}", &seq, transcript_id, offset)` -> sha1 -> first 15 hex chars + 'F'|'R'
+// (reference: src/microphasing.rs:667-675). `{:?}` of Vec<u8> is "[65, 67, ...]".
+inline std::string haplotype_id(const uint8_t* seq, size_t n, const std::string& transcript_id, uint64_t offset,
+                                char strand_initial) {
+    std::string s = "[";
+    char tmp[8];
+    for (size_t i = 0; i < n; i++) {
+        if (i) s += ", ";
+        int l = std::snprintf(tmp, sizeof tmp, "%u", unsigned(seq[i]));
+        s.append(tmp, l);
+    }
+    s += "]";
+    s += transcript_id;
+    s += std::to_string(offset);
+    Sha1 sh;
+    sh.update(s.data(), s.size());
+    std::string id = sh.hexdigest().substr(0, 15);
+    id.push_back(strand_initial);
+    return id;
+}
+
+// ------------------------------------------------------------------ f64 printing
+// Rust ryu::Buffer::format_finite "pretty" layout (what csv+serde write for an f64 field).
+inline std::string fmt_f64(double v) {
+    if (v != v) return "NaN";
+    if (v == 1.0 / 0.0) return "inf";
+    if (v == -1.0 / 0.0) return "-inf";
+    std::string out;
+    if (std::signbit(v)) { out.push_back('-'); v = -v; }
+    if (v == 0.0) { out += "0.0"; return out; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);  // shortest round-trip
+    std::string s(buf, r.ptr);
+    // parse d.ddddde[+-]xx
+    size_t epos = s.find('e');
+    std::string mant = s.substr(0, epos);
+    int exp10 = std::atoi(s.c_str() + epos + 1);
+    std::string digits;
+    for (char c : mant)
+        if (c != '.') digits.push_back(c);
+    // strip trailing zeros (to_chars shortest never emits them, but be safe)
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    long length = long(digits.size());
+    long kk = exp10 + 1;        // 10^(kk-1) <= v < 10^kk
+    long k = kk - length;       // v = digits * 10^k
+    if (0 <= k && kk <= 16) {
+        out += digits;
+        out.append(size_t(kk - length), '0');
+        out += ".0";
+    } else if (0 < kk && kk <= 16) {
+        out.append(digits, 0, size_t(kk));
+        out.push_back('.');
+        out.append(digits, size_t(kk), std::string::npos);
+    } else if (-5 < kk && kk <= 0) {
+        out += "0.";
+        out.append(size_t(-kk), '0');
+        out += digits;
+    } else if (length == 1) {
+        out += digits;
+        out.push_back('e');
+        out += std::to_string(kk - 1);
+    } else {
+        out.push_back(digits[0]);
+        out.push_back('.');
+        out.append(digits, 1, std::string::npos);
+        out.push_back('e');
+        out += std::to_string(kk - 1);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ writers
+// bio::io::fasta::Writer::write(id, None, seq): ">id\nSEQ\n"
+inline void write_fasta(std::string& out, const std::string& id, const uint8_t* seq, size_t n) {
+    out.push_back('>');
+    out += id;
+    out.push_back('\n');
+    out.append(reinterpret_cast<const char*>(seq), n);
+    out.push_back('\n');
+}
+
+// csv crate, QuoteStyle::Necessary with delimiter '\t'
+inline void tsv_field(std::string& out, const std::string& f) {
+    bool need = false;
+    for (char c : f)
+        if (c == '\t' || c == '"' || c == '\n' || c == '\r') { need = true; break; }
+    if (!need) { out += f; return; }
+    out.push_back('"');
+    for (char c : f) {
+        if (c == '"') out.push_back('"');
+        out.push_back(c);
+    }
+    out.push_back('"');
+}
+
+inline const char* idrecord_header() {
+    return "id\ttranscript\tgene_id\tgene_name\tchrom\toffset\tframe\tfreq\tdepth\tnvar\tnsomatic\tnvariant_sites\t"
+           "nsomvariant_sites\tstrand\tvariant_sites\tsomatic_positions\tsomatic_aa_change\tgermline_positions\t"
+           "germline_aa_change\tnormal_sequence\tmutant_sequence\n";
+}
+
+// csv::Writer::serialize(IDRecord): header on first record only (reference: src/common.rs:350-373)
+inline void write_tsv_record(SomaticOutput& o, const IDRecord& r) {
+    std::string& t = o.tsv;
+    if (!o.tsv_header_written) { t += idrecord_header(); o.tsv_header_written = true; }
+    auto S = [&](const std::string& f) { tsv_field(t, f); t.push_back('\t'); };
+    auto U = [&](uint64_t v) { t += std::to_string(v); t.push_back('\t'); };
+    S(r.id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom);
+    U(r.offset); U(r.frame);
+    t += fmt_f64(r.freq); t.push_back('\t');
+    U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
+    S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change);
+    S(r.germline_positions); S(r.germline_aa_change); S(r.normal_sequence);
+    tsv_field(t, r.mutant_sequence);
+    t.push_back('\n');
+}
+
+}  // namespace mp
