@@ -1,0 +1,89 @@
+/* microphaser_hip.h - C ABI of the MI355X phasing engine (libmicrophaser_hip.so).
+ *
+ * The reference (koesterlab/microphaser, Rust) has no plugin / FFI interface; the seam is cut
+ * at `phase_gene` (reference: src/microphasing.rs:882-893), called once per protein-coding gene
+ * by `phase` (src/microphasing.rs:1943-2131) from `run_somatic` (src/main.rs:60-102).
+ * Every entry point below names the reference interface it replaces. Conventions:
+ *   - plain C types only; every function returns 0 on success, non-zero on error
+ *     (message via mp_last_error); nothing throws or aborts across the boundary
+ *     (the reference propagates Box<dyn Error> to main -> exit(1), src/main.rs:260-265);
+ *   - the caller owns inputs for the duration of a call, the library owns what it returns
+ *     until the matching *_free;
+ *   - one mp_ctx per GPU; a ctx is not shared between host threads; no global state;
+ *   - there is NO CPU fallback: without a gfx950 device mp_batch_run fails.
+ */
+#ifndef MICROPHASER_HIP_H
+#define MICROPHASER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mp_ctx mp_ctx;
+typedef struct mp_dataset mp_dataset;
+typedef struct mp_batch mp_batch;
+typedef struct mp_results mp_results;
+
+enum { MP_MODE_SOMATIC = 0 };
+
+/* Context. device >= 0: HIP device ordinal. device == -1: host-only context (data sets and
+ * planning work, anything that needs the kernels fails loudly). */
+int mp_create(int device, mp_ctx** out);
+void mp_destroy(mp_ctx* ctx);
+const char* mp_last_error(const mp_ctx* ctx);
+
+/* Inputs of `microphaser somatic` (reference: run_somatic opens them, src/main.rs:71-87;
+ * phase_gene loads per gene: refseq :895-901, reads :905-920, variants :932-942).
+ * gtf_path == NULL reads the GTF from stdin like the reference. */
+int mp_dataset_load(mp_ctx* ctx, const char* bam_path, const char* vcf_path, const char* fasta_path, const char* gtf_path,
+                    int unsupported_allele_warning_only, mp_dataset** out);
+/* Deterministic synthetic exome: the benchmark workload. */
+int mp_dataset_synth(mp_ctx* ctx, uint64_t seed, uint32_t n_transcripts, double depth, double var_spacing, mp_dataset** out);
+/* Write prefix.{bam,vcf,gtf,fa,fa.fai} so that a CLI run sees the same inputs. */
+int mp_dataset_write(mp_ctx* ctx, const mp_dataset* ds, const char* prefix);
+uint32_t mp_dataset_num_genes(const mp_dataset* ds);   /* protein-coding genes, GTF order */
+uint64_t mp_dataset_num_reads(const mp_dataset* ds);
+void mp_dataset_free(mp_dataset* ds);
+
+/* Statistics of one pass of the hot path (filled by mp_batch_run). */
+typedef struct mp_run_stats {
+    double k1_ms, k2_ms, k3_ms, total_ms;  /* HIP-event times on the launch stream */
+    uint64_t n_windows_planned;            /* main-ORF windows in the speculative schedule */
+    uint64_t n_steps, n_transcripts, n_reads, n_variants;
+    uint64_t n_groups, n_records;
+    uint64_t bytes_k1, bytes_k2, bytes_k3; /* algorithmic HBM bytes per launch */
+    uint64_t hbm_bytes;                    /* device memory held by the batch */
+    uint32_t rows_per_lane, mask_words, attempts;
+} mp_run_stats;
+
+/* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM
+ * (replaces the per-gene loading + the data-independent part of the window scheduler,
+ * src/microphasing.rs:905-1342). */
+int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, uint32_t gene_lo, uint32_t gene_hi,
+                    mp_batch** out);
+/* One pass of the hot path over the resident batch: read pileup -> haplotype bitsets,
+ * sliding-window haplotype counting, window sequences (replaces ObservationMatrix::{cleanup_reads,
+ * shrink_left, push_read, extend_right} and the count + sequence phases of print_haplotypes,
+ * src/microphasing.rs:220-343, 373-603). Inputs and results stay in HBM. */
+int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* stats);
+/* Copy the results back and produce the reference's three output streams (replaces the rest of
+ * print_haplotypes + phase_gene: :604-880, :1345-1941, src/common.rs:376-568). */
+int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out);
+void mp_batch_free(mp_batch* batch);
+
+/* Convenience: create + run + results for all genes (what `microphaser somatic` does). */
+int mp_phase_dataset(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, mp_results** out);
+
+const char* mp_results_fasta(const mp_results* r, size_t* len);         /* stdout FASTA        */
+const char* mp_results_normal_fasta(const mp_results* r, size_t* len);  /* --normal-output     */
+const char* mp_results_tsv(const mp_results* r, size_t* len);           /* --tsv               */
+uint64_t mp_results_windows(const mp_results* r);  /* main-ORF print_haplotypes calls actually made */
+void mp_results_free(mp_results* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,217 @@
+"""microphaser_amd - MI355X-native phasing engine behind microphaser's `somatic` path.
+
+Thin ctypes binding of the C ABI in include/microphaser_hip.h (libmicrophaser_hip.so, built
+in-tree by microphaser_amd/csrc/Makefile). Python is plumbing only: everything on the hot path
+runs in the HIP kernels; the host side (planner, consumer, ingest, CLI) is C++.
+
+There is no CPU fallback: without the built library import fails, without a GPU the kernels'
+entry points fail loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmicrophaser_hip.so")
+CLI_PATH = os.path.join(LIB_DIR, "microphaser")
+
+MODE_SOMATIC = 0
+
+
+def build(verbose=False):
+    """Compile the HIP library + CLI for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    r = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libmicrophaser_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+
+
+class RunStats(ctypes.Structure):
+    _fields_ = [
+        ("k1_ms", ctypes.c_double), ("k2_ms", ctypes.c_double), ("k3_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+        ("n_windows_planned", ctypes.c_uint64),
+        ("n_steps", ctypes.c_uint64), ("n_transcripts", ctypes.c_uint64), ("n_reads", ctypes.c_uint64), ("n_variants", ctypes.c_uint64),
+        ("n_groups", ctypes.c_uint64), ("n_records", ctypes.c_uint64),
+        ("bytes_k1", ctypes.c_uint64), ("bytes_k2", ctypes.c_uint64), ("bytes_k3", ctypes.c_uint64),
+        ("hbm_bytes", ctypes.c_uint64),
+        ("rows_per_lane", ctypes.c_uint32), ("mask_words", ctypes.c_uint32), ("attempts", ctypes.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C microphaser_amd/csrc). There is no fallback path." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, cp, u32, u64, i32, dbl = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_double
+    pp = ctypes.POINTER(vp)
+    sig = {
+        "mp_create": (i32, [i32, pp]),
+        "mp_destroy": (None, [vp]),
+        "mp_last_error": (cp, [vp]),
+        "mp_dataset_load": (i32, [vp, cp, cp, cp, cp, i32, pp]),
+        "mp_dataset_synth": (i32, [vp, u64, u32, dbl, dbl, pp]),
+        "mp_dataset_write": (i32, [vp, vp, cp]),
+        "mp_dataset_num_genes": (u32, [vp]),
+        "mp_dataset_num_reads": (u64, [vp]),
+        "mp_dataset_free": (None, [vp]),
+        "mp_batch_create": (i32, [vp, vp, i32, u64, u32, u32, pp]),
+        "mp_batch_run": (i32, [vp, vp, ctypes.POINTER(RunStats)]),
+        "mp_batch_results": (i32, [vp, vp, pp]),
+        "mp_batch_free": (None, [vp]),
+        "mp_phase_dataset": (i32, [vp, vp, i32, u64, pp]),
+        "mp_results_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_results_normal_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_results_tsv": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_results_windows": (u64, [vp]),
+        "mp_results_free": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+C_ABI_SYMBOLS = [
+    "mp_create", "mp_destroy", "mp_last_error", "mp_dataset_load", "mp_dataset_synth", "mp_dataset_write",
+    "mp_dataset_num_genes", "mp_dataset_num_reads", "mp_dataset_free", "mp_batch_create", "mp_batch_run",
+    "mp_batch_results", "mp_batch_free", "mp_phase_dataset", "mp_results_fasta", "mp_results_normal_fasta",
+    "mp_results_tsv", "mp_results_windows", "mp_results_free",
+]
+
+
+class MicrophaserError(RuntimeError):
+    pass
+
+
+class Context:
+    """One per GPU (device >= 0) or host-only (device = -1: planning works, kernels fail loudly)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        rc = lib().mp_create(device, ctypes.byref(self._h))
+        if rc != 0:
+            msg = lib().mp_last_error(self._h).decode()
+            lib().mp_destroy(self._h)
+            self._h = None
+            raise MicrophaserError(msg)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MicrophaserError(lib().mp_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().mp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, bam, vcf, fasta, gtf, unsupported_allele_warning_only=False):
+        h = ctypes.c_void_p()
+        self._check(lib().mp_dataset_load(self._h, bam.encode(), vcf.encode(), fasta.encode(), gtf.encode(),
+                                          int(unsupported_allele_warning_only), ctypes.byref(h)))
+        return Dataset(self, h)
+
+    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4):
+        h = ctypes.c_void_p()
+        self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))
+        return Dataset(self, h)
+
+
+class Dataset:
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+
+    @property
+    def num_genes(self):
+        return lib().mp_dataset_num_genes(self._h)
+
+    @property
+    def num_reads(self):
+        return lib().mp_dataset_num_reads(self._h)
+
+    def write(self, prefix):
+        self.ctx._check(lib().mp_dataset_write(self.ctx._h, self._h, prefix.encode()))
+
+    def batch(self, window_len=27, gene_lo=0, gene_hi=None, mode=MODE_SOMATIC):
+        h = ctypes.c_void_p()
+        hi = self.num_genes if gene_hi is None else gene_hi
+        self.ctx._check(lib().mp_batch_create(self.ctx._h, self._h, mode, window_len, gene_lo, hi, ctypes.byref(h)))
+        return Batch(self.ctx, h, self)
+
+    def phase(self, window_len=27, mode=MODE_SOMATIC):
+        """`microphaser somatic` on this data set: returns Results (fasta, normal_fasta, tsv)."""
+        h = ctypes.c_void_p()
+        self.ctx._check(lib().mp_phase_dataset(self.ctx._h, self._h, mode, window_len, ctypes.byref(h)))
+        return Results(h)
+
+    def close(self):
+        if self._h:
+            lib().mp_dataset_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    def __init__(self, ctx, h, ds):
+        self.ctx, self._h, self._ds = ctx, h, ds
+
+    def run(self):
+        st = RunStats()
+        self.ctx._check(lib().mp_batch_run(self.ctx._h, self._h, ctypes.byref(st)))
+        return st
+
+    def results(self):
+        h = ctypes.c_void_p()
+        self.ctx._check(lib().mp_batch_results(self.ctx._h, self._h, ctypes.byref(h)))
+        return Results(h)
+
+    def close(self):
+        if self._h:
+            lib().mp_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Results:
+    def __init__(self, h):
+        self._h = h
+        n = ctypes.c_size_t()
+        L = lib()
+        p = L.mp_results_fasta(h, ctypes.byref(n))
+        self.fasta = ctypes.string_at(p, n.value) if n.value else b""
+        p = L.mp_results_normal_fasta(h, ctypes.byref(n))
+        self.normal_fasta = ctypes.string_at(p, n.value) if n.value else b""
+        p = L.mp_results_tsv(h, ctypes.byref(n))
+        self.tsv = ctypes.string_at(p, n.value) if n.value else b""
+        self.windows = L.mp_results_windows(h)
+        L.mp_results_free(h)
+        self._h = None

@@ -1,0 +1,66 @@
+// Host-side packed batch: what mp_phase_genes uploads to HBM. Built by the planner (plan.cpp)
+// from the per-gene inputs phase_gene would load (reference: src/microphasing.rs:895-942).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "model.hpp"
+#include "plan.hpp"
+#include "walk.hpp"
+
+namespace mp {
+
+struct ExonPlan {           // host-only: geometry of one scheduled exon pass
+    ExonGeom geom;
+    uint32_t tx = 0;
+};
+
+struct GeneHost {           // host-only per-gene bookkeeping
+    const GeneInput* input = nullptr;
+    uint64_t max_read_len = 0;
+    uint32_t read_off = 0, n_reads = 0;   // into the batch read arrays
+    uint32_t var_off = 0, n_vars = 0;
+    uint64_t ref_off = 0;
+    uint32_t tx_off = 0, n_tx = 0;        // coding transcripts only
+    std::vector<uint32_t> tx_src;         // index into gene.transcripts for each planned transcript
+};
+
+struct Batch {
+    uint64_t window_len = 27;
+    // ---- genes
+    std::vector<GeneHost> genes;
+    std::vector<uint32_t> g_read_off, g_var_off, g_start;  // per gene (+1 for the offsets)
+    std::vector<uint64_t> g_ref_off;
+    // ---- reads (gene-major, start-sorted, mapq-filtered)
+    std::vector<uint32_t> r_pos, r_end, r_lseq, r_ncig, r_dup;
+    std::vector<uint64_t> r_cigoff, r_seqoff, r_qualoff;
+    std::vector<uint32_t> cigar_pool;
+    std::vector<uint8_t> seq_pool, qual_pool;
+    std::vector<size_t> r_src;            // host-only: ReadStore index of each batch read
+    // ---- variants
+    std::vector<uint32_t> v_pos, v_info, v_len, v_insoff, v_rev2fwd;
+    std::vector<uint8_t> ins_pool;
+    // ---- refseq
+    std::vector<uint8_t> ref_pool;
+    // ---- plan
+    std::vector<TxDev> tx;
+    std::vector<Step> steps;
+    std::vector<WinStatic> wins;
+    std::vector<ExonPlan> exons;
+    std::vector<uint8_t> str_pool;        // transcript ids
+    std::vector<uint32_t> tx_order;       // launch order (longest first)
+    // ---- sizing
+    uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks
+    uint32_t max_rows_bound = 0;          // upper bound on simultaneously live rows (+pending) of any transcript
+    uint64_t n_main_windows = 0;          // main-ORF printing steps in the plan (speculative upper bound)
+
+    // algorithmic byte counts for the roofline line
+    uint64_t bytes_k1_in() const;
+    uint64_t bytes_k1_out() const;
+};
+
+// Build the batch + plan for a list of loaded genes. `mapq_min` = 5 for `somatic`
+// (reference: src/microphasing.rs:910), 0 for `normal`.
+void build_batch(const std::vector<GeneInput>& genes, const ReadStore& reads, uint64_t window_len, uint8_t mapq_min, Batch& out);
+
+}  // namespace mp

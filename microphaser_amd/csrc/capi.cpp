@@ -1,0 +1,179 @@
+// C ABI (include/microphaser_hip.h) over the planner / device context / consumer.
+#include "../../include/microphaser_hip.h"
+
+#include <fstream>
+#include <iostream>
+#include <memory>
+
+#include "batch.hpp"
+#include "consume.hpp"
+#include "device.hpp"
+#include "synth.hpp"
+
+using namespace mp;
+
+struct mp_ctx {
+    std::unique_ptr<DeviceContext> dev;
+    std::string err;
+};
+struct mp_dataset {
+    Dataset ds;
+};
+struct mp_batch {
+    Batch batch;
+    std::vector<GeneInput> genes;  // the slice [gene_lo, gene_hi) (GeneHost::input points into it)
+    const ReadStore* reads = nullptr;
+    bool uploaded = false, ran = false;
+    RunTiming timing;
+};
+struct mp_results {
+    SomaticOutput out;
+};
+
+namespace {
+template <class F>
+int guarded(mp_ctx* ctx, F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->err = e.what();
+        return 1;
+    } catch (...) {
+        if (ctx) ctx->err = "unknown error";
+        return 1;
+    }
+}
+DeviceContext& need_device(mp_ctx* ctx) {
+    if (!ctx->dev) throw Error("this context has no GPU (created with device -1): the phasing kernels need an MI355X, there is no CPU fallback");
+    return *ctx->dev;
+}
+}  // namespace
+
+extern "C" {
+
+int mp_create(int device, mp_ctx** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    std::unique_ptr<mp_ctx> c(new mp_ctx());
+    int rc = guarded(c.get(), [&] {
+        if (device >= 0) c->dev.reset(new DeviceContext(device));
+    });
+    // hand the context back even on failure so the caller can read the message
+    *out = c.release();
+    return rc;
+}
+
+void mp_destroy(mp_ctx* ctx) { delete ctx; }
+
+const char* mp_last_error(const mp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mp_dataset_load(mp_ctx* ctx, const char* bam, const char* vcf, const char* fasta, const char* gtf, int warn_only, mp_dataset** out) {
+    return guarded(ctx, [&] {
+        std::unique_ptr<mp_dataset> d(new mp_dataset());
+        if (gtf) {
+            std::ifstream in(gtf);
+            if (!in) throw Error(std::string("cannot open ") + gtf);
+            dataset_load_files(bam, vcf, fasta, in, warn_only != 0, d->ds);
+        } else {
+            dataset_load_files(bam, vcf, fasta, std::cin, warn_only != 0, d->ds);
+        }
+        *out = d.release();
+    });
+}
+
+int mp_dataset_synth(mp_ctx* ctx, uint64_t seed, uint32_t n_transcripts, double depth, double var_spacing, mp_dataset** out) {
+    return guarded(ctx, [&] {
+        std::unique_ptr<mp_dataset> d(new mp_dataset());
+        SynthConfig cfg;
+        cfg.seed = seed;
+        cfg.n_transcripts = n_transcripts;
+        cfg.depth = depth;
+        cfg.var_spacing = var_spacing;
+        synth_generate(cfg, d->ds);
+        *out = d.release();
+    });
+}
+
+int mp_dataset_write(mp_ctx* ctx, const mp_dataset* ds, const char* prefix) {
+    return guarded(ctx, [&] { dataset_write_files(ds->ds, prefix); });
+}
+
+uint32_t mp_dataset_num_genes(const mp_dataset* ds) { return ds ? uint32_t(ds->ds.genes.size()) : 0; }
+uint64_t mp_dataset_num_reads(const mp_dataset* ds) { return ds ? uint64_t(ds->ds.bam.reads.size()) : 0; }
+void mp_dataset_free(mp_dataset* ds) { delete ds; }
+
+int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, uint32_t gene_lo, uint32_t gene_hi, mp_batch** out) {
+    return guarded(ctx, [&] {
+        if (mode != MP_MODE_SOMATIC) throw Error("only MP_MODE_SOMATIC is implemented");
+        if (gene_hi > ds->ds.genes.size()) gene_hi = uint32_t(ds->ds.genes.size());
+        if (gene_lo > gene_hi) gene_lo = gene_hi;
+        std::unique_ptr<mp_batch> b(new mp_batch());
+        b->genes.assign(ds->ds.genes.begin() + gene_lo, ds->ds.genes.begin() + gene_hi);
+        b->reads = &ds->ds.bam.reads;
+        build_batch(b->genes, *b->reads, window_len, /*mapq_min=*/5, b->batch);  // src/microphasing.rs:910
+        if (ctx->dev) {
+            ctx->dev->upload(b->batch);
+            b->uploaded = true;
+        }
+        *out = b.release();
+    });
+}
+
+int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        if (!batch->uploaded) { dev.upload(batch->batch); batch->uploaded = true; }
+        dev.run(batch->timing);
+        batch->ran = true;
+        if (st) {
+            const Batch& b = batch->batch;
+            const RunTiming& t = batch->timing;
+            *st = mp_run_stats();
+            st->k1_ms = t.k1_ms; st->k2_ms = t.k2_ms; st->k3_ms = t.k3_ms; st->total_ms = t.total_ms;
+            st->n_windows_planned = b.n_main_windows;
+            st->n_steps = b.steps.size(); st->n_transcripts = b.tx.size();
+            st->n_reads = b.r_pos.size(); st->n_variants = b.v_pos.size();
+            st->n_groups = t.n_group_slots; st->n_records = t.n_recs;
+            st->bytes_k1 = b.bytes_k1_in() + b.bytes_k1_out();
+            // K2: step records + per-row mask/core loads + window headers + groups
+            st->bytes_k2 = b.steps.size() * sizeof(Step) + b.r_pos.size() * (20 + 16ull * b.mask_words) +
+                           b.wins.size() * sizeof(WinDyn) + t.n_group_slots * (sizeof(Group) + 4);
+            // K3: group + window + refseq window reads, summary + record writes
+            st->bytes_k3 = t.n_group_slots * (sizeof(Group) + 4 + sizeof(WinStatic) + 32 + sizeof(GroupSum)) + t.n_recs * sizeof(HapRec);
+            st->hbm_bytes = dev.hbm_bytes();
+            st->rows_per_lane = uint32_t(t.rows_per_lane); st->mask_words = b.mask_words; st->attempts = t.attempts;
+        }
+    });
+}
+
+int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        if (!batch->ran) throw Error("mp_batch_results before mp_batch_run");
+        HostResults hr;
+        dev.download(hr);
+        std::unique_ptr<mp_results> r(new mp_results());
+        consume_batch(batch->batch, hr, r->out);
+        *out = r.release();
+    });
+}
+
+void mp_batch_free(mp_batch* batch) { delete batch; }
+
+int mp_phase_dataset(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, mp_results** out) {
+    mp_batch* b = nullptr;
+    int rc = mp_batch_create(ctx, ds, mode, window_len, 0, mp_dataset_num_genes(ds), &b);
+    if (rc == 0) rc = mp_batch_run(ctx, b, nullptr);
+    if (rc == 0) rc = mp_batch_results(ctx, b, out);
+    mp_batch_free(b);
+    return rc;
+}
+
+const char* mp_results_fasta(const mp_results* r, size_t* len) { if (len) *len = r->out.fasta.size(); return r->out.fasta.data(); }
+const char* mp_results_normal_fasta(const mp_results* r, size_t* len) { if (len) *len = r->out.normal_fasta.size(); return r->out.normal_fasta.data(); }
+const char* mp_results_tsv(const mp_results* r, size_t* len) { if (len) *len = r->out.tsv.size(); return r->out.tsv.data(); }
+uint64_t mp_results_windows(const mp_results* r) { return r->out.n_windows; }
+void mp_results_free(mp_results* r) { delete r; }
+
+}  // extern "C"

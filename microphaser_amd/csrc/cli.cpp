@@ -1,0 +1,74 @@
+// `microphaser` command line over the C ABI - same surface as the reference binary for the
+// accelerated path (reference: src/cli.yaml, src/somatic_cli.yaml:9-50, src/main.rs:34-102):
+//   microphaser somatic <tumor.bam> -r/--ref F -b/--variants V [-t/--tsv info.tsv]
+//              [-n/--normal-output normal.fasta] [-w/--window-len 27] [-u] [-v]  < GTF  > FASTA
+// exit status 1 on error, message on stderr (src/main.rs:260-265).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/microphaser_hip.h"
+
+static int fail(mp_ctx* ctx, const char* what) {
+    std::fprintf(stderr, "%s: %s\n", what, mp_last_error(ctx));
+    return 1;
+}
+
+static bool write_file(const std::string& path, const char* data, size_t n) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fwrite(data, 1, n, f);
+    std::fclose(f);
+    return true;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: microphaser somatic <tumor.bam> --ref <fasta> --variants <vcf> [--tsv info.tsv] [--normal-output normal.fasta] [--window-len 27] < gtf > fasta\n");
+        return 1;
+    }
+    std::string sub = argv[1];
+    if (sub != "somatic") {
+        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic` is available\n", sub.c_str());
+        return 1;
+    }
+    std::string bam, vcf, ref, tsv = "info.tsv", normal = "normal.fasta";
+    unsigned long long window_len = 27;
+    int warn_only = 0, device = 0;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&]() -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(1); }
+            return argv[++i];
+        };
+        if (a == "--variants" || a == "-b") vcf = val();
+        else if (a == "--ref" || a == "-r") ref = val();
+        else if (a == "--tsv" || a == "-t") tsv = val();
+        else if (a == "--normal-output" || a == "-n") normal = val();
+        else if (a == "--window-len" || a == "-w") window_len = std::strtoull(val(), nullptr, 10);
+        else if (a == "--unsupported-allele-warning-only" || a == "-u") warn_only = 1;
+        else if (a == "--device") device = std::atoi(val());
+        else if (a == "-v" || a == "--verbose") {}
+        else if (!a.empty() && a[0] != '-') bam = a;
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
+    }
+    if (bam.empty() || vcf.empty() || ref.empty()) { std::fprintf(stderr, "tumor BAM, --variants and --ref are required\n"); return 1; }
+    mp_ctx* ctx = nullptr;
+    if (mp_create(device, &ctx) != 0) { int rc = fail(ctx, "mp_create"); mp_destroy(ctx); return rc; }
+    mp_dataset* ds = nullptr;
+    if (mp_dataset_load(ctx, bam.c_str(), vcf.c_str(), ref.c_str(), nullptr, warn_only, &ds) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
+    mp_results* res = nullptr;
+    if (mp_phase_dataset(ctx, ds, MP_MODE_SOMATIC, window_len, &res) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
+    size_t n = 0;
+    const char* p = mp_results_fasta(res, &n);
+    std::fwrite(p, 1, n, stdout);
+    p = mp_results_normal_fasta(res, &n);
+    if (!write_file(normal, p, n)) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
+    p = mp_results_tsv(res, &n);
+    if (!write_file(tsv, p, n)) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
+    mp_results_free(res);
+    mp_dataset_free(ds);
+    mp_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,459 @@
+// Consumer: turns the kernels' per-window results into the reference's output streams.
+//
+// It re-runs the window scheduler (walk.hpp) and answers every print_haplotypes call
+// (reference: src/microphasing.rs:353-880) from the device results:
+//   * haplotype keys / counts / depth      <- K2 (WinDyn + Group)
+//   * sequences, variant profile, stop, id  <- K3 (GroupSum + HapRec)
+// and keeps, on the host, exactly the state the reference threads through the windows of a
+// transcript: frameshift_frequencies, the `frame` / `shift_in_window` latches, termination,
+// hap_vec / prev_hap_vec and the splice-side merge (:1505-1908, src/common.rs:376-568).
+// No sequence is built and no read is touched on the host.
+#include "consume.hpp"
+
+#include <cmath>
+#include <limits>
+#include <tuple>
+
+#include "util.hpp"
+
+namespace mp {
+
+namespace {
+
+std::vector<std::string> split_bar(const std::string& s) {
+    std::vector<std::string> out;
+    size_t a = 0;
+    for (;;) {
+        size_t b = s.find('|', a);
+        if (b == std::string::npos) { out.push_back(s.substr(a)); break; }
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+    return out;
+}
+std::string join_bar(const std::vector<std::string>& v) {
+    std::string s;
+    for (size_t i = 0; i < v.size(); i++) { if (i) s += "|"; s += v[i]; }
+    return s;
+}
+
+// IDRecord::update (reference: src/common.rs:376-526)
+IDRecord record_update(const IDRecord& self, const IDRecord& rec, uint64_t offset, uint64_t frame, double freq,
+                       const std::string& wt_seq, const std::string& mt_seq, uint64_t wlen) {
+    IDRecord r;
+    r.id = haplotype_id(reinterpret_cast<const uint8_t*>(mt_seq.data()), mt_seq.size(), self.transcript, offset,
+                        self.strand.empty() ? '?' : self.strand[0]);
+    auto num = [](const std::string& p) { return uint64_t(std::strtoull(p.c_str(), nullptr, 10)); };
+    auto at = [](const std::vector<std::string>& v, size_t c) -> const std::string& {
+        if (c >= v.size()) throw Error("reference would panic: index out of bounds (aa_change)");
+        return v[c];
+    };
+    const bool fwd = self.strand == "Forward";
+    std::vector<std::string> s_p, g_p, s_aa, g_aa;
+    uint32_t nvariants = 0, nsomatic = 0;
+    {
+        auto aa = split_bar(self.somatic_aa_change);
+        size_t c = 0;
+        for (const auto& p : split_bar(self.somatic_positions)) {
+            if (p.empty()) break;
+            bool active = fwd ? (self.offset + offset <= num(p)) : (self.offset + wlen - offset >= num(p));
+            if (active) { s_p.push_back(p); s_aa.push_back(at(aa, c)); nsomatic++; nvariants++; }
+            c++;
+        }
+    }
+    {
+        auto aa = split_bar(rec.somatic_aa_change);
+        size_t c = 0;
+        for (const auto& p : split_bar(rec.somatic_positions)) {
+            if (p.empty()) break;
+            bool active = fwd ? (rec.offset + offset >= num(p)) : (rec.offset + wlen - 3 - offset <= num(p));
+            if (active) { s_p.push_back(p); s_aa.push_back(at(aa, c)); nsomatic++; nvariants++; }
+            c++;
+        }
+    }
+    {
+        auto aa = split_bar(self.germline_aa_change);
+        size_t c = 0;
+        for (const auto& p : split_bar(self.germline_positions)) {
+            if (p.empty()) break;
+            if (self.offset + offset <= num(p)) { g_p.push_back(p); g_aa.push_back(at(aa, c)); nvariants++; }
+            c++;
+        }
+    }
+    {
+        auto aa = split_bar(rec.germline_aa_change);
+        size_t c = 0;
+        for (const auto& p : split_bar(rec.germline_positions)) {
+            if (p.empty()) break;
+            if (rec.offset >= num(p) - offset) { g_p.push_back(p); g_aa.push_back(at(aa, c)); nvariants++; }
+            c++;
+        }
+    }
+    r.transcript = self.transcript; r.gene_id = self.gene_id; r.gene_name = self.gene_name; r.chrom = self.chrom;
+    r.offset = fwd ? self.offset + offset : rec.offset + wlen + 3 - offset;
+    r.frame = frame;
+    r.freq = freq;
+    r.depth = (rec.depth == 0 || self.depth == 0) ? 0 : (rec.depth + self.depth) / 2;
+    r.nvar = nvariants;
+    r.nsomatic = nsomatic;
+    r.nvariant_sites = self.nvariant_sites + rec.nvariant_sites;
+    r.nsomvariant_sites = self.nsomvariant_sites + rec.nsomvariant_sites;
+    r.strand = self.strand;
+    std::string vr = self.variant_sites + "|" + rec.variant_sites;
+    if (!vr.empty() && vr.front() == '|') vr.erase(vr.begin());
+    if (!vr.empty() && vr.back() == '|') vr.pop_back();
+    r.variant_sites = vr;
+    r.somatic_positions = join_bar(s_p); r.somatic_aa_change = join_bar(s_aa);
+    r.germline_positions = join_bar(g_p); r.germline_aa_change = join_bar(g_aa);
+    r.normal_sequence = wt_seq;
+    r.mutant_sequence = mt_seq;
+    return r;
+}
+
+// IDRecord::add_freq (reference: src/common.rs:528-568)
+IDRecord record_add_freq(const IDRecord& self, double freq) {
+    IDRecord r = self;
+    r.nvar = self.nvar == 0 ? self.nvar : (freq > 0.0 ? self.nvar - 1 : self.nvar);
+    r.nsomatic = r.nvar < self.nsomatic ? self.nsomatic - 1 : self.nsomatic;
+    r.freq = self.freq > 0.5 ? self.freq : self.freq + freq;
+    return r;
+}
+
+struct ConsumerHooks {
+    const Batch& b;
+    const HostResults& res;
+    const GeneHost& gh;
+    const Gene& gene;
+    const Transcript& transcript;
+    const TxDev& T;
+    SomaticOutput& out;
+    uint64_t window_len;
+    size_t next_step = 0, cur_step = 0;
+    bool is_fwd;
+
+    void on_exon(const ExonGeom&) {}
+
+    void on_step(const ExonGeom&, const StepGeom& sg, const std::vector<size_t>&) {
+        if (next_step >= T.n_steps) throw Error("internal error: consumer walked past the planned schedule");
+        cur_step = T.step_off + next_step++;
+        const Step& st = b.steps[cur_step];
+        if (st.sso != uint32_t(sg.sso) || uint64_t(st.wlen) != sg.splice_end - sg.sso)
+            throw Error("internal error: consumer and planner schedules diverged");
+    }
+
+    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame_in, FsFreq fsf,
+                                                 bool is_first_exon_window) {
+        const Step& st = b.steps[cur_step];
+        if (!(st.flags & SF_PRINT)) throw Error("internal error: print_haplotypes at a step the planner did not schedule");
+        const WinStatic& ws = b.wins[st.win];
+        const WinDyn& wd = res.win_dyn[st.win];
+        if (!(wd.flags & WD_DONE)) throw Error("internal error: window was not computed on the device");
+        if (frame_in == 0) out.n_windows++;
+        const std::vector<Variant>& gvars = gh.input->variants;
+        const uint32_t ncols = ws.ncols;
+        // window variants in ascending position (print_haplotypes order, :373-379)
+        std::vector<const Variant*> variants(ncols);
+        for (uint32_t j = 0; j < ncols; j++) {
+            uint32_t dq = is_fwd ? j : ncols - 1 - j;
+            uint32_t tr = ws.col_lo + dq;
+            uint32_t f = is_fwd ? tr : b.v_rev2fwd[gh.var_off + tr];
+            variants[j] = &gvars[f];
+        }
+        // haplotype keys of this call (:383-411) from the device groups (ascending (hap, frame0, f1nz))
+        struct Key { uint64_t hap, hframe; size_t count; uint64_t slot; };
+        std::vector<Key> keys;
+        size_t frame_depth = 0;
+        uint64_t frame = frame_in;
+        uint64_t zero_slot = ~0ull;
+        for (uint32_t k = 0; k < wd.ngroups; k++) {
+            uint64_t slot = uint64_t(wd.group_off) + k;
+            const Group& G = res.groups[slot];
+            if (G.hap == 0 && zero_slot == ~0ull) zero_slot = slot;
+            if (G.count == 0) continue;
+            uint64_t f0 = G.aux >> 1;
+            bool f1nz = G.aux & 1;
+            if (frame > 0 && f0 != frame && f1nz) continue;
+            frame_depth += G.count;
+            uint64_t kf = frame > 0 ? frame : f0;
+            if (!keys.empty() && keys.back().hap == G.hap && keys.back().hframe == kf) keys.back().count += G.count;
+            else keys.push_back({G.hap, kf, G.count, slot});
+        }
+        if (keys.empty()) {  // :429-431
+            if (zero_slot == ~0ull) throw Error("internal error: reference haplotype missing from device results");
+            keys.push_back({0, 0, 0, zero_slot});
+        }
+        const char* strand = is_fwd ? "Forward" : "Reverse";
+        const bool has_frameshift = frame > 0;
+        const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
+        const uint64_t wl = eg.ewl;  // print_haplotypes' window_len parameter (:1421)
+        const bool boundary = (ws.flags & (SF_FIRST_EXON_WIN | SF_LAST_EXON_WIN | SF_SHORT_EXON)) != 0;
+        std::vector<HapSeq> haplotypes_vec;
+        uint64_t shift_in_window = 0;
+        for (const Key& key : keys) {
+            const GroupSum& gs = res.gsum[key.slot];
+            if (!(gs.flags & GS_VALID)) throw Error("internal error: haplotype was not processed by the window-sequence kernel");
+            const HapRec* rec = (gs.flags & GS_HAS_REC) ? &res.recs[gs.rec] : nullptr;
+            const bool indel = gs.flags & GS_INDEL, insertion = gs.flags & GS_INSERTION, stop_gain = gs.flags & GS_STOP;
+            const bool differs = gs.flags & GS_DIFFERS, broke = gs.flags & GS_BROKE;
+            if (ws.need_recs && !rec) throw Error("internal error: missing haplotype record for an indel window");
+            const uint32_t n_somatic = rec ? rec->nsom : 0, n_variants = rec ? rec->nvar : 0;
+            const double freq = key.count == 0 ? 0.0 : double(key.count) / double(frame_depth);
+            bool shift_is_set = false;
+            if (rec) {  // shift_in_window latch and frameshift events of the sequence walk (:479-502)
+                uint32_t visited = rec->prof_len + (broke ? 1u : 0u);
+                for (uint32_t j = 0; j < visited && j < ncols; j++) {
+                    const Variant& v = *variants[j];
+                    shift_in_window = shift_in_window > 0 ? shift_in_window : v.frameshift();
+                    bool set = j < rec->prof_len ? ((rec->prof_set >> j) & 1) : true;
+                    if (set && shift_in_window > 0) {
+                        shift_is_set = true;
+                        fsf[v.frameshift()] = {freq, !v.is_germline};
+                        fsf[0] = {1.0 - freq, false};
+                    }
+                }
+            }
+            double frame_frequency = freq;  // :605-631
+            if (shift_is_set && frame == 0) frame = shift_in_window;
+            fsf.emplace(frame, std::make_pair(0.0, false));
+            if (shift_in_window == 0) frame_frequency = freq * fsf.at(frame).first;
+            if (shift_in_window == 0 && key.hframe > 0 && frame == 0) frame_frequency = 0.0;
+            const bool germ_cleared = (indel && insertion) || (shift_in_window == 0 && (fsf.at(frame).second || (has_frameshift && differs)));
+            const uint64_t seq_len = rec ? rec->seq_len : ws.wlen;
+            const uint64_t germ_len = germ_cleared ? 0 : (rec ? rec->germ_len : ws.wlen);
+            const bool germ_ne_seq = germ_cleared ? (seq_len != 0) : differs;
+            const uint64_t this_window_len = seq_len < wl ? seq_len : wl;
+            const uint64_t normal_window_len = indel ? (germ_len < wl ? germ_len : wl) : this_window_len;
+            // peptides are only materialised when something can observe them
+            const bool emit_pre = (n_somatic > 0 || has_frameshift) && !eg.is_short && germ_ne_seq && (!stop_gain || has_frameshift);
+            std::string normal_peptide, neopeptide;
+            const bool need_strings = rec && (indel || boundary || emit_pre);
+            if ((indel || boundary || emit_pre) && !rec) throw Error("internal error: missing haplotype record");
+            if (need_strings) {
+                auto sl = [](const uint8_t* p, uint64_t n, uint64_t a, uint64_t e) {
+                    if (a > e || e > n) throw Error("reference would panic: slice index out of range");
+                    return std::string(reinterpret_cast<const char*>(p) + a, e - a);
+                };
+                if (germ_len != 0) {
+                    if (splice_pos == 1) normal_peptide = sl(rec->germ, germ_len, splice_gap, germ_len);
+                    else if (splice_pos == 0) normal_peptide = sl(rec->germ, germ_len, 0, normal_window_len);
+                    else normal_peptide = sl(rec->germ, germ_len, 0, germ_len);
+                }
+                if (splice_pos == 1) neopeptide = sl(rec->seq, seq_len, splice_gap, seq_len);
+                else if (splice_pos == 0) neopeptide = insertion ? sl(rec->seq, seq_len, 0, seq_len) : sl(rec->seq, seq_len, 0, this_window_len);
+                else neopeptide = sl(rec->seq, seq_len, 0, seq_len);
+            }
+            bool remove_peptide = false;  // :702-718
+            if (stop_gain && splice_pos != 2 && (wl == this_window_len || indel) && !is_first_exon_window &&
+                (!indel || normal_peptide != neopeptide || std::fabs(freq - 1.0) < std::numeric_limits<double>::epsilon())) {
+                remove_peptide = true;
+                if (frame == 0) fsf[frame] = {0.0, false};
+                else fsf.erase(frame);
+            }
+            const bool emit = emit_pre && frame_frequency > 0.0;
+            HapSeq hs;
+            if (boundary || emit) {
+                IDRecord& r = hs.record;
+                std::string sites, som_pos, som_pc, germ_pos, germ_pc;
+                uint32_t n_sites = 0, n_som_sites = 0;
+                auto add = [](std::string& s, const std::string& x) { if (!s.empty()) s += "|"; s += x; };
+                bool f_sp = true, f_gp = true;
+                for (uint32_t c = 0; c < ncols; c++) {  // :733-759
+                    const Variant& v = *variants[c];
+                    if (c < rec->prof_len && ((rec->prof_set >> c) & 1)) {
+                        if (!v.is_germline) {
+                            add(som_pos, std::to_string(v.pos + 1));
+                            if (!f_sp) som_pc += "|";
+                            som_pc += v.prot_change; f_sp = false;
+                        } else {
+                            add(germ_pos, std::to_string(v.pos + 1));
+                            if (!f_gp) germ_pc += "|";
+                            germ_pc += v.prot_change; f_gp = false;
+                        }
+                    }
+                    if (c == 0 || v.pos != variants[c - 1]->pos) {
+                        n_sites++;
+                        add(sites, std::to_string(v.pos + 1));
+                        if (!v.is_germline) n_som_sites++;
+                    }
+                }
+                if (gs.flags & GS_ID_VALID) {
+                    char idb[20];
+                    std::snprintf(idb, sizeof idb, "%015llx%c", (unsigned long long)rec->id60, strand[0]);
+                    r.id = idb;
+                } else {
+                    r.id = haplotype_id(rec->seq, seq_len, transcript.id, offset, strand[0]);
+                }
+                r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
+                r.offset = splice_pos == 0 ? offset + 1 : offset + 1 + splice_gap;
+                r.frame = frame;
+                r.freq = frame_frequency;
+                r.depth = wd.nrows;
+                r.nvar = n_variants; r.nsomatic = n_somatic;
+                r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
+                r.strand = strand;
+                r.variant_sites = sites; r.somatic_positions = som_pos; r.somatic_aa_change = som_pc;
+                r.germline_positions = germ_pos; r.germline_aa_change = germ_pc;
+                r.normal_sequence = normal_peptide; r.mutant_sequence = neopeptide;
+                if (emit) {  // :839-875
+                    if (splice_pos == 1) {
+                        if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
+                        write_fasta(out.fasta, r.id, rec->seq + splice_gap, seq_len - splice_gap);
+                    } else if (splice_pos == 0) {
+                        write_fasta(out.fasta, r.id, rec->seq, this_window_len);
+                    }
+                    if (germ_len != 0) {
+                        if (splice_pos == 1) {
+                            if (splice_gap > germ_len) throw Error("reference would panic: slice index out of range");
+                            write_fasta(out.normal_fasta, r.id, rec->germ + splice_gap, germ_len - splice_gap);
+                        } else if (splice_pos == 0) {
+                            if (this_window_len > germ_len) throw Error("reference would panic: slice index out of range");
+                            write_fasta(out.normal_fasta, r.id, rec->germ, this_window_len);
+                        }
+                    }
+                    write_tsv_record(out, r);
+                }
+                // the carried-over record holds the UNSLICED sequences (:807-832)
+                r.normal_sequence.assign(reinterpret_cast<const char*>(rec->germ), germ_len);
+                r.mutant_sequence.assign(reinterpret_cast<const char*>(rec->seq), seq_len);
+            }
+            if (!remove_peptide || frame == 0) haplotypes_vec.push_back(std::move(hs));  // :835-837
+        }
+        return {std::move(haplotypes_vec), std::move(fsf)};
+    }
+
+    // splice-side merge (reference: src/microphasing.rs:1505-1908)
+    void splice_merge(const ExonGeom& eg, const StepGeom& sg, uint64_t exon_rest, std::map<uint64_t, uint64_t>& frameshifts,
+                      FsFreq& fsf, std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec) {
+        const uint64_t offset = sg.offset;
+        const std::vector<HapSeq>& first_hap_vec = is_fwd ? hap_vec : prev_hap_vec;
+        const std::vector<HapSeq>& sec_hap_vec = is_fwd ? prev_hap_vec : hap_vec;
+        using MKey = std::tuple<uint64_t, std::string, std::string>;
+        std::map<MKey, std::tuple<std::string, IDRecord, std::string>> output_map;
+        std::vector<HapSeq> new_hap_vec;
+        const double eps = std::numeric_limits<double>::epsilon();
+        for (const HapSeq& hapseq : first_hap_vec) {
+            const IDRecord& record = hapseq.record;
+            const std::string& wt = record.normal_sequence;
+            const std::string& mt = record.mutant_sequence;
+            for (const HapSeq& prev_hapseq : sec_hap_vec) {
+                const IDRecord& prev = prev_hapseq.record;
+                const std::string& pwt = prev.normal_sequence;
+                const std::string& pmt = prev.mutant_sequence;
+                std::string new_wt = pwt + wt;
+                std::vector<std::string> new_mts;
+                if (wt != mt) {
+                    new_mts.push_back(pwt + mt);
+                    if (pwt != pmt) { new_mts.push_back(pmt + wt); new_mts.push_back(pmt + mt); }
+                } else {
+                    new_mts.push_back(pmt + mt);
+                }
+                const double merged = std::fabs(record.freq - prev.freq) < eps ? record.freq : record.freq * prev.freq;
+                if (eg.is_short && !eg.is_last) {
+                    HapSeq nh;
+                    nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_wt, window_len);
+                    new_hap_vec.push_back(std::move(nh));
+                }
+                for (const std::string& new_mt : new_mts) {
+                    if (eg.is_short && !eg.is_last) {
+                        HapSeq nh;
+                        nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_mt, window_len);
+                        new_hap_vec.push_back(std::move(nh));
+                        continue;
+                    }
+                    std::vector<std::pair<uint64_t, uint64_t>> active;
+                    if (is_fwd) {
+                        for (auto it = frameshifts.begin(); it != frameshifts.end() && it->first < offset; ++it) active.push_back(*it);
+                    } else {
+                        for (auto it = frameshifts.lower_bound(offset + eg.ewl); it != frameshifts.end(); ++it) active.push_back(*it);
+                    }
+                    for (const auto& pf : active) {
+                        const uint64_t pos = pf.first, frameshift = pf.second;
+                        fsf.emplace(frameshift, std::make_pair(0.0, false));
+                        const bool shift_in_window = is_fwd ? pos >= prev.offset : pos < record.offset + eg.ewl;
+                        const bool somatic_shift = fsf.at(frameshift).second;
+                        const double fs_freq = fsf.at(frameshift).first;
+                        const double f0 = fsf.at(0).first;
+                        const double main_orf_freq = f0 == 0.0 ? fs_freq : f0;
+                        const double shift_orf_freq = shift_in_window ? fs_freq : (f0 == 0.0 ? fs_freq : f0);
+                        const double vf_rec = is_fwd ? record.freq / main_orf_freq : record.freq / shift_orf_freq;
+                        const double vf_prev = is_fwd ? prev.freq / shift_orf_freq : prev.freq / main_orf_freq;
+                        const double freq_rec = f0 == 0.0 ? fs_freq : vf_rec * fs_freq;
+                        const double freq_prev = f0 == 0.0 ? fs_freq : vf_prev * fs_freq;
+                        const double out_freq = std::fabs(record.freq - prev.freq) < eps ? freq_rec : freq_rec * freq_prev;
+                        const uint64_t out_shift = shift_in_window ? 0 : frameshift;
+                        uint64_t splice_offset = 3 - out_shift;
+                        if (!is_fwd && exon_rest < 3) splice_offset += exon_rest;
+                        size_t end_offset = 3 + size_t(out_shift);
+                        if (sg.is_last_exon_window) end_offset = 0;
+                        if (uint64_t(new_mt.size()) < 2 * window_len) {
+                            if (is_fwd) splice_offset = 0; else end_offset = 0;
+                        }
+                        for (;;) {
+                            if (end_offset > new_mt.size()) throw Error("reference would panic: attempt to subtract with overflow");
+                            if (!(splice_offset + window_len <= uint64_t(new_mt.size() - end_offset))) break;
+                            std::string out_wt;
+                            if (splice_offset + window_len <= uint64_t(new_wt.size())) {
+                                if (is_fwd) out_wt = new_wt.substr(size_t(splice_offset), size_t(window_len));
+                                else {
+                                    if (new_wt.size() < end_offset + window_len) throw Error("reference would panic: attempt to subtract with overflow");
+                                    out_wt = new_wt.substr(new_wt.size() - end_offset - size_t(window_len), size_t(window_len));
+                                }
+                            }
+                            std::string out_mt = is_fwd ? new_mt.substr(size_t(splice_offset), size_t(window_len))
+                                                        : new_mt.substr(new_mt.size() - end_offset - size_t(window_len), size_t(window_len));
+                            if (out_shift > 0 && out_wt == out_mt && somatic_shift) out_wt.clear();
+                            if (out_wt == out_mt || (out_wt.empty() && frameshift == 0)) {
+                                if (is_fwd) splice_offset += 3; else end_offset += 3;
+                                continue;
+                            }
+                            const uint64_t out_offset = is_fwd ? splice_offset : uint64_t(end_offset);
+                            IDRecord out_record = is_fwd ? record_update(prev, record, out_offset, frameshift, out_freq, out_wt, out_mt, window_len)
+                                                         : record_update(record, prev, out_offset, frameshift, out_freq, out_wt, out_mt, window_len);
+                            MKey id_tuple{out_offset, out_mt, out_wt};
+                            auto fit = output_map.find(id_tuple);
+                            const double old_freq = fit == output_map.end() ? 0.0 : std::get<1>(fit->second).freq;
+                            output_map[id_tuple] = std::make_tuple(out_mt, record_add_freq(out_record, old_freq), out_wt);
+                            if (is_fwd) splice_offset += 3; else end_offset += 3;
+                        }
+                    }
+                }
+            }
+        }
+        if (eg.is_short && !eg.is_last) {
+            prev_hap_vec = std::move(new_hap_vec);
+        } else {
+            for (const auto& kv : output_map) {
+                const std::string& out_mt = std::get<0>(kv.second);
+                const IDRecord& out_record = std::get<1>(kv.second);
+                const std::string& out_wt = std::get<2>(kv.second);
+                if (out_mt != out_wt) {
+                    if (out_mt.size() < window_len) throw Error("reference would panic: slice index out of range");
+                    write_fasta(out.fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), size_t(window_len));
+                    if (!out_wt.empty()) {
+                        if (out_wt.size() < window_len) throw Error("reference would panic: slice index out of range");
+                        write_fasta(out.normal_fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_wt.data()), size_t(window_len));
+                    }
+                    write_tsv_record(out, out_record);
+                }
+            }
+            if (eg.is_short) prev_hap_vec = std::move(new_hap_vec);
+        }
+    }
+};
+
+}  // namespace
+
+void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
+    for (const GeneHost& gh : b.genes) {
+        const GeneInput& gi = *gh.input;
+        VarIndex vi{&gi.variants};
+        for (uint32_t k = 0; k < gh.n_tx; k++) {
+            const TxDev& T = b.tx[gh.tx_off + k];
+            const Transcript& t = gi.gene.transcripts[gh.tx_src[k]];
+            ConsumerHooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
+            walk_transcript(gi.gene, t, vi, gh.max_read_len, b.window_len, hooks);
+        }
+    }
+}
+
+}  // namespace mp

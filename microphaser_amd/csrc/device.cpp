@@ -1,0 +1,196 @@
+#include "device.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace mp {
+
+[[noreturn]] void throw_hip(hipError_t e, const char* file, int line) {
+    throw Error(std::string("HIP error: ") + hipGetErrorString(e) + " at " + file + ":" + std::to_string(line));
+}
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__); } while (0)
+
+DeviceContext::DeviceContext(int device) : device_(device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) throw Error("no HIP device available: the phasing hot path needs an MI355X (gfx950); there is no CPU fallback");
+    if (device < 0 || device >= n) throw Error("invalid HIP device index " + std::to_string(device));
+    HIP_OK(hipSetDevice(device));
+    HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    for (auto& ev : ev_) HIP_OK(hipEventCreate(&ev));
+}
+
+DeviceContext::~DeviceContext() {
+    hipSetDevice(device_);
+    free_batch();
+    for (auto& ev : ev_) if (ev) hipEventDestroy(ev);
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+void* DeviceContext::dalloc(size_t bytes) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+    hbm_bytes_ += bytes;
+    return p;
+}
+
+template <class T>
+T* DeviceContext::up(const std::vector<T>& v) {
+    T* p = static_cast<T*>(dalloc(v.size() * sizeof(T)));
+    allocs_.push_back(p);
+    if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
+    return p;
+}
+
+void DeviceContext::free_outputs() {
+    for (void* p : out_allocs_) hipFree(p);
+    out_allocs_.clear();
+}
+
+void DeviceContext::free_batch() {
+    free_outputs();
+    for (void* p : allocs_) hipFree(p);
+    allocs_.clear();
+    hbm_bytes_ = 0;
+    std::memset(&d_, 0, sizeof d_);
+}
+
+void DeviceContext::upload(const Batch& b) {
+    HIP_OK(hipSetDevice(device_));
+    free_batch();
+    std::vector<uint32_t> r_gene(b.r_pos.size());
+    for (size_t g = 0; g + 1 < b.g_read_off.size(); g++)
+        for (uint32_t i = b.g_read_off[g]; i < b.g_read_off[g + 1]; i++) r_gene[i] = uint32_t(g);
+    d_.g_read_off = up(b.g_read_off);
+    d_.g_var_off = up(b.g_var_off);
+    d_.g_start = up(b.g_start);
+    d_.g_ref_off = up(b.g_ref_off);
+    d_.r_gene = up(r_gene);
+    d_.r_pos = up(b.r_pos);
+    d_.r_end = up(b.r_end);
+    d_.r_lseq = up(b.r_lseq);
+    d_.r_ncig = up(b.r_ncig);
+    d_.r_dup = up(b.r_dup);
+    d_.r_cigoff = up(b.r_cigoff);
+    d_.r_seqoff = up(b.r_seqoff);
+    d_.r_qualoff = up(b.r_qualoff);
+    d_.cigar_pool = up(b.cigar_pool);
+    d_.seq_pool = up(b.seq_pool);
+    d_.qual_pool = up(b.qual_pool);
+    d_.v_pos = up(b.v_pos);
+    d_.v_info = up(b.v_info);
+    d_.v_len = up(b.v_len);
+    d_.v_insoff = up(b.v_insoff);
+    d_.v_rev2fwd = up(b.v_rev2fwd);
+    d_.ins_pool = up(b.ins_pool);
+    d_.ref_pool = up(b.ref_pool);
+    d_.tx = up(b.tx);
+    d_.steps = up(b.steps);
+    d_.wins = up(b.wins);
+    d_.str_pool = up(b.str_pool);
+    d_.tx_order = up(b.tx_order);
+    d_.n_reads = uint32_t(b.r_pos.size());
+    d_.n_tx = uint32_t(b.tx.size());
+    d_.n_wins = uint32_t(b.wins.size());
+    d_.mask_words = b.mask_words;
+    // K1 outputs
+    d_.r_varlo = static_cast<uint32_t*>(dalloc(size_t(d_.n_reads) * 4)); allocs_.push_back(d_.r_varlo);
+    d_.r_sup = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_sup);
+    d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);
+    d_.win_dyn = static_cast<WinDyn*>(dalloc(size_t(d_.n_wins) * sizeof(WinDyn))); allocs_.push_back(d_.win_dyn);
+    d_.cursors = static_cast<unsigned long long*>(dalloc(16)); allocs_.push_back(d_.cursors);
+    d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
+    d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
+    max_rows_bound_ = b.max_rows_bound;
+    rpl_ = 1;
+    while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_ + max_rows_bound_ / 8 + 2) rpl_ *= 2;
+    // first guess: 6 distinct haplotypes per window + chunk slack per transcript
+    group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 4096 + 4096;
+    rec_cap_ = group_cap_ / 2 + 4096;
+    alloc_outputs();
+    HIP_OK(hipStreamSynchronize(stream_));
+}
+
+void DeviceContext::alloc_outputs() {
+    free_outputs();
+    auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); return p; };
+    d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
+    d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
+    d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
+    d_.recs = static_cast<HapRec*>(oalloc(rec_cap_ * sizeof(HapRec)));
+    d_.group_cap = group_cap_;
+    d_.rec_cap = rec_cap_;
+}
+
+void DeviceContext::run(RunTiming& t) {
+    HIP_OK(hipSetDevice(device_));
+    t = RunTiming();
+    for (int attempt = 0; attempt < 8; attempt++) {
+        t.attempts = uint32_t(attempt + 1);
+        t.rows_per_lane = rpl_;
+        HIP_OK(hipMemsetAsync(d_.cursors, 0, 16, stream_));
+        HIP_OK(hipMemsetAsync(d_.err, 0, 4, stream_));
+        HIP_OK(hipMemsetAsync(d_.g_win, 0xFF, group_cap_ * 4, stream_));
+        HIP_OK(hipMemsetAsync(d_.win_dyn, 0, size_t(d_.n_wins) * sizeof(WinDyn), stream_));
+        HIP_OK(hipMemsetAsync(d_.tx_first_stop, 0xFF, size_t(d_.n_tx) * 4, stream_));
+        HIP_OK(hipEventRecord(ev_[0], stream_));
+        launch_k1_pileup_bits(d_, stream_);
+        HIP_OK(hipEventRecord(ev_[1], stream_));
+        launch_k2_window_replay(d_, rpl_, stream_);
+        HIP_OK(hipEventRecord(ev_[2], stream_));
+        unsigned long long cur[2] = {0, 0};
+        uint32_t err = 0;
+        HIP_OK(hipMemcpyAsync(cur, d_.cursors, 8, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        if (err & WD_ROW_OVERFLOW) {
+            if (rpl_ >= 16) throw Error("more than 1024 simultaneously live reads in one window (depth too high for this build)");
+            rpl_ *= 2;
+            continue;
+        }
+        if ((err & WD_GROUP_OVERFLOW) || cur[0] > group_cap_) {
+            group_cap_ = std::max<uint64_t>(group_cap_ * 2, cur[0] + 4096);
+            rec_cap_ = std::max(rec_cap_, group_cap_ / 2);
+            alloc_outputs();
+            continue;
+        }
+        uint64_t slots = cur[0];
+        launch_k3_window_seq(d_, slots, stream_);
+        HIP_OK(hipEventRecord(ev_[3], stream_));
+        HIP_OK(hipMemcpyAsync(cur, d_.cursors, 16, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        if ((err & WD_GROUP_OVERFLOW) || cur[1] > rec_cap_) {
+            rec_cap_ = std::max<uint64_t>(rec_cap_ * 2, cur[1] + 4096);
+            alloc_outputs();
+            continue;
+        }
+        HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
+        HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
+        HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
+        HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[3]));
+        t.n_group_slots = last_slots_ = slots;
+        t.n_recs = last_recs_ = cur[1];
+        return;
+    }
+    throw Error("device result buffers kept overflowing");
+}
+
+void DeviceContext::download(HostResults& r) {
+    HIP_OK(hipSetDevice(device_));
+    r.n_group_slots = last_slots_;
+    r.n_recs = last_recs_;
+    r.win_dyn.resize(d_.n_wins);
+    r.groups.resize(last_slots_);
+    r.gsum.resize(last_slots_);
+    r.recs.resize(last_recs_);
+    if (d_.n_wins) HIP_OK(hipMemcpyAsync(r.win_dyn.data(), d_.win_dyn, size_t(d_.n_wins) * sizeof(WinDyn), hipMemcpyDeviceToHost, stream_));
+    if (last_slots_) {
+        HIP_OK(hipMemcpyAsync(r.groups.data(), d_.groups, last_slots_ * sizeof(Group), hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(r.gsum.data(), d_.gsum, last_slots_ * sizeof(GroupSum), hipMemcpyDeviceToHost, stream_));
+    }
+    if (last_recs_) HIP_OK(hipMemcpyAsync(r.recs.data(), d_.recs, last_recs_ * sizeof(HapRec), hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+}
+
+}  // namespace mp

@@ -1,0 +1,60 @@
+// Device context: owns the HIP stream and the HBM buffers of one batch, runs K1 -> K2 -> K3.
+// One context per GPU, not shared between host threads.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "batch.hpp"
+#include "kernels.hpp"
+
+namespace mp {
+
+struct HostResults {         // device results copied back for the consumer
+    std::vector<WinDyn> win_dyn;
+    std::vector<Group> groups;
+    std::vector<GroupSum> gsum;
+    std::vector<HapRec> recs;
+    uint64_t n_group_slots = 0, n_recs = 0;
+};
+
+struct RunTiming {
+    float k1_ms = 0, k2_ms = 0, k3_ms = 0, total_ms = 0;
+    uint64_t n_group_slots = 0, n_recs = 0;
+    int rows_per_lane = 1;
+    uint32_t attempts = 0;
+};
+
+class DeviceContext {
+  public:
+    explicit DeviceContext(int device);
+    ~DeviceContext();
+    DeviceContext(const DeviceContext&) = delete;
+    DeviceContext& operator=(const DeviceContext&) = delete;
+
+    void upload(const Batch& b);   // H2D of the packed batch + plan; allocates outputs
+    // One pass of the hot path over the resident batch (inputs in HBM -> results in HBM).
+    // Retries with more rows per lane / larger group buffers if the kernels report overflow.
+    void run(RunTiming& t);
+    void download(HostResults& r); // D2H of the results of the last run()
+    void free_batch();
+    int device() const { return device_; }
+    uint64_t hbm_bytes() const { return hbm_bytes_; }
+
+  private:
+    void* dalloc(size_t bytes);
+    template <class T> T* up(const std::vector<T>& v);
+    void alloc_outputs();
+    void free_outputs();
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<void*> allocs_, out_allocs_;
+    DeviceBatch d_{};
+    uint64_t hbm_bytes_ = 0;
+    uint64_t group_cap_ = 0, rec_cap_ = 0;
+    int rpl_ = 1;
+    uint32_t max_rows_bound_ = 0;
+    uint64_t last_slots_ = 0, last_recs_ = 0;
+};
+
+}  // namespace mp

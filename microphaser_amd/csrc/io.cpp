@@ -441,6 +441,15 @@ IndexedFasta::IndexedFasta(const std::string& path) : path_(path) {
     }
 }
 
+void MemFasta::fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const {
+    auto it = contigs.find(chrom);
+    if (it == contigs.end()) throw Error("Unknown sequence name: " + chrom);
+    const std::string& s = *it->second;
+    if (stop > s.size()) throw Error("FASTA read interval was out of bounds");
+    if (start > stop) throw Error("Invalid query interval");
+    out.assign(s.begin() + long(start), s.begin() + long(stop));
+}
+
 void IndexedFasta::ensure_loaded() const {
     if (!file_.empty()) return;
     FileBytes fb(path_);
@@ -594,7 +603,7 @@ void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gen
     if (have_gene) on_gene(gene);
 }
 
-void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const IndexedFasta& fasta,
+void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const RefSource& fasta,
                       bool warning_only, const std::function<void(GeneInput&)>& on_gene) {
     ReadBuffer rb(bam);
     stream_gtf(gtf, [&](const Gene& g) {

@@ -84,11 +84,23 @@ void gene_variants(const VcfData& vcf, const std::string& chrom, uint64_t start,
                    bool unsupported_allele_warning_only, std::vector<Variant>& out);
 
 // ---------------------------------------------------------------- FASTA
-class IndexedFasta {
+// Anything that can serve reference bases for [start, stop) of a contig.
+struct RefSource {
+    virtual ~RefSource() = default;
+    virtual void fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const = 0;
+};
+
+// In-memory contigs (synthetic data sets).
+struct MemFasta : RefSource {
+    std::map<std::string, const std::string*> contigs;
+    void fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const override;
+};
+
+class IndexedFasta : public RefSource {
   public:
     explicit IndexedFasta(const std::string& path);  // needs path + ".fai"
     // bio::io::fasta::IndexedReader::fetch + read: [start, stop), case preserved.
-    void fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const;
+    void fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const override;
     bool has(const std::string& chrom) const { return idx_.count(chrom) != 0; }
 
   private:
@@ -108,7 +120,7 @@ void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gen
 
 // Convenience: run the per-gene loading of phase_gene (refseq, reads, variants) for every
 // protein-coding gene of a GTF stream.
-void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const IndexedFasta& fasta,
+void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const RefSource& fasta,
                       bool unsupported_allele_warning_only, const std::function<void(GeneInput&)>& on_gene);
 
 }  // namespace mp

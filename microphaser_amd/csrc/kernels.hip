@@ -1,0 +1,674 @@
+// gfx950 (CDNA4, wave64) kernels of the phasing hot path. Integer / bitset work, HBM- and
+// latency-bound: no MFMA. One wavefront = 64 lanes everywhere (hard-coded).
+//
+//   K1 k1_pileup_bits     read x variant predicates  (reference: supports_variant / bad_quality,
+//                         src/microphasing.rs:78-139) -> per-read support / low-quality bit masks
+//   K2 k2_window_replay   ObservationMatrix sliding-window state machine, one wave per transcript,
+//                         rows (reads) live in lanes, columns (variants) in an LDS ring
+//                         (reference: src/microphasing.rs:220-343 + count phase :383-411)
+//   K3 k3_window_seq      per (window, haplotype): mutant / germline window sequence, variant
+//                         profile, stop scan, SHA-1 id (reference: src/microphasing.rs:434-603,
+//                         :42-76, :667-675)
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace mp {
+
+#define HIP_CHECK_LAUNCH() \
+    do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { throw_hip(e_, __FILE__, __LINE__); } } while (0)
+
+[[noreturn]] void throw_hip(hipError_t e, const char* file, int line);
+
+// ====================================================================== K1
+// rust-htslib CigarStringView::read_pos(ref_pos, false, false), see model.hpp cigar_read_pos.
+__device__ __forceinline__ int cigar_read_pos_dev(const uint32_t* cig, uint32_t ncig, uint32_t read_start, uint32_t ref_pos) {
+    int64_t rpos = read_start;
+    int64_t qpos = 0;
+    uint32_t j = 0;
+    bool found = false;
+    for (uint32_t i = 0; i < ncig; i++) {
+        uint32_t op = cig[i] & 0xF;
+        if (op == 0 || op == 7 || op == 8 || op == 1 || op == 4) { j = i; found = true; break; }
+        if (op == 2 || op == 3) return -1;
+        if (op == 5 && i > 0 && i + 1 < ncig) return -1;
+        if (i + 1 == ncig) return -1;
+    }
+    if (!found) return -1;
+    while (rpos <= int64_t(ref_pos) && j < ncig) {
+        uint32_t op = cig[j] & 0xF;
+        int64_t l = cig[j] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            if (rpos + l > int64_t(ref_pos)) return int(qpos + (int64_t(ref_pos) - rpos));
+            rpos += l; qpos += l; j++;
+        } else if (op == 4 || op == 1) { qpos += l; j++; }
+        else if (op == 2 || op == 3) { rpos += l; j++; }
+        else if (op == 6) { j++; }
+        else return -1;
+    }
+    return -1;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= d.n_reads) return;
+    uint32_t g = d.r_gene[i];
+    uint32_t vbase = d.g_var_off[g];
+    uint32_t nv = d.g_var_off[g + 1] - vbase;
+    uint32_t rpos = d.r_pos[i], rend = d.r_end[i], lseq = d.r_lseq[i], ncig = d.r_ncig[i];
+    const uint32_t* cig = d.cigar_pool + d.r_cigoff[i];
+    const uint8_t* seq4 = d.seq_pool + d.r_seqoff[i];
+    const uint8_t* qual = d.qual_pool + d.r_qualoff[i];
+    // first variant with pos >= rpos
+    uint32_t lo = 0, hi = nv;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (d.v_pos[vbase + mid] < rpos) lo = mid + 1; else hi = mid;
+    }
+    uint64_t sup[W], lq[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
+    for (uint32_t k = lo; k < nv && (k - lo) < 64u * W; k++) {
+        uint32_t vpos = d.v_pos[vbase + k];
+        if (vpos >= rend) break;
+        uint32_t info = d.v_info[vbase + k];
+        uint32_t kind = info & VI_KIND_MASK;
+        bool s = false, q = false;
+        if (kind == 0) {  // SNV
+            uint32_t rel = vpos - rpos;
+            if (rel < lseq && qual[rel] < 10) q = true;
+            if (!q) {
+                int p = cigar_read_pos_dev(cig, ncig, rpos, vpos);
+                if (p >= 0 && uint32_t(p) < lseq) {
+                    uint8_t b4 = seq4[p >> 1];
+                    uint32_t code = (p & 1) ? (b4 & 0xF) : (b4 >> 4);
+                    const char dec[17] = "=ACMGRSVTWYHKDBN";
+                    s = uint8_t(dec[code]) == uint8_t(info >> VI_ALT_SHIFT);
+                }
+            }
+        } else {  // insertion / deletion: any I / D op of exactly that length
+            uint32_t want = kind == 1 ? 1u : 2u;
+            uint32_t vlen = d.v_len[vbase + k];
+            for (uint32_t c = 0; c < ncig; c++)
+                if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
+        }
+        uint32_t b = k - lo;
+#pragma unroll
+        for (int w = 0; w < W; w++)
+            if ((b >> 6) == uint32_t(w)) {
+                if (s) sup[w] |= 1ull << (b & 63);
+                if (q) lq[w] |= 1ull << (b & 63);
+            }
+    }
+    d.r_varlo[i] = lo;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        d.r_sup[uint64_t(i) * W + w] = sup[w];
+        d.r_lq[uint64_t(i) * W + w] = lq[w];
+    }
+}
+
+// ====================================================================== K2
+enum : uint32_t { ST_EMPTY = 0, ST_PENDING = 1, ST_ROW = 2, ST_MASK = 3, RF_BAD = 4, RF_SL = 8, RF_F1 = 16 };
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
+
+constexpr uint32_t GROUP_CHUNK = 4096;
+
+template <int RPL>
+__global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = d.tx_order[blockIdx.x];
+    const TxDev T = d.tx[t];
+    const uint32_t rbase = d.g_read_off[T.gene];
+    const uint32_t vbase = d.g_var_off[T.gene];
+    const bool is_rev = T.strand != 0;
+    const uint32_t W = d.mask_words;
+
+    __shared__ uint32_t colf[64];     // forward variant index (gene-relative) of each live column
+    __shared__ uint32_t colinfo[64];  // v_info | start-loss bit 31
+
+    uint32_t fl[RPL], rs[RPL], re[RPL], rvl[RPL], rdup[RPL], ridx[RPL], fr0[RPL];
+    uint64_t hap[RPL], msup[RPL], mlq[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; r++) { fl[r] = ST_EMPTY; rs[r] = re[r] = rvl[r] = rdup[r] = ridx[r] = fr0[r] = 0; hap[r] = msup[r] = mlq[r] = 0; }
+
+    uint32_t ncols = 0, head = 0;
+    uint64_t chunk_pos = 0, chunk_end = 0;
+    uint32_t sticky_err = 0;
+
+    // support / low-quality bit of row slot r for forward variant index f
+    auto bits_of = [&](int r, uint32_t f, bool& s, bool& q) {
+        uint32_t b = f - rvl[r];
+        s = false; q = false;
+        if (f < rvl[r] || b >= 64u * W) return;
+        if (W == 1) { s = (msup[r] >> b) & 1; q = (mlq[r] >> b) & 1; }
+        else {
+            uint64_t a = d.r_sup[uint64_t(ridx[r]) * W + (b >> 6)], c = d.r_lq[uint64_t(ridx[r]) * W + (b >> 6)];
+            s = (a >> (b & 63)) & 1; q = (c >> (b & 63)) & 1;
+        }
+    };
+    // Observation::update_haplotype for one variant (reference: microphasing.rs:157-197); hap already shifted
+    auto update_row = [&](int r, bool s, bool q, uint32_t info) {
+        uint32_t fs = (info & VI_FS_MASK) >> VI_FS_SHIFT;
+        if (fs) fl[r] |= RF_F1;
+        if (s) {
+            if (info & 0x80000000u) fl[r] |= RF_SL;
+            hap[r] |= 1ull;
+            fr0[r] += fs;
+        }
+        if (q || (fl[r] & (RF_BAD | RF_SL))) { hap[r] = 0; fl[r] |= RF_BAD; }
+    };
+
+    for (uint32_t s0 = 0; s0 < T.n_steps; s0 += 64) {
+        const uint32_t nb = min(64u, T.n_steps - s0);
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0;
+        if (lane < nb) {
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + (T.step_off + s0 + lane));
+            w0 = sp[0]; w1 = sp[1]; w2 = sp[2]; w3 = sp[3]; w4 = sp[4]; w5 = sp[5];
+        }
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint32_t sso = rdlane(w0, i), cand_lo = rdlane(w1, i), col_hi = rdlane(w2, i), win = rdlane(w3, i);
+            const uint32_t p4 = rdlane(w4, i), p5 = rdlane(w5, i);
+            const uint32_t cand_n = p4 & 0xFFFF, wlen = (p4 >> 16) & 0xFF, n_del = p4 >> 24;
+            const uint32_t n_add = p5 & 0xFF, sflags = (p5 >> 8) & 0xFF;
+            const uint32_t splice_end = sso + wlen;
+
+            // ---- cleanup_reads (:259-278): forward keeps end >= splice_end, reverse keeps start <= sso
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                uint32_t st = fl[r] & ST_MASK;
+                if (st != ST_EMPTY) {
+                    bool keep = is_rev ? (rs[r] <= sso) : (re[r] >= splice_end);
+                    if (is_rev && (sflags & SF_FULL_RANGE) && st == ST_PENDING) keep = false;  // re-listed below if still in range
+                    if (!keep) fl[r] = ST_EMPTY;
+                }
+            }
+            // ---- shrink_left (:220-229)
+            if (n_del) {
+                ncols -= n_del;
+                head = (head + n_del) & 63;
+                uint64_t mask = (1ull << ncols) - 1ull;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) hap[r] &= mask;
+            }
+            // ---- new candidate reads into empty slots
+            bool any_rows_before = false;
+            if (cand_n) {
+                if (is_rev && (sflags & SF_FULL_RANGE)) {
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) any_rows_before |= (__ballot((fl[r] & ST_MASK) == ST_ROW) != 0);
+                }
+                uint32_t left = cand_n, c = cand_lo;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) {
+                    if (left) {
+                        bool empty = (fl[r] & ST_MASK) == ST_EMPTY;
+                        uint64_t freem = __ballot(empty);
+                        uint32_t rank = lanes_below(freem, lane);
+                        if (empty && rank < left) {
+                            uint32_t gi = rbase + c + rank;
+                            ridx[r] = gi;
+                            rs[r] = d.r_pos[gi];
+                            re[r] = d.r_end[gi];
+                            rvl[r] = d.r_varlo[gi];
+                            rdup[r] = d.r_dup[gi];
+                            if (W == 1) { msup[r] = d.r_sup[gi]; mlq[r] = d.r_lq[gi]; }
+                            fl[r] = ST_PENDING;
+                        }
+                        uint32_t took = min(uint32_t(__popcll(freem)), left);
+                        c += took;
+                        left -= took;
+                    }
+                }
+                if (left) sticky_err |= WD_ROW_OVERFLOW;
+            }
+            // ---- push_read (:297-343) for every pending candidate
+            bool att[RPL];
+            bool any_att = false;
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso;
+                any_att |= att[r];
+            }
+            if (__ballot(any_att)) {
+#pragma unroll
+                for (int r = 0; r < RPL; r++)
+                    if (att[r]) { hap[r] = 0; fr0[r] = 0; fl[r] &= ST_MASK; }
+                __syncthreads();
+                for (uint32_t j = 0; j < ncols; j++) {
+                    uint32_t f = colf[(head + j) & 63], info = colinfo[(head + j) & 63];
+#pragma unroll
+                    for (int r = 0; r < RPL; r++)
+                        if (att[r]) {
+                            bool s, q;
+                            bits_of(r, f, s, q);
+                            hap[r] <<= 1;
+                            update_row(r, s, q, info);
+                        }
+                }
+                // `contains` (:281-294) only ever matches on the reverse strand (rows keyed by start)
+                bool need_dup = false;
+                if (is_rev) {
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) need_dup |= att[r] && !(fl[r] & RF_BAD) && ((rdup[r] >> 31) || any_rows_before);
+                }
+                if (__ballot(need_dup)) {
+#pragma unroll
+                    for (int rc = 0; rc < RPL; rc++) {
+                        bool chk = is_rev && att[rc] && !(fl[rc] & RF_BAD) && ((rdup[rc] >> 31) || any_rows_before);
+                        uint64_t m = __ballot(chk);
+                        while (m) {
+                            uint32_t l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            uint32_t key = rdlane(rdup[rc], l) & 0x7FFFFFFFu;
+                            uint32_t myidx = rdlane(ridx[rc], l);
+                            bool hit = false;
+#pragma unroll
+                            for (int r = 0; r < RPL; r++) {
+                                bool same = (rdup[r] & 0x7FFFFFFFu) == key;
+                                bool row_hit = (fl[r] & ST_MASK) == ST_ROW && same;
+                                bool cand_hit = att[r] && !(fl[r] & RF_BAD) && same && ridx[r] < myidx;
+                                hit |= (__ballot(row_hit || cand_hit) != 0);
+                            }
+                            if (hit && lane == l) att[rc] = false;  // contained: stays pending
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RPL; r++)
+                    if (att[r]) {
+                        if (fl[r] & RF_BAD) fl[r] = is_rev ? uint32_t(ST_PENDING) : uint32_t(ST_EMPTY);  // :333-335 not inserted
+                        else fl[r] = (fl[r] & ~ST_MASK) | ST_ROW;
+                    }
+            }
+            if (!is_rev) {  // forward: every key is offered exactly once
+#pragma unroll
+                for (int r = 0; r < RPL; r++)
+                    if ((fl[r] & ST_MASK) == ST_PENDING) fl[r] = ST_EMPTY;
+            }
+            // ---- extend_right (:232-256)
+            for (uint32_t a = 0; a < n_add; a++) {
+                uint32_t tr = col_hi - n_add + a;
+                uint32_t f = is_rev ? d.v_rev2fwd[vbase + tr] : tr;
+                uint32_t info = d.v_info[vbase + f];
+                uint32_t pos = d.v_pos[vbase + f];
+                if (pos >= T.sl_lo && pos < T.sl_hi) info |= 0x80000000u; else info &= 0x7FFFFFFFu;
+                __syncthreads();
+                if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
+                ncols++;
+#pragma unroll
+                for (int r = 0; r < RPL; r++)
+                    if ((fl[r] & ST_MASK) == ST_ROW) {
+                        bool s, q;
+                        bits_of(r, f, s, q);
+                        hap[r] <<= 1;
+                        update_row(r, s, q, info);
+                    }
+            }
+            // ---- count phase of print_haplotypes (:383-411)
+            if (sflags & SF_PRINT) {
+                uint32_t nrows = 0, nvalid = 0;
+                bool act[RPL];
+#pragma unroll
+                for (int r = 0; r < RPL; r++) {
+                    bool row = (fl[r] & ST_MASK) == ST_ROW;
+                    act[r] = row && !(fl[r] & RF_BAD);
+                    nrows += __popcll(__ballot(row));
+                    nvalid += __popcll(__ballot(act[r]));
+                }
+                // the reference haplotype (0, frame 0) is always listed (count 0 if no row carries it): the
+                // consumer needs its sequence for the empty-window case (:429-431)
+                bool zero_here = false;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) zero_here |= act[r] && hap[r] == 0 && fr0[r] == 0 && !(fl[r] & RF_F1);
+                const bool has_zero = __ballot(zero_here) != 0;
+                nvalid += has_zero ? 0u : 1u;
+                uint32_t werr = sticky_err;
+                if (chunk_pos + nvalid > chunk_end) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(d.cursors, (unsigned long long)GROUP_CHUNK);
+                    uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                    chunk_pos = (uint64_t(bhi) << 32) | blo;
+                    chunk_end = chunk_pos + GROUP_CHUNK;
+                }
+                const bool can_write = chunk_end <= d.group_cap && nvalid <= GROUP_CHUNK;
+                if (!can_write) werr |= WD_GROUP_OVERFLOW;
+                const uint64_t gbase = chunk_pos;
+                uint32_t ng = has_zero ? 0u : 1u;  // lane 0 stages the zero-count reference group
+                uint32_t sg_hi = 0, sg_lo = 0, sg_aux = 0, sg_cnt = 0;
+                for (;;) {
+                    uint32_t khi = 0xFFFFFFFFu, klo = 0xFFFFFFFFu, ka = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int r = 0; r < RPL; r++)
+                        if (act[r]) {
+                            uint32_t h = uint32_t(hap[r] >> 32), l = uint32_t(hap[r]);
+                            uint32_t a = (fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u);
+                            if (h < khi || (h == khi && (l < klo || (l == klo && a < ka)))) { khi = h; klo = l; ka = a; }
+                        }
+                    if (!__ballot(khi != 0xFFFFFFFFu)) break;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        uint32_t oh = __shfl_xor(khi, off), ol = __shfl_xor(klo, off), oa = __shfl_xor(ka, off);
+                        if (oh < khi || (oh == khi && (ol < klo || (ol == klo && oa < ka)))) { khi = oh; klo = ol; ka = oa; }
+                    }
+                    uint64_t kh = (uint64_t(khi) << 32) | klo;
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) {
+                        uint32_t a = (fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u);
+                        bool m = act[r] && hap[r] == kh && a == ka;
+                        cnt += __popcll(__ballot(m));
+                        if (m) act[r] = false;
+                    }
+                    if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_aux = ka; sg_cnt = cnt; }
+                    ng++;
+                    if ((ng & 63) == 0 && can_write) {
+                        uint64_t gi = gbase + ng - 64 + lane;
+                        Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
+                        d.groups[gi] = G;
+                        d.g_win[gi] = win;
+                    }
+                }
+                if ((ng & 63) && can_write && lane < (ng & 63)) {
+                    uint64_t gi = gbase + (ng & ~63u) + lane;
+                    Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
+                    d.groups[gi] = G;
+                    d.g_win[gi] = win;
+                }
+                if (lane == 0) {
+                    WinDyn wd;
+                    wd.group_off = uint32_t(gbase);
+                    wd.ngroups = ng;
+                    wd.nrows = nrows;
+                    wd.flags = WD_DONE | werr;
+                    d.win_dyn[win] = wd;
+                }
+                if (can_write) chunk_pos += ng;
+            }
+        }
+    }
+    if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
+}
+
+// ====================================================================== K3
+__device__ __forceinline__ bool is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
+__device__ __forceinline__ uint8_t to_lower(uint8_t c) { return is_upper(c) ? uint8_t(c + 32) : c; }
+__device__ __forceinline__ uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? uint8_t(c - 32) : c; }
+__device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+struct Sha1Dev {
+    uint32_t h[5];
+    uint32_t w[16];
+    uint32_t fill;   // bytes in the current block
+    uint64_t total;
+    __device__ void init() {
+        h[0] = 0x67452301u; h[1] = 0xEFCDAB89u; h[2] = 0x98BADCFEu; h[3] = 0x10325476u; h[4] = 0xC3D2E1F0u;
+        for (int i = 0; i < 16; i++) w[i] = 0;
+        fill = 0; total = 0;
+    }
+    __device__ void block() {
+        uint32_t a = h[0], b = h[1], c = h[2], dd = h[3], e = h[4];
+        uint32_t ww[16];
+        for (int i = 0; i < 16; i++) ww[i] = w[i];
+        for (int i = 0; i < 80; i++) {
+            uint32_t wi;
+            if (i < 16) wi = ww[i];
+            else {
+                wi = rol32(ww[(i + 13) & 15] ^ ww[(i + 8) & 15] ^ ww[(i + 2) & 15] ^ ww[i & 15], 1);
+                ww[i & 15] = wi;
+            }
+            uint32_t f, k;
+            if (i < 20) { f = (b & c) | (~b & dd); k = 0x5A827999u; }
+            else if (i < 40) { f = b ^ c ^ dd; k = 0x6ED9EBA1u; }
+            else if (i < 60) { f = (b & c) | (b & dd) | (c & dd); k = 0x8F1BBCDCu; }
+            else { f = b ^ c ^ dd; k = 0xCA62C1D6u; }
+            uint32_t tmp = rol32(a, 5) + f + e + k + wi;
+            e = dd; dd = c; c = rol32(b, 30); b = a; a = tmp;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += dd; h[4] += e;
+        for (int i = 0; i < 16; i++) w[i] = 0;
+        fill = 0;
+    }
+    __device__ void put(uint8_t byte) {
+        w[fill >> 2] |= uint32_t(byte) << (24 - 8 * (fill & 3));
+        fill++; total++;
+        if (fill == 64) block();
+    }
+    __device__ void put_dec(uint32_t v) {
+        char tmp[10];
+        int n = 0;
+        do { tmp[n++] = char('0' + v % 10); v /= 10; } while (v);
+        while (n) put(uint8_t(tmp[--n]));
+    }
+    __device__ void finish() {
+        uint64_t bits = total * 8;
+        // put() keeps counting `total`; the length was captured above
+        put(0x80);
+        while (fill != 56) put(0);
+        for (int i = 0; i < 8; i++) put(uint8_t(bits >> (56 - 8 * i)));
+    }
+};
+
+__device__ __forceinline__ bool stop_codon_at(const uint8_t* s, uint32_t c, bool fwd) {
+    uint8_t a = s[c], b = s[c + 1], e = s[c + 2];
+    if (fwd) return a == 'T' && ((b == 'G' && e == 'A') || (b == 'A' && (e == 'G' || e == 'A')));
+    return (a == 'T' && b == 'C' && e == 'A') || (a == 'C' && b == 'T' && e == 'A') || (a == 'T' && b == 'T' && e == 'A');
+}
+
+__global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_slots) {
+    uint64_t g = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t w = g < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
+    bool live = w != 0xFFFFFFFFu;
+    uint32_t sumflags = 0;
+    bool need_rec = false;
+    HapRec rec;
+    if (live) {
+        const WinStatic ws = d.wins[w];
+        const TxDev T = d.tx[ws.tx];
+        const uint32_t vbase = d.g_var_off[T.gene];
+        const uint32_t gstart = d.g_start[T.gene];
+        const uint8_t* ref = d.ref_pool + d.g_ref_off[T.gene];
+        const uint64_t hap = d.groups[g].hap;
+        const bool is_rev = T.strand != 0;
+        const uint32_t ncols = ws.ncols;
+        const uint32_t window_end = ws.sso + ws.wlen;
+        uint32_t i = ws.sso, j = 0;
+        uint32_t ns = 0, ngm = 0;
+        uint32_t nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
+        uint64_t prof_set = 0;
+        bool indel = false, insertion = false, broke_flag = false;
+        uint32_t pos_j = 0, info_j = 0, f_j = 0;
+        auto load_j = [&]() {
+            if (j < ncols) {
+                uint32_t dq = is_rev ? (ncols - 1 - j) : j;
+                uint32_t tr = ws.col_lo + dq;
+                f_j = is_rev ? d.v_rev2fwd[vbase + tr] : tr;
+                pos_j = d.v_pos[vbase + f_j];
+                info_j = d.v_info[vbase + f_j];
+            }
+        };
+        auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) rec.seq[ns] = c; ns++; };
+        auto push_g = [&](uint8_t c) { if (ngm < SEQ_CAP) rec.germ[ngm] = c; ngm++; };
+        load_j();
+        while (i < window_end) {
+            while (j < ncols && i == pos_j) {
+                uint32_t fs = (info_j & VI_FS_MASK) >> VI_FS_SHIFT;
+                if (first_fs == 0 && fs) { first_fs = fs; first_fs_j = j; }
+                uint32_t dq = is_rev ? (ncols - 1 - j) : j;
+                uint32_t bit = ncols - 1 - dq;
+                if ((hap >> bit) & 1) {
+                    uint32_t kind = info_j & VI_KIND_MASK;
+                    bool germline = info_j & VI_GERMLINE;
+                    uint8_t r = ref[i - gstart];
+                    bool brk = false;
+                    if (kind == 0) {
+                        uint8_t alt = uint8_t(info_j >> VI_ALT_SHIFT);
+                        uint8_t sw = is_upper(r) ? to_lower(alt) : alt;
+                        push_g(germline ? sw : r);
+                        push_s(sw);
+                        i += 1;
+                    } else if (kind == 1) {
+                        uint32_t il = d.v_len[vbase + f_j] + 1;
+                        const uint8_t* ins = d.ins_pool + d.v_insoff[vbase + f_j];
+                        bool up = is_upper(r);
+                        for (uint32_t k = 0; k < il; k++) {
+                            uint8_t c = up ? to_lower(ins[k]) : to_upper(ins[k]);
+                            if (germline) push_g(c);
+                            push_s(c);
+                        }
+                        if (!germline) indel = true;
+                        insertion = true;
+                        i += 1;
+                    } else {
+                        uint32_t dl = d.v_len[vbase + f_j];
+                        if (is_rev && pos_j + dl - 1 >= window_end) { brk = true; }
+                        else {
+                            if (germline || i == window_end - 1) push_g(r);
+                            else {
+                                for (uint32_t k = 0; k < dl + 1; k++) push_g(ref[i - gstart + k]);
+                                indel = true;
+                            }
+                            push_s(r);
+                            i += dl + 1;
+                        }
+                    }
+                    if (brk) { broke_flag = true; break; }
+                    if (!germline) nsom++;
+                    nvar++;
+                    prof_set |= 1ull << j;
+                }
+                j++;
+                load_j();
+            }
+            if (i < window_end) {
+                uint8_t r = ref[i - gstart];
+                push_s(r);
+                push_g(r);
+                i++;
+            }
+        }
+        uint32_t seq_len = min(ns, uint32_t(SEQ_CAP)), germ_len = min(ngm, uint32_t(SEQ_CAP));
+        // neopeptide slice and stop scan (:686-697, :42-76)
+        uint32_t this_len = seq_len < ws.ewl ? seq_len : ws.ewl;
+        uint32_t nlo = 0, nhi = seq_len;
+        if (ws.splice_pos == 1) nlo = min(uint32_t(ws.splice_gap), seq_len);
+        else if (ws.splice_pos == 0 && !insertion) nhi = this_len;
+        bool stop = false;
+        uint32_t nlen = nhi - nlo;
+        if (nlen >= 3) {
+            if (!is_rev) {
+                for (uint32_t c = 0; c + 3 <= nlen; c += 3)
+                    if (stop_codon_at(rec.seq + nlo, c, true)) { stop = true; break; }
+            } else {
+                for (int c = int(nlen) - 3; c >= 0; c -= 3)
+                    if (stop_codon_at(rec.seq + nlo, uint32_t(c), false)) { stop = true; break; }
+            }
+        }
+        bool differs = seq_len != germ_len;
+        if (!differs)
+            for (uint32_t k = 0; k < seq_len; k++)
+                if (rec.seq[k] != rec.germ[k]) { differs = true; break; }
+        sumflags = GS_VALID | (stop ? GS_STOP : 0) | (differs ? GS_DIFFERS : 0) | (indel ? GS_INDEL : 0) |
+                   (insertion ? GS_INSERTION : 0) | (broke_flag ? GS_BROKE : 0);
+        const bool want_all = (ws.flags & (SF_FIRST_EXON_WIN | SF_LAST_EXON_WIN | SF_SHORT_EXON)) || ws.need_recs;
+        need_rec = nsom > 0 || want_all;
+        rec.prof_set = prof_set;
+        rec.seq_len = uint8_t(seq_len);
+        rec.germ_len = uint8_t(germ_len);
+        rec.prof_len = uint8_t(j);
+        rec.nvar = uint8_t(nvar);
+        rec.nsom = uint8_t(nsom);
+        rec.first_fs = uint8_t(first_fs);
+        rec.first_fs_j = uint8_t(first_fs_j);
+        rec.pad = 0;
+        rec.id60 = 0;
+        if (need_rec && (nsom > 0 || ws.need_recs)) {
+            // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (:667-675)
+            Sha1Dev sh;
+            sh.init();
+            sh.put('[');
+            for (uint32_t k = 0; k < seq_len; k++) {
+                if (k) { sh.put(','); sh.put(' '); }
+                sh.put_dec(rec.seq[k]);
+            }
+            sh.put(']');
+            for (uint32_t k = 0; k < T.id_len; k++) sh.put(d.str_pool[T.id_off + k]);
+            sh.put_dec(ws.sso);
+            sh.finish();
+            rec.id60 = (uint64_t(sh.h[0]) << 28) | (uint64_t(sh.h[1]) >> 4);
+            sumflags |= GS_ID_VALID;
+        }
+        if (stop && ws.splice_pos != 2 && !(ws.flags & SF_FIRST_EXON_WIN)) atomicMin(&d.tx_first_stop[ws.tx], w);
+    }
+    // compact record allocation: one atomic per wave
+    uint64_t m = __ballot(need_rec);
+    uint32_t recidx = 0;
+    if (m) {
+        unsigned long long base = 0;
+        uint32_t leader = __builtin_ctzll(m);
+        if (lane == leader) base = atomicAdd(d.cursors + 1, (unsigned long long)__popcll(m));
+        uint32_t blo = __shfl(uint32_t(base), leader), bhi = __shfl(uint32_t(base >> 32), leader);
+        uint64_t b = (uint64_t(bhi) << 32) | blo;
+        uint64_t mine = b + lanes_below(m, lane);
+        if (need_rec) {
+            if (mine < d.rec_cap) {
+                d.recs[mine] = rec;
+                sumflags |= GS_HAS_REC;
+                recidx = uint32_t(mine);
+            } else {
+                atomicOr(d.err, WD_GROUP_OVERFLOW);
+            }
+        }
+    }
+    if (live) {
+        GroupSum gs;
+        gs.flags = sumflags;
+        gs.rec = recidx;
+        d.gsum[g] = gs;
+    }
+}
+
+// ====================================================================== launchers
+void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
+    if (d.n_reads == 0) return;
+    dim3 grid((d.n_reads + 255) / 256), block(256);
+    switch (d.mask_words) {
+        case 1: hipLaunchKernelGGL(k1_pileup_bits<1>, grid, block, 0, stream, d); break;
+        case 2: hipLaunchKernelGGL(k1_pileup_bits<2>, grid, block, 0, stream, d); break;
+        case 3: case 4: {
+            DeviceBatch d4 = d;
+            if (d.mask_words == 3) throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+            hipLaunchKernelGGL(k1_pileup_bits<4>, grid, block, 0, stream, d4);
+            break;
+        }
+        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+    HIP_CHECK_LAUNCH();
+}
+
+void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream) {
+    if (d.n_tx == 0) return;
+    dim3 grid(d.n_tx), block(64);
+    switch (rows_per_lane) {
+        case 1: hipLaunchKernelGGL(k2_window_replay<1>, grid, block, 0, stream, d); break;
+        case 2: hipLaunchKernelGGL(k2_window_replay<2>, grid, block, 0, stream, d); break;
+        case 4: hipLaunchKernelGGL(k2_window_replay<4>, grid, block, 0, stream, d); break;
+        case 8: hipLaunchKernelGGL(k2_window_replay<8>, grid, block, 0, stream, d); break;
+        case 16: hipLaunchKernelGGL(k2_window_replay<16>, grid, block, 0, stream, d); break;
+        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+    HIP_CHECK_LAUNCH();
+}
+
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {
+    if (n_group_slots == 0) return;
+    dim3 grid(uint32_t((n_group_slots + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k3_window_seq, grid, block, 0, stream, d, n_group_slots);
+    HIP_CHECK_LAUNCH();
+}
+
+}  // namespace mp

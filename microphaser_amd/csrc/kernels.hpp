@@ -1,0 +1,50 @@
+// Launch interface of the gfx950 kernels (kernels.hip). Host code never sees kernel symbols.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plan.hpp"
+
+namespace mp {
+
+struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
+    // genes
+    const uint32_t *g_read_off, *g_var_off, *g_start;
+    const uint64_t* g_ref_off;
+    // reads
+    const uint32_t *r_gene, *r_pos, *r_end, *r_lseq, *r_ncig, *r_dup;
+    const uint64_t *r_cigoff, *r_seqoff, *r_qualoff;
+    const uint32_t* cigar_pool;
+    const uint8_t *seq_pool, *qual_pool;
+    // variants
+    const uint32_t *v_pos, *v_info, *v_len, *v_insoff, *v_rev2fwd;
+    const uint8_t* ins_pool;
+    const uint8_t* ref_pool;
+    // plan
+    const TxDev* tx;
+    const Step* steps;
+    const WinStatic* wins;
+    const uint8_t* str_pool;
+    const uint32_t* tx_order;
+    uint32_t n_reads, n_tx, n_wins, mask_words;
+    // K1 output
+    uint32_t* r_varlo;
+    uint64_t *r_sup, *r_lq;  // [read * mask_words + w]
+    // K2 output
+    WinDyn* win_dyn;
+    Group* groups;
+    uint32_t* g_win;              // window of each group slot (0xFFFFFFFF = unused slot)
+    unsigned long long* cursors;  // [0] group cursor, [1] record cursor
+    uint64_t group_cap, rec_cap;
+    uint32_t* err;                // sticky error word (WD_* bits)
+    // K3 output
+    GroupSum* gsum;
+    HapRec* recs;
+    uint32_t* tx_first_stop;      // per transcript: smallest window index with a main-ORF stop (0xFFFFFFFF none)
+};
+
+// rows_per_lane in {1,2,4,8,16}. All launches are asynchronous on `stream`.
+void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
+void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream);
+
+}  // namespace mp

@@ -1,0 +1,293 @@
+// Planner: packs loaded genes into the device batch and records the static window schedule.
+// reference: the data-independent part of phase_gene (src/microphasing.rs:905-942 loading,
+// :944-1342 scheduler) - see walk.hpp for the shared control flow.
+#include <algorithm>
+#include <deque>
+#include <map>
+#include <numeric>
+
+#include "batch.hpp"
+
+namespace mp {
+
+namespace {
+
+struct PlannerHooks {
+    Batch& b;
+    const GeneHost& gh;
+    const std::vector<Variant>& vars;
+    const std::vector<uint32_t>& fwd2rev;  // gene-relative
+    bool is_fwd;
+    uint32_t tx_idx;
+    uint32_t cur_exon = 0;
+    std::deque<uint32_t> cols;  // transcription-order indices of the live columns (oldest first)
+    uint32_t col_hi = 0;
+    bool fs_seen = false;
+    uint64_t prev_cand_lo = 0;
+    bool have_prev_cand = false;
+    size_t cur_step = 0;
+    uint64_t max_live = 0;
+
+    uint32_t tr_index(size_t fwd_idx) const { return is_fwd ? uint32_t(fwd_idx) : fwd2rev[fwd_idx]; }
+
+    void on_exon(const ExonGeom& eg) {
+        ExonPlan ep;
+        ep.geom = eg;
+        ep.tx = tx_idx;
+        cur_exon = uint32_t(b.exons.size());
+        b.exons.push_back(ep);
+        have_prev_cand = false;
+    }
+
+    // gene-relative index of the first kept read with pos >= key
+    uint32_t read_lower(uint64_t key) const {
+        const uint32_t* p = b.r_pos.data() + gh.read_off;
+        return uint32_t(std::lower_bound(p, p + gh.n_reads, key, [](uint32_t a, uint64_t k) { return uint64_t(a) < k; }) - p);
+    }
+
+    void ensure_window(const ExonGeom& eg, const StepGeom& sg) {
+        Step& st = b.steps[cur_step];
+        if (st.flags & SF_PRINT) return;
+        st.flags |= SF_PRINT;
+        st.win = uint32_t(b.wins.size());
+        WinStatic w{};
+        w.tx = tx_idx;
+        w.sso = st.sso;
+        w.ncols = uint16_t(cols.size());
+        w.col_lo = col_hi - uint32_t(cols.size());
+        w.wlen = st.wlen;
+        w.ewl = uint8_t(eg.ewl);
+        w.splice_pos = uint8_t(sg.splice_pos);
+        w.splice_gap = uint8_t(sg.splice_gap);
+        w.flags = st.flags;
+        b.wins.push_back(w);
+        // upper bound of the sequence lengths print_haplotypes can build for this window
+        uint64_t max_len = st.wlen;
+        bool non_snv = false;
+        for (uint32_t c : cols) {
+            const Variant& v = vars[is_fwd ? c : b.v_rev2fwd[gh.var_off + c]];
+            if (v.kind == VK_INS) max_len += v.seq.size();
+            if (v.kind == VK_DEL) max_len += v.len + 1;
+            if (v.kind != VK_SNV) non_snv = true;
+        }
+        b.wins.back().need_recs = (non_snv || fs_seen) ? 1 : 0;
+        if (max_len > SEQ_CAP)
+            throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
+                        " nt; this build supports at most " + std::to_string(SEQ_CAP) + " (long indel in window)");
+    }
+
+    void on_step(const ExonGeom& eg, const StepGeom& sg, const std::vector<size_t>& new_cols) {
+        Step st{};
+        if (sg.sso > 0xFFFFFFFFull) throw Error("coordinate exceeds 32 bits");
+        st.sso = uint32_t(sg.sso);
+        uint64_t wlen = sg.splice_end - sg.sso;
+        if (wlen > 255) throw Error("window longer than 255 nt is not supported");
+        st.wlen = uint8_t(wlen);
+        if (sg.deleted > cols.size()) throw Error("reference would panic: drain range out of bounds (shrink_left)");
+        if (sg.deleted > 255 || new_cols.size() > 255) throw Error("more than 255 column changes in one step");
+        st.n_del = uint8_t(sg.deleted);
+        st.n_add = uint8_t(new_cols.size());
+        for (size_t k = 0; k < sg.deleted; k++) cols.pop_front();
+        for (size_t k : new_cols) {
+            uint32_t tr = tr_index(k);
+            if (!cols.empty() && cols.back() + 1 != tr) {
+                // columns must stay a contiguous run in transcription order for the packed plan
+                throw Error("non-contiguous variant columns (unsupported scheduler corner case)");
+            }
+            cols.push_back(tr);
+            col_hi = tr + 1;
+            if (vars[k].frameshift() > 0) fs_seen = true;
+        }
+        if (cols.size() > 63) throw Error("more than 63 variant columns in one window (reference overflows its u64 haplotype word)");
+        st.col_hi = col_hi;
+        st.win = 0xFFFFFFFFu;
+        st.splice_pos = uint8_t(sg.splice_pos);
+        st.splice_gap = uint8_t(sg.splice_gap);
+        st.exon = cur_exon;
+        uint8_t fl = 0;
+        if (sg.is_first_exon_window) fl |= SF_FIRST_EXON_WIN;
+        if (sg.is_last_exon_window) fl |= SF_LAST_EXON_WIN;
+        if (eg.is_short) fl |= SF_SHORT_EXON;
+        if (eg.is_first) fl |= SF_FIRST_EXON;
+        if (eg.is_last) fl |= SF_LAST_EXON;
+        // candidate reads: forward = every key is tried exactly once (:1229-1248); reverse = the whole
+        // range is re-scanned every step (:1198-1226) - only the keys that newly entered the range are
+        // listed, the kernel keeps the not-yet-admitted ones pending.
+        uint64_t lo = sg.cand_lo, hi = sg.cand_hi;
+        if (sg.is_first_exon_window) {
+            fl |= SF_FULL_RANGE;
+        } else if (!is_fwd && have_prev_cand) {
+            hi = std::min(hi, prev_cand_lo);
+            if (hi < lo) hi = lo;
+        }
+        prev_cand_lo = sg.cand_lo;
+        have_prev_cand = true;
+        uint32_t c0 = read_lower(lo), c1 = read_lower(hi);
+        if (c1 - c0 > 65535) throw Error("more than 65535 candidate reads in one step");
+        st.cand_lo = c0;
+        st.cand_n = uint16_t(c1 - c0);
+        st.flags = fl;
+        cur_step = b.steps.size();
+        b.steps.push_back(st);
+        // live-row bound: reads whose start lies in the full candidate key range of this step
+        uint64_t span = uint64_t(read_lower(sg.cand_hi)) - read_lower(sg.sso >= (gh.max_read_len) ? sg.sso - gh.max_read_len : 0);
+        max_live = std::max(max_live, span);
+        if (fs_seen) ensure_window(eg, sg);
+    }
+
+    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
+        ensure_window(eg, sg);
+        if (frame == 0) b.n_main_windows++;
+        fsf.emplace(frame, std::make_pair(1.0, false));
+        std::vector<HapSeq> v(1);
+        return {std::move(v), std::move(fsf)};
+    }
+
+    void splice_merge(const ExonGeom&, const StepGeom&, uint64_t, std::map<uint64_t, uint64_t>&, FsFreq&, std::vector<HapSeq>&,
+                      std::vector<HapSeq>&) {}
+};
+
+}  // namespace
+
+void build_batch(const std::vector<GeneInput>& genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
+    b = Batch();
+    b.window_len = window_len;
+    b.genes.resize(genes.size());
+    uint32_t max_span_vars = 0;
+    for (size_t gi_ = 0; gi_ < genes.size(); gi_++) {
+        const GeneInput& gi = genes[gi_];
+        GeneHost& gh = b.genes[gi_];
+        gh.input = &gi;
+        if (gi.gene.end() + 100 > 0xFFFFFFF0ull) throw Error("coordinate exceeds 32 bits");
+        // ---- reads: read_tree (:909-920)
+        std::vector<size_t> kept;
+        for (size_t r : gi.reads) {
+            if (rs.mapq[r] < mapq_min) continue;
+            gh.max_read_len = std::max<uint64_t>(gh.max_read_len, rs.l_seq[r]);
+            kept.push_back(r);
+        }
+        std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t c) { return rs.pos[a] < rs.pos[c]; });
+        gh.read_off = uint32_t(b.r_pos.size());
+        gh.n_reads = uint32_t(kept.size());
+        std::map<std::pair<int64_t, std::string>, uint32_t> first_of;
+        for (size_t k = 0; k < kept.size(); k++) {
+            size_t r = kept[k];
+            if (rs.pos[r] < 0) throw Error("negative read position");
+            b.r_pos.push_back(uint32_t(rs.pos[r]));
+            b.r_end.push_back(uint32_t(rs.end_pos[r]));
+            b.r_lseq.push_back(rs.l_seq[r]);
+            b.r_ncig.push_back(rs.n_cigar[r]);
+            b.r_cigoff.push_back(b.cigar_pool.size());
+            b.cigar_pool.insert(b.cigar_pool.end(), rs.cigar(r), rs.cigar(r) + rs.n_cigar[r]);
+            b.r_seqoff.push_back(b.seq_pool.size());
+            const uint8_t* s4 = rs.seq_pool.data() + rs.seq_off[r];
+            b.seq_pool.insert(b.seq_pool.end(), s4, s4 + (rs.l_seq[r] + 1) / 2);
+            b.r_qualoff.push_back(b.qual_pool.size());
+            b.qual_pool.insert(b.qual_pool.end(), rs.qual(r), rs.qual(r) + rs.l_seq[r]);
+            auto key = std::make_pair(rs.pos[r], std::string(rs.qname(r)));
+            auto it = first_of.find(key);
+            uint32_t dup;
+            if (it == first_of.end()) { first_of.emplace(key, uint32_t(k)); dup = uint32_t(k); }
+            else dup = it->second | 0x80000000u;  // bit31: an earlier read has the same (pos, qname)
+            b.r_dup.push_back(dup);
+            b.r_src.push_back(r);
+        }
+        // mark the FIRST read of each duplicated (pos, qname) key too
+        for (size_t k = 0; k < kept.size(); k++) {
+            uint32_t d = b.r_dup[gh.read_off + k];
+            if (d & 0x80000000u) b.r_dup[gh.read_off + (d & 0x7FFFFFFFu)] |= 0x80000000u;
+        }
+        // ---- variants
+        gh.var_off = uint32_t(b.v_pos.size());
+        gh.n_vars = uint32_t(gi.variants.size());
+        for (const Variant& v : gi.variants) {
+            b.v_pos.push_back(uint32_t(v.pos));
+            uint32_t info = uint32_t(v.kind) | (v.is_germline ? VI_GERMLINE : 0) | (uint32_t(v.frameshift()) << VI_FS_SHIFT) |
+                            (uint32_t(v.alt) << VI_ALT_SHIFT);
+            b.v_info.push_back(info);
+            b.v_len.push_back(uint32_t(v.len));
+            b.v_insoff.push_back(uint32_t(b.ins_pool.size()));
+            if (v.kind == VK_INS) b.ins_pool.insert(b.ins_pool.end(), v.seq.begin(), v.seq.end());
+        }
+        std::vector<uint32_t> fwd2rev(gi.variants.size());
+        {
+            size_t hi = gi.variants.size();
+            uint32_t rv = 0;
+            b.v_rev2fwd.resize(gh.var_off + gi.variants.size());
+            while (hi > 0) {
+                size_t lo = hi - 1;
+                while (lo > 0 && gi.variants[lo - 1].pos == gi.variants[hi - 1].pos) lo--;
+                for (size_t k = lo; k < hi; k++) {
+                    b.v_rev2fwd[gh.var_off + rv] = uint32_t(k);
+                    fwd2rev[k] = rv++;
+                }
+                hi = lo;
+            }
+        }
+        // mask width: variants spanned by one read
+        {
+            size_t vlo = 0, vhi = 0;
+            const auto& vs = gi.variants;
+            for (size_t k = 0; k < kept.size(); k++) {
+                uint64_t s = b.r_pos[gh.read_off + k], e = b.r_end[gh.read_off + k];
+                while (vlo < vs.size() && vs[vlo].pos < s) vlo++;
+                if (vhi < vlo) vhi = vlo;
+                while (vhi < vs.size() && vs[vhi].pos < e) vhi++;
+                size_t hi2 = vhi;
+                // reads are start-sorted but ends are not monotone: recount the tail exactly
+                while (hi2 > vlo && vs[hi2 - 1].pos >= e) hi2--;
+                max_span_vars = std::max<uint32_t>(max_span_vars, uint32_t(hi2 - vlo));
+            }
+        }
+        // ---- refseq
+        gh.ref_off = b.ref_pool.size();
+        b.ref_pool.insert(b.ref_pool.end(), gi.refseq.begin(), gi.refseq.end());
+        b.g_read_off.push_back(gh.read_off);
+        b.g_var_off.push_back(gh.var_off);
+        b.g_start.push_back(uint32_t(gi.gene.start()));
+        b.g_ref_off.push_back(gh.ref_off);
+        // ---- transcripts
+        gh.tx_off = uint32_t(b.tx.size());
+        VarIndex vi{&gi.variants};
+        for (size_t ti = 0; ti < gi.gene.transcripts.size(); ti++) {
+            const Transcript& t = gi.gene.transcripts[ti];
+            if (!t.is_coding()) continue;
+            TxDev td{};
+            td.gene = uint32_t(gi_);
+            td.step_off = uint32_t(b.steps.size());
+            td.strand = t.strand == FORWARD ? 0 : 1;
+            td.id_off = uint32_t(b.str_pool.size());
+            td.id_len = uint32_t(t.id.size());
+            b.str_pool.insert(b.str_pool.end(), t.id.begin(), t.id.end());
+            // start-loss interval (:1305-1319): the first scheduled exon's first codon
+            td.sl_lo = 1; td.sl_hi = 0;
+            for (const Interval& ex : t.exons) {
+                if (ex.start > ex.end) continue;
+                if (t.strand == FORWARD) { td.sl_lo = uint32_t(ex.start); td.sl_hi = uint32_t(ex.start + 3); }
+                else { td.sl_lo = uint32_t(ex.end >= 3 ? ex.end - 3 : 0); td.sl_hi = uint32_t(ex.end); }
+                break;
+            }
+            PlannerHooks hooks{b, gh, gi.variants, fwd2rev, t.strand == FORWARD, uint32_t(b.tx.size())};
+            walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks);
+            td.n_steps = uint32_t(b.steps.size()) - td.step_off;
+            b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
+            b.tx.push_back(td);
+            gh.tx_src.push_back(uint32_t(ti));
+        }
+        gh.n_tx = uint32_t(b.tx.size()) - gh.tx_off;
+    }
+    b.g_read_off.push_back(uint32_t(b.r_pos.size()));
+    b.g_var_off.push_back(uint32_t(b.v_pos.size()));
+    b.mask_words = max_span_vars <= 64 ? 1 : max_span_vars <= 128 ? 2 : 4;
+    if (max_span_vars > 256) throw Error("a read spans more than 256 variants; mask width not supported");
+    b.tx_order.resize(b.tx.size());
+    std::iota(b.tx_order.begin(), b.tx_order.end(), 0u);
+    std::stable_sort(b.tx_order.begin(), b.tx_order.end(), [&](uint32_t a, uint32_t c) { return b.tx[a].n_steps > b.tx[c].n_steps; });
+}
+
+uint64_t Batch::bytes_k1_in() const {
+    return r_pos.size() * (4 * 5 + 8 * 3) + cigar_pool.size() * 4 + seq_pool.size() + qual_pool.size() + v_pos.size() * 12;
+}
+uint64_t Batch::bytes_k1_out() const { return r_pos.size() * (4 + 16ull * mask_words); }
+
+}  // namespace mp

@@ -1,0 +1,119 @@
+// Packed, device-ready form of a batch of genes ("the batch") and the static window schedule
+// ("the plan") the HIP kernels replay. Plain-old-data structs in this header are shared
+// verbatim between host code and kernels.hip.
+//
+// Layout in HBM (all struct-of-arrays, gene-major):
+//   reads     : r_pos r_end r_lseq r_ncig r_cigoff r_seqoff r_qualoff r_dup   + cigar/seq/qual pools
+//   variants  : v_pos v_info v_len v_insoff (forward = ascending pos, ALT order within a pos)
+//               v_rev2fwd (transcription order of '-' strand genes -> forward index)   + ins pool
+//   refseq    : bytes of [gene.start, gene.end+100) per gene, case preserved
+//   plan      : TxDev per transcript, Step per nt-offset step, WinStatic per printing step
+//   K1 output : r_varlo, r_sup[W], r_lq[W]            (read x variant predicate bits)
+//   K2 output : WinDyn per printing step, Group per distinct (haplotype, frame) key
+//   K3 output : GroupSum per group, HapRec per group that can be emitted / merged
+#pragma once
+#include <cstdint>
+
+namespace mp {
+
+// v_info bit layout
+enum : uint32_t {
+    VI_KIND_MASK = 0x3,        // VarKind
+    VI_GERMLINE = 1u << 2,
+    VI_FS_SHIFT = 3,           // frameshift() in {0,1,2}
+    VI_FS_MASK = 0x3u << 3,
+    VI_ALT_SHIFT = 8,          // SNV alt byte
+};
+
+struct TxDev {           // one per coding transcript
+    uint32_t gene;       // batch gene index
+    uint32_t step_off;   // first Step
+    uint32_t n_steps;
+    uint32_t strand;     // 0 forward, 1 reverse
+    uint32_t sl_lo, sl_hi;   // start-loss position interval [lo, hi) (empty if lo >= hi)
+    uint32_t id_off, id_len; // transcript id bytes in the string pool (hashed into haplotype ids)
+};
+
+// Step.flags
+enum : uint8_t {
+    SF_PRINT = 1,        // print_haplotypes may be called at this step (superset)
+    SF_FULL_RANGE = 2,   // candidates are a full key range (first window of an exon): reverse strand re-scans
+    SF_FIRST_EXON_WIN = 4,
+    SF_LAST_EXON_WIN = 8,
+    SF_SHORT_EXON = 16,
+    SF_FIRST_EXON = 32,
+    SF_LAST_EXON = 64,
+};
+
+struct Step {            // one per nt-offset step of the window scheduler (reference: microphasing.rs:1030-1914)
+    uint32_t sso;        // splice_side_offset (absolute, 0-based)
+    uint32_t cand_lo;    // gene-relative index of the first NEW candidate read
+    uint32_t col_hi;     // transcription-order variant index one past the newest column after this step
+    uint32_t win;        // window index if SF_PRINT else 0xFFFFFFFF
+    uint16_t cand_n;     // number of new candidate reads
+    uint8_t wlen;        // splice_end - sso
+    uint8_t n_del;       // columns dropped at this step (incl. the exon-start shrink of last_window_vars)
+    uint8_t n_add;       // columns appended at this step
+    uint8_t flags;       // SF_*
+    uint8_t splice_pos;  // 0,1,2
+    uint8_t splice_gap;
+    uint32_t exon;       // index into the host-side ExonPlan array
+};
+static_assert(sizeof(Step) == 28, "Step layout");
+
+struct WinStatic {       // one per printing step; everything K3 needs that does not depend on reads
+    uint32_t tx;
+    uint32_t sso;
+    uint32_t col_lo;     // transcription-order index of the OLDEST column
+    uint16_t ncols;
+    uint8_t wlen;
+    uint8_t ewl;         // exon_window_len passed to print_haplotypes as window_len
+    uint8_t splice_pos;
+    uint8_t splice_gap;
+    uint8_t flags;       // SF_* of the step
+    uint8_t need_recs;   // 1: K3 writes a HapRec (+id) for EVERY haplotype (indel / frameshift context)
+};
+static_assert(sizeof(WinStatic) == 20, "WinStatic layout");
+
+struct WinDyn {          // K2 output per printing step
+    uint32_t group_off;  // first Group
+    uint32_t ngroups;
+    uint32_t nrows;      // ObservationMatrix::nrows() (depth column)
+    uint32_t flags;      // WD_*
+};
+enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4 };
+
+struct Group {           // K2 output: one distinct (haplotype, frame.0, frame.1 != 0) key of one window, ascending
+    uint64_t hap;
+    uint32_t count;
+    uint32_t aux;        // frame0 << 1 | (frame1 != 0)
+};
+
+// GroupSum.flags
+enum : uint32_t {
+    GS_VALID = 1,
+    GS_STOP = 2,         // has_stop_codon(neopeptide)
+    GS_DIFFERS = 4,      // germline_seq != seq (before any clearing)
+    GS_INDEL = 8,
+    GS_INSERTION = 16,
+    GS_BROKE = 32,       // reverse-strand incomplete deletion hit (variant index = prof_len)
+    GS_HAS_REC = 64,     // a HapRec was written (rec index in GroupSum.rec)
+    GS_ID_VALID = 128,   // HapRec.id holds the SHA-1 prefix
+};
+struct GroupSum {        // K3 output per group
+    uint32_t flags;
+    uint32_t rec;        // HapRec index if GS_HAS_REC
+};
+
+constexpr int SEQ_CAP = 48;
+struct HapRec {          // K3 output for groups whose sequence the host needs
+    uint64_t prof_set;   // bit c set <=> variant_profile[c] != 0 (c < prof_len)
+    uint64_t id60;       // first 60 bits of the SHA-1 (15 hex digits), big-endian in the low 60 bits
+    uint8_t seq_len, germ_len, prof_len, nvar, nsom, first_fs, first_fs_j, pad;
+    uint8_t seq[SEQ_CAP];
+    uint8_t germ[SEQ_CAP];
+    uint8_t pad2[8];
+};
+static_assert(sizeof(HapRec) == 128, "HapRec layout");
+
+}  // namespace mp

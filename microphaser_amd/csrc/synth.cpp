@@ -1,0 +1,289 @@
+// Deterministic synthetic exome generator: the benchmark workload of
+// BASELINE.json configs[1..3] ("synthetic 1k / 20k-transcript exome, 30x, ~5 variant sites per
+// window" and the 500x / 20-sites stress case). Everything is generated in memory in the very
+// same containers the file readers fill (BamData, VcfData, GTF text, contigs), so the in-memory
+// path and the on-disk path (dataset_write_files + dataset_load_files) see identical inputs.
+#include "synth.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+namespace mp {
+
+namespace {
+
+struct Rng {  // splitmix64 seeded xoshiro256**
+    uint64_t s[4];
+    explicit Rng(uint64_t seed) {
+        uint64_t z = seed;
+        for (auto& x : s) {
+            z += 0x9E3779B97F4A7C15ull;
+            uint64_t y = z;
+            y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull;
+            y = (y ^ (y >> 27)) * 0x94D049BB133111EBull;
+            x = y ^ (y >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uni() { return double(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint64_t below(uint64_t n) { return n ? next() % n : 0; }
+    double normal() {
+        double u1 = uni(), u2 = uni();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+    uint32_t poisson(double lambda) {
+        double l = std::exp(-lambda), p = 1.0;
+        uint32_t k = 0;
+        do { k++; p *= uni(); } while (p > l);
+        return k - 1;
+    }
+};
+
+const char BASES[4] = {'A', 'C', 'G', 'T'};
+inline uint8_t code4(char b) { return b == 'A' ? 1 : b == 'C' ? 2 : b == 'G' ? 4 : b == 'T' ? 8 : 15; }
+inline char comp(char b) { return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A' : 'N'; }
+inline bool is_stop(char a, char b, char c) { return a == 'T' && ((b == 'A' && (c == 'A' || c == 'G')) || (b == 'G' && c == 'A')); }
+const char* AA3[20] = {"Ala", "Arg", "Asn", "Asp", "Cys", "Gln", "Glu", "Gly", "His", "Ile",
+                       "Leu", "Lys", "Met", "Phe", "Pro", "Ser", "Thr", "Trp", "Tyr", "Val"};
+
+struct SynVar { uint64_t pos; char alt; bool somatic; int hap; /* 0 = A, 1 = B, 2 = both */ };
+
+}  // namespace
+
+void synth_generate(const SynthConfig& cfg, Dataset& ds) {
+    ds = Dataset();
+    Rng rng(cfg.seed);
+    const uint32_t n_contigs = 4;
+    const uint32_t L = cfg.read_len;
+    ds.contig_names.resize(n_contigs);
+    ds.contig_seq.resize(n_contigs);
+    for (uint32_t c = 0; c < n_contigs; c++) ds.contig_names[c] = "chrS" + std::to_string(c + 1);
+    std::ostringstream gtf;
+    ReadStore& rs = ds.bam.reads;
+    ds.bam.ref_names = ds.contig_names;
+    uint64_t read_serial = 0;
+    struct PendingRead { uint64_t pos; std::vector<uint8_t> seq4, qual; uint8_t mapq; uint64_t serial; };
+    std::vector<uint8_t> seq4((L + 1) / 2), qual(L);
+    const uint32_t per_contig = (cfg.n_transcripts + n_contigs - 1) / n_contigs;
+    uint32_t tx_serial = 0;
+    for (uint32_t c = 0; c < n_contigs; c++) {
+        std::string& contig = ds.contig_seq[c];
+        contig.assign(2000, 'N');
+        for (char& ch : contig) ch = BASES[rng.below(4)];
+        std::vector<PendingRead> creads;
+        for (uint32_t gi = 0; gi < per_contig && tx_serial < cfg.n_transcripts; gi++, tx_serial++) {
+            const bool reverse = (tx_serial & 1) != 0;
+            // ---- exon structure
+            uint32_t n_exons = std::min<uint32_t>(30, std::max<uint32_t>(1, 1 + rng.poisson(8.0)));
+            std::vector<uint64_t> elen(n_exons);
+            uint64_t cds = 0;
+            for (auto& e : elen) {
+                double v = 130.0 * std::exp(0.6 * rng.normal());
+                e = uint64_t(std::min(1500.0, std::max(30.0, v)));
+                cds += e;
+            }
+            elen.back() += (3 - cds % 3) % 3;
+            cds += (3 - cds % 3) % 3;
+            const uint64_t utr = 150, margin = 200;
+            // genomic layout (ascending): margin | [3'UTR+stop if reverse] exons/introns [stop+3'UTR if forward] | margin
+            const uint64_t gene_start = contig.size();
+            uint64_t cur = gene_start + margin;
+            std::vector<std::pair<uint64_t, uint64_t>> gexons(n_exons);  // genomic order
+            uint64_t utr_lo = 0, utr_hi = 0, stop_lo = 0;
+            if (reverse) { utr_lo = cur; utr_hi = cur + utr; stop_lo = utr_hi; cur = stop_lo + 3; }
+            for (uint32_t k = 0; k < n_exons; k++) {
+                uint64_t len = reverse ? elen[n_exons - 1 - k] : elen[k];
+                gexons[k] = {cur, cur + len};
+                cur += len;
+                if (k + 1 < n_exons) cur += 200 + rng.below(4801);
+            }
+            if (!reverse) { stop_lo = cur; utr_lo = cur + 3; utr_hi = utr_lo + utr; cur = utr_hi; }
+            const uint64_t gene_end = cur + margin;
+            // ---- reference bases
+            contig.resize(gene_end + 2000);
+            for (uint64_t p = gene_start; p < gene_end + 2000; p++) contig[p] = BASES[rng.below(4)];
+            // spliced CDS in transcript orientation: remove in-frame stops, put ATG first, real stop after
+            std::vector<uint64_t> cds_pos;  // genomic position of each CDS base in transcript order
+            if (!reverse) {
+                for (auto& ex : gexons) for (uint64_t p = ex.first; p < ex.second; p++) cds_pos.push_back(p);
+            } else {
+                for (size_t k = gexons.size(); k-- > 0;) for (uint64_t p = gexons[k].second; p-- > gexons[k].first;) cds_pos.push_back(p);
+            }
+            auto tbase = [&](size_t i) { return reverse ? comp(contig[cds_pos[i]]) : contig[cds_pos[i]]; };
+            auto set_tbase = [&](size_t i, char b) { contig[cds_pos[i]] = reverse ? comp(b) : b; };
+            set_tbase(0, 'A'); set_tbase(1, 'T'); set_tbase(2, 'G');
+            for (size_t i = 3; i + 2 < cds_pos.size(); i += 3)
+                while (is_stop(tbase(i), tbase(i + 1), tbase(i + 2))) set_tbase(i + 1, BASES[rng.below(4)]);
+            if (!reverse) { contig[stop_lo] = 'T'; contig[stop_lo + 1] = 'A'; contig[stop_lo + 2] = 'A'; }
+            else { contig[stop_lo] = 'T'; contig[stop_lo + 1] = 'T'; contig[stop_lo + 2] = 'A'; }  // revcomp(TAA)
+            // ---- GTF (transcription order, Ensembl style)
+            char gid[32], tid[32], gname[32];
+            std::snprintf(gid, sizeof gid, "SYNG%08u", tx_serial);
+            std::snprintf(tid, sizeof tid, "SYNT%08u", tx_serial);
+            std::snprintf(gname, sizeof gname, "SG%u", tx_serial);
+            const char* chrom = ds.contig_names[c].c_str();
+            const char strand = reverse ? '-' : '+';
+            std::string attr_g = std::string("gene_id \"") + gid + "\"; gene_name \"" + gname + "\"; gene_biotype \"protein_coding\";";
+            std::string attr_t = std::string("gene_id \"") + gid + "\"; transcript_id \"" + tid + "\"; gene_name \"" + gname +
+                                 "\"; gene_biotype \"protein_coding\"; transcript_biotype \"protein_coding\";";
+            auto line = [&](const char* feat, uint64_t s0, uint64_t e0, const std::string& frame, const std::string& attr) {
+                gtf << chrom << "\tsynth\t" << feat << "\t" << (s0 + 1) << "\t" << e0 << "\t.\t" << strand << "\t" << frame << "\t" << attr << "\n";
+            };
+            line("gene", gene_start, gene_end, ".", attr_g);
+            line("transcript", gene_start, gene_end, ".", attr_t);
+            uint64_t consumed = 0;
+            for (uint32_t k = 0; k < n_exons; k++) {
+                const auto& ex = reverse ? gexons[n_exons - 1 - k] : gexons[k];
+                line("CDS", ex.first, ex.second, std::to_string((3 - consumed % 3) % 3), attr_t);
+                if (k == 0) {
+                    if (!reverse) line("start_codon", ex.first, ex.first + 3, "0", attr_t);
+                    else line("start_codon", ex.second - 3, ex.second, "0", attr_t);
+                }
+                consumed += ex.second - ex.first;
+            }
+            line("three_prime_utr", utr_lo, utr_hi, ".", attr_t);
+            // ---- variants: SNV sites inside the CDS
+            std::vector<SynVar> vars;
+            const double p_site = 1.0 / cfg.var_spacing;
+            for (auto& ex : gexons)
+                for (uint64_t p = ex.first; p < ex.second; p++) {
+                    if (rng.uni() >= p_site) continue;
+                    SynVar v;
+                    v.pos = p;
+                    do { v.alt = BASES[rng.below(4)]; } while (v.alt == contig[p]);
+                    v.somatic = rng.uni() < 0.2;
+                    if (v.somatic) v.hap = int(rng.below(2));
+                    else v.hap = rng.uni() < 0.1 ? 2 : int(rng.below(2));
+                    vars.push_back(v);
+                }
+            for (const SynVar& v : vars) {
+                VcfRecord r;
+                r.chrom = chrom;
+                r.pos = v.pos;
+                r.ref = std::string(1, contig[v.pos]);
+                r.alts = {std::string(1, v.alt)};
+                r.somatic = v.somatic;
+                uint32_t aa = uint32_t((v.pos * 2654435761ull) >> 7);
+                char ann[160];
+                std::snprintf(ann, sizeof ann, "%c|missense_variant|MODERATE|%s|%s|transcript|%s|protein_coding|1/1|c.%lluN>%c|p.%s%llu%s|||||",
+                              v.alt, gname, gid, tid, (unsigned long long)(v.pos % 100000), v.alt, AA3[aa % 20],
+                              (unsigned long long)(v.pos % 1000 + 1), AA3[(aa / 20) % 20]);
+                r.ann_first = ann;
+                ds.vcf.records.push_back(std::move(r));
+            }
+            // ---- reads: exome-capture shaped (exon +- flank), 101M, haplotype-resolved
+            for (auto& ex : gexons) {
+                uint64_t lo = ex.first - 100, hi = ex.second;  // start range
+                uint64_t span = hi - lo;
+                uint64_t n = uint64_t(std::llround(cfg.depth * double(span) / double(L)));
+                for (uint64_t k = 0; k < n; k++) {
+                    PendingRead pr;
+                    pr.pos = lo + rng.below(span);
+                    const int hap = int(rng.below(2));
+                    const bool tumor = rng.uni() < 0.6;
+                    pr.mapq = rng.uni() < 0.01 ? 0 : 60;
+                    pr.serial = read_serial++;
+                    std::fill(seq4.begin(), seq4.end(), 0);
+                    // variants overlapping this read
+                    auto it = std::lower_bound(vars.begin(), vars.end(), pr.pos, [](const SynVar& v, uint64_t p) { return v.pos < p; });
+                    for (uint32_t q = 0; q < L; q++) {
+                        uint64_t p = pr.pos + q;
+                        char bch = contig[p];
+                        while (it != vars.end() && it->pos < p) ++it;
+                        if (it != vars.end() && it->pos == p) {
+                            bool carries = it->somatic ? (it->hap == hap && tumor) : (it->hap == 2 || it->hap == hap);
+                            if (carries) bch = it->alt;
+                        }
+                        if (rng.uni() < 0.001) { char e; do { e = BASES[rng.below(4)]; } while (e == bch); bch = e; }
+                        seq4[q >> 1] |= uint8_t(code4(bch) << ((q & 1) ? 0 : 4));
+                        qual[q] = rng.uni() < 0.02 ? 5 : 35;
+                    }
+                    pr.seq4 = seq4;
+                    pr.qual = qual;
+                    creads.push_back(std::move(pr));
+                }
+            }
+        }
+        std::stable_sort(creads.begin(), creads.end(), [](const PendingRead& a, const PendingRead& b2) { return a.pos < b2.pos; });
+        ds.bam.tid_begin.push_back(rs.size());
+        uint32_t cig = (L << 4) | C_M;
+        for (const PendingRead& pr : creads) {
+            char name[32];
+            std::snprintf(name, sizeof name, "r%llu", (unsigned long long)pr.serial);
+            rs.add(int32_t(c), int64_t(pr.pos), pr.mapq, 0, &cig, 1, pr.seq4.data(), L, pr.qual.data(), name);
+        }
+        ds.bam.ref_lens.push_back(int64_t(contig.size()));
+    }
+    ds.bam.tid_begin.push_back(rs.size());
+    ds.vcf.contigs = ds.contig_names;
+    ds.gtf = gtf.str();
+    dataset_load_genes(ds, false);
+}
+
+void dataset_load_genes(Dataset& ds, bool warn_only) {
+    MemFasta mf;
+    for (size_t c = 0; c < ds.contig_names.size(); c++) mf.contigs[ds.contig_names[c]] = &ds.contig_seq[c];
+    std::istringstream in(ds.gtf);
+    ds.genes.clear();
+    load_gene_inputs(in, ds.bam, ds.vcf, ds.fasta ? static_cast<const RefSource&>(*ds.fasta) : static_cast<const RefSource&>(mf),
+                     warn_only, [&](GeneInput& gi) { ds.genes.push_back(std::move(gi)); });
+}
+
+void dataset_load_files(const std::string& bam, const std::string& vcf, const std::string& fasta, std::istream& gtf,
+                        bool warn_only, Dataset& ds) {
+    ds = Dataset();
+    load_bam(bam, ds.bam);
+    load_vcf(vcf, ds.vcf);
+    ds.fasta = std::make_shared<IndexedFasta>(fasta);
+    std::ostringstream ss;
+    ss << gtf.rdbuf();
+    ds.gtf = ss.str();
+    dataset_load_genes(ds, warn_only);
+}
+
+void dataset_write_files(const Dataset& ds, const std::string& prefix) {
+    write_bam(prefix + ".bam", ds.bam.ref_names, ds.bam.ref_lens, ds.bam.reads);
+    {
+        std::ofstream v(prefix + ".vcf");
+        v << "##fileformat=VCFv4.2\n";
+        for (size_t c = 0; c < ds.contig_names.size(); c++) v << "##contig=<ID=" << ds.contig_names[c] << ",length=" << ds.contig_seq[c].size() << ">\n";
+        v << "##INFO=<ID=SOMATIC,Number=0,Type=Flag,Description=\"somatic\">\n##INFO=<ID=ANN,Number=.,Type=String,Description=\"ann\">\n";
+        v << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+        for (const VcfRecord& r : ds.vcf.records) {
+            v << r.chrom << "\t" << (r.pos + 1) << "\t.\t" << r.ref << "\t";
+            for (size_t a = 0; a < r.alts.size(); a++) v << (a ? "," : "") << r.alts[a];
+            v << "\t.\t.\t";
+            if (r.somatic) v << "SOMATIC;";
+            v << "ANN=" << r.ann_first << "\n";
+        }
+    }
+    { std::ofstream g(prefix + ".gtf"); g << ds.gtf; }
+    {
+        std::ofstream f(prefix + ".fa"), fai(prefix + ".fa.fai");
+        uint64_t off = 0;
+        for (size_t c = 0; c < ds.contig_names.size(); c++) {
+            std::string hdr = ">" + ds.contig_names[c] + "\n";
+            f << hdr;
+            off += hdr.size();
+            const std::string& s = ds.contig_seq[c];
+            fai << ds.contig_names[c] << "\t" << s.size() << "\t" << off << "\t60\t61\n";
+            for (size_t p = 0; p < s.size(); p += 60) {
+                size_t n = std::min<size_t>(60, s.size() - p);
+                f.write(s.data() + p, long(n));
+                f << "\n";
+                off += n + 1;
+            }
+        }
+    }
+}
+
+}  // namespace mp

@@ -1,0 +1,36 @@
+// In-memory data set (what `microphaser somatic` reads from BAM / VCF / FASTA / GTF) and the
+// deterministic synthetic exome generator used by the benchmark.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "io.hpp"
+
+namespace mp {
+
+struct SynthConfig {
+    uint64_t seed = 1001;
+    uint32_t n_transcripts = 1000;
+    double depth = 30.0;
+    double var_spacing = 5.4;  // mean nt between SNV sites inside the CDS
+    uint32_t read_len = 101;
+};
+
+struct Dataset {
+    std::vector<std::string> contig_names;
+    std::vector<std::string> contig_seq;       // synthetic data sets only
+    std::shared_ptr<IndexedFasta> fasta;       // file-backed data sets
+    BamData bam;
+    VcfData vcf;
+    std::string gtf;
+    std::vector<GeneInput> genes;              // protein-coding genes in GTF order, loaded as phase_gene would
+};
+
+void synth_generate(const SynthConfig& cfg, Dataset& ds);
+void dataset_load_genes(Dataset& ds, bool unsupported_allele_warning_only);
+void dataset_load_files(const std::string& bam, const std::string& vcf, const std::string& fasta, std::istream& gtf,
+                        bool unsupported_allele_warning_only, Dataset& ds);
+void dataset_write_files(const Dataset& ds, const std::string& prefix);  // prefix.{bam,vcf,gtf,fa,fa.fai}
+
+}  // namespace mp

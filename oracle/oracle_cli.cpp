@@ -7,6 +7,7 @@
 #include <iostream>
 
 #include "../microphaser_amd/csrc/io.hpp"
+#include "../microphaser_amd/csrc/synth.hpp"
 #include "somatic_oracle.hpp"
 
 using namespace mp;
@@ -25,7 +26,45 @@ int main(int argc, char** argv) {
             return 2;
         }
         std::string sub = argv[1];
-        if (sub != "somatic") throw Error("oracle_cli: only `somatic` is restated so far");
+        if (sub == "synth") {
+            // oracle_cli synth --seed S --transcripts N --depth D --spacing P [--genes LO:HI] [--stats F] [--prefix OUT]
+            // regenerates the deterministic synthetic data set in-process and runs the oracle on genes [LO,HI)
+            SynthConfig cfg;
+            uint64_t lo = 0, hi = ~0ull, wl = 27;
+            std::string stats, prefix;
+            for (int i = 2; i < argc; i++) {
+                std::string a = argv[i];
+                auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + a); return argv[++i]; };
+                if (a == "--seed") cfg.seed = std::stoull(val());
+                else if (a == "--transcripts") cfg.n_transcripts = uint32_t(std::stoul(val()));
+                else if (a == "--depth") cfg.depth = std::stod(val());
+                else if (a == "--spacing") cfg.var_spacing = std::stod(val());
+                else if (a == "--window-len") wl = std::stoull(val());
+                else if (a == "--genes") { std::string v = val(); size_t c = v.find(':'); lo = std::stoull(v.substr(0, c)); hi = std::stoull(v.substr(c + 1)); }
+                else if (a == "--stats") stats = val();
+                else if (a == "--prefix") prefix = val();
+                else throw Error("unknown argument " + a);
+            }
+            Dataset ds;
+            synth_generate(cfg, ds);
+            if (hi > ds.genes.size()) hi = ds.genes.size();
+            SomaticOutput out;
+            auto t0 = std::chrono::steady_clock::now();
+            for (uint64_t g = lo; g < hi; g++) mp_oracle::phase_gene(ds.genes[g], ds.bam.reads, wl, out);
+            double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (!prefix.empty()) {
+                write_file(prefix + ".fa", out.fasta);
+                write_file(prefix + ".normal.fa", out.normal_fasta);
+                write_file(prefix + ".tsv", out.tsv);
+            }
+            char buf[256];
+            std::snprintf(buf, sizeof buf, "{\"windows\": %llu, \"phase_seconds\": %.6f, \"genes\": %llu}\n",
+                          (unsigned long long)out.n_windows, secs, (unsigned long long)(hi - lo));
+            if (!stats.empty()) write_file(stats, buf);
+            else std::fputs(buf, stdout);
+            return 0;
+        }
+        if (sub != "somatic") throw Error("oracle_cli: only `somatic` and `synth` are available");
         std::string bam_path, vcf_path, ref_path, tsv_path = "info.tsv", normal_path = "normal.fasta", stats_path;
         uint64_t window_len = 27;
         bool warn_only = false;

@@ -1,0 +1,67 @@
+"""Parity of the HIP path (through the C ABI) against the reference's golden outputs and the CPU oracle."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ORACLE_CLI, SOMATIC_FIXTURES, fixture_paths, read_expected
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    import microphaser_amd as m
+    return m.Context(0)
+
+
+@pytest.mark.parametrize("name", sorted(SOMATIC_FIXTURES))
+def test_gpu_matches_reference_expected_output(ctx, name):
+    p = fixture_paths(name)
+    res = ctx.load(p["bam"], p["vcf"], p["fasta"], p["gtf"]).phase()
+    exp = read_expected(p["expected"])
+    assert res.fasta == exp["fa"]
+    assert res.normal_fasta == exp["normal.fa"]
+    assert res.tsv == exp["tsv"]
+
+
+def test_gpu_empty_vcf(ctx):
+    p = fixture_paths("test_forward")
+    res = ctx.load(p["bam"], os.path.join(GOLDEN, "test_empty", "empty_test.vcf"), p["fasta"], p["gtf"]).phase()
+    assert (res.fasta, res.normal_fasta, res.tsv) == (b"", b"", b"")
+
+
+def oracle_synth(tmp, seed, n, depth=30.0, spacing=5.4):
+    prefix = os.path.join(tmp, "oracle_%d_%d" % (seed, n))
+    r = subprocess.run([ORACLE_CLI, "synth", "--seed", str(seed), "--transcripts", str(n), "--depth", str(depth),
+                        "--spacing", str(spacing), "--prefix", prefix], capture_output=True, check=True)
+    st = json.loads(r.stdout)
+    return {e: open(prefix + "." + e, "rb").read() for e in ("fa", "normal.fa", "tsv")}, st
+
+
+@pytest.mark.parametrize("seed,n,depth,spacing", [(7, 40, 30.0, 5.4), (1001, 150, 30.0, 5.4), (5005, 6, 500.0, 1.35), (99, 30, 120.0, 2.5)])
+def test_gpu_matches_oracle_on_synthetic_exome(ctx, tmp_path, seed, n, depth, spacing):
+    exp, st = oracle_synth(str(tmp_path), seed, n, depth, spacing)
+    ds = ctx.synth(seed, n, depth, spacing)
+    res = ds.phase()
+    assert res.windows == st["windows"]
+    assert res.fasta == exp["fa"]
+    assert res.normal_fasta == exp["normal.fa"]
+    assert res.tsv == exp["tsv"]
+    assert exp["tsv"].count(b"\n") > 100
+
+
+def test_gpu_gene_sharding_is_order_preserving(ctx, tmp_path):
+    """Shards of genes concatenated in order give the whole-job output (the multi-GPU contract)."""
+    ds = ctx.synth(31, 24)
+    whole = ds.phase()
+    parts = []
+    for lo, hi in ((0, 7), (7, 16), (16, 24)):
+        b = ds.batch(gene_lo=lo, gene_hi=hi)
+        b.run()
+        parts.append(b.results())
+    tsv = b"".join([parts[0].tsv] + [p.tsv.split(b"\n", 1)[1] if p.tsv else b"" for p in parts[1:]])
+    assert b"".join(p.fasta for p in parts) == whole.fasta
+    assert tsv == whole.tsv
+    assert sum(p.windows for p in parts) == whole.windows

@@ -1,0 +1,43 @@
+"""The CPU oracle against the reference's own golden outputs (no GPU).
+
+This is what pins the oracle: the expected .fa / .normal.fa / .tsv files are the reference's
+(tests/lib.rs:106-342), the inputs are its BAM / VCF / GTF fixtures plus the mini reference FASTA
+rebuilt by tests/golden/make_golden.py.
+"""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ORACLE_CLI, SOMATIC_FIXTURES, fixture_paths, read_expected, run_oracle_files
+
+
+@pytest.mark.parametrize("name", sorted(SOMATIC_FIXTURES))
+def test_oracle_matches_reference_expected_output(built, tmp_path, name):
+    p = fixture_paths(name)
+    got = run_oracle_files(p, str(tmp_path))
+    exp = read_expected(p["expected"])
+    for ext in ("fa", "normal.fa", "tsv"):
+        assert got[ext] == exp[ext], "%s.%s differs from the reference's expected output" % (name, ext)
+
+
+def test_oracle_empty_vcf_gives_three_empty_files(built, tmp_path):
+    # tests/lib.rs:106-130 (test_empty)
+    p = fixture_paths("test_forward")
+    p["vcf"] = os.path.join(GOLDEN, "test_empty", "empty_test.vcf")
+    got = run_oracle_files(p, str(tmp_path))
+    assert got == {"fa": b"", "normal.fa": b"", "tsv": b""}
+
+
+def test_oracle_unsorted_gtf_fails(built, tmp_path):
+    # tests/lib.rs:344-382 (unsorted_gtf_test): unsorted must fail, sorted must succeed
+    d = os.path.join(GOLDEN, "test_unsorted_gtf")
+    base = [ORACLE_CLI, "somatic", os.path.join(d, "forward_test.bam"), "--variants", os.path.join(d, "empty.vcf"),
+            "--ref", os.path.join(GOLDEN, "test_forward", "chr14.mini.fa"), "--tsv", str(tmp_path / "t.tsv"),
+            "--normal-output", str(tmp_path / "n.fa")]
+    with open(os.path.join(d, "chr14.unsorted.BDKRB2_DHRS2.gtf"), "rb") as f:
+        r = subprocess.run(base, stdin=f, capture_output=True)
+    assert r.returncode != 0 and b"not sorted" in r.stderr
+    with open(os.path.join(d, "chr14.sorted.DHRS2_BDKRB2.gtf"), "rb") as f:
+        r = subprocess.run(base, stdin=f, capture_output=True)
+    assert r.returncode == 0
