@@ -11,6 +11,7 @@
 #include "consume.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <tuple>
 
@@ -132,6 +133,7 @@ struct ConsumerHooks {
     bool is_fwd;
 
     void on_exon(const ExonGeom&) {}
+    void routed(bool) {}
 
     void on_step(const ExonGeom&, const StepGeom& sg, const std::vector<size_t>&) {
         if (next_step >= T.n_steps) throw Error("internal error: consumer walked past the planned schedule");
@@ -182,11 +184,18 @@ struct ConsumerHooks {
             if (zero_slot == ~0ull) throw Error("internal error: reference haplotype missing from device results");
             keys.push_back({0, 0, 0, zero_slot});
         }
+        if (const char* tr = std::getenv("MP_TRACE")) {
+            FILE* tf = std::fopen(tr, "a");
+            std::fprintf(tf, "P %s %llu f%llu depth=%u fd=%zu first=%d :", transcript.id.c_str(), (unsigned long long)sg.sso, (unsigned long long)frame, wd.nrows, frame_depth, int(is_first_exon_window));
+            for (const Key& k : keys) std::fprintf(tf, " (%llu,%llu)=%zu", (unsigned long long)k.hap, (unsigned long long)k.hframe, k.count);
+            std::fprintf(tf, "\n");
+            std::fclose(tf);
+        }
         const char* strand = is_fwd ? "Forward" : "Reverse";
         const bool has_frameshift = frame > 0;
         const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
         const uint64_t wl = eg.ewl;  // print_haplotypes' window_len parameter (:1421)
-        const bool boundary = (ws.flags & (SF_FIRST_EXON_WIN | SF_LAST_EXON_WIN | SF_SHORT_EXON)) != 0;
+        const bool boundary = (ws.need_recs & WS_CARRY) != 0;  // haplotypes feed a splice-side merge
         std::vector<HapSeq> haplotypes_vec;
         uint64_t shift_in_window = 0;
         for (const Key& key : keys) {
@@ -195,7 +204,7 @@ struct ConsumerHooks {
             const HapRec* rec = (gs.flags & GS_HAS_REC) ? &res.recs[gs.rec] : nullptr;
             const bool indel = gs.flags & GS_INDEL, insertion = gs.flags & GS_INSERTION, stop_gain = gs.flags & GS_STOP;
             const bool differs = gs.flags & GS_DIFFERS, broke = gs.flags & GS_BROKE;
-            if (ws.need_recs && !rec) throw Error("internal error: missing haplotype record for an indel window");
+            if ((ws.need_recs & WS_ALL_IDS) && !rec) throw Error("internal error: missing haplotype record for an indel window");
             const uint32_t n_somatic = rec ? rec->nsom : 0, n_variants = rec ? rec->nvar : 0;
             const double freq = key.count == 0 ? 0.0 : double(key.count) / double(frame_depth);
             bool shift_is_set = false;
@@ -331,6 +340,13 @@ struct ConsumerHooks {
         std::map<MKey, std::tuple<std::string, IDRecord, std::string>> output_map;
         std::vector<HapSeq> new_hap_vec;
         const double eps = std::numeric_limits<double>::epsilon();
+        if (const char* tr = std::getenv("MP_TRACE")) {
+            FILE* tf = std::fopen(tr, "a");
+            std::fprintf(tf, "M %s %llu\n", transcript.id.c_str(), (unsigned long long)offset);
+            for (const auto& h : first_hap_vec) std::fprintf(tf, "  F %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
+            for (const auto& h : sec_hap_vec) std::fprintf(tf, "  S %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
+            std::fclose(tf);
+        }
         for (const HapSeq& hapseq : first_hap_vec) {
             const IDRecord& record = hapseq.record;
             const std::string& wt = record.normal_sequence;

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
                 if (rec.seq[k] != rec.germ[k]) { differs = true; break; }
         sumflags = GS_VALID | (stop ? GS_STOP : 0) | (differs ? GS_DIFFERS : 0) | (indel ? GS_INDEL : 0) |
                    (insertion ? GS_INSERTION : 0) | (broke_flag ? GS_BROKE : 0);
-        const bool want_all = (ws.flags & (SF_FIRST_EXON_WIN | SF_LAST_EXON_WIN | SF_SHORT_EXON)) || ws.need_recs;
+        const bool want_all = ws.need_recs != 0;
         need_rec = nsom > 0 || want_all;
         rec.prof_set = prof_set;
         rec.seq_len = uint8_t(seq_len);
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
         rec.first_fs_j = uint8_t(first_fs_j);
         rec.pad = 0;
         rec.id60 = 0;
-        if (need_rec && (nsom > 0 || ws.need_recs)) {
+        if (need_rec && (nsom > 0 || (ws.need_recs & WS_ALL_IDS))) {
             // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (:667-675)
             Sha1Dev sh;
             sh.init();

@@ -27,6 +27,8 @@ struct PlannerHooks {
     bool have_prev_cand = false;
     size_t cur_step = 0;
     uint64_t max_live = 0;
+    // windows whose haplotypes currently sit in prev_hap_vec / hap_vec (they feed the next splice-side merge)
+    uint32_t last_print_win = 0xFFFFFFFFu, held_prev = 0xFFFFFFFFu, held_hap = 0xFFFFFFFFu;
 
     uint32_t tr_index(size_t fwd_idx) const { return is_fwd ? uint32_t(fwd_idx) : fwd2rev[fwd_idx]; }
 
@@ -70,7 +72,7 @@ struct PlannerHooks {
             if (v.kind == VK_DEL) max_len += v.len + 1;
             if (v.kind != VK_SNV) non_snv = true;
         }
-        b.wins.back().need_recs = (non_snv || fs_seen) ? 1 : 0;
+        b.wins.back().need_recs = (non_snv || fs_seen) ? WS_ALL_IDS : 0;
         if (max_len > SEQ_CAP)
             throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
                         " nt; this build supports at most " + std::to_string(SEQ_CAP) + " (long indel in window)");
@@ -137,14 +139,21 @@ struct PlannerHooks {
 
     std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
         ensure_window(eg, sg);
+        last_print_win = b.steps[cur_step].win;
         if (frame == 0) b.n_main_windows++;
         fsf.emplace(frame, std::make_pair(1.0, false));
         std::vector<HapSeq> v(1);
         return {std::move(v), std::move(fsf)};
     }
 
+    void routed(bool to_prev) { (to_prev ? held_prev : held_hap) = last_print_win; }
+
+    // the merge reads the full records of both carried-over windows (:1527-1540)
     void splice_merge(const ExonGeom&, const StepGeom&, uint64_t, std::map<uint64_t, uint64_t>&, FsFreq&, std::vector<HapSeq>&,
-                      std::vector<HapSeq>&) {}
+                      std::vector<HapSeq>&) {
+        if (held_prev != 0xFFFFFFFFu) b.wins[held_prev].need_recs |= WS_CARRY;
+        if (held_hap != 0xFFFFFFFFu) b.wins[held_hap].need_recs |= WS_CARRY;
+    }
 };
 
 }  // namespace

@@ -71,7 +71,11 @@ struct WinStatic {       // one per printing step; everything K3 needs that does
     uint8_t splice_pos;
     uint8_t splice_gap;
     uint8_t flags;       // SF_* of the step
-    uint8_t need_recs;   // 1: K3 writes a HapRec (+id) for EVERY haplotype (indel / frameshift context)
+    uint8_t need_recs;   // WS_* : K3 writes a HapRec for EVERY haplotype of this window
+};
+enum : uint8_t {
+    WS_ALL_IDS = 1,      // indel / frameshift context: every haplotype can be emitted -> records + SHA-1 ids
+    WS_CARRY = 2,        // the window's haplotypes are carried into a splice-side merge -> records
 };
 static_assert(sizeof(WinStatic) == 20, "WinStatic layout");
 

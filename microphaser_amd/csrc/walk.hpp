@@ -66,6 +66,7 @@ struct VarIndex {
 //   void on_step(const ExonGeom&, const StepGeom&, const std::vector<size_t>& new_cols_fwd_idx);
 //       called once per step after the column delta is known (columns are appended in the given order)
 //   std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom&, const StepGeom&, uint64_t frame, FsFreq, bool is_first_exon_window);
+//   void routed(bool to_prev_hap_vec);   // which carry-over vector the last print's haplotypes went to
 //   void splice_merge(const ExonGeom&, const StepGeom&, uint64_t exon_rest, std::map<uint64_t,uint64_t>& frameshifts,
 //                     FsFreq&, std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec);
 //   static constexpr bool kDynamic;   // false: planner (never terminates)
@@ -217,8 +218,10 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
                     auto res = hooks.print(eg, sg, frameshift, std::move(frameshift_frequencies), is_first_exon_window);
                     frameshift_frequencies = std::move(res.second);
                     if (res.first.empty() || !frameshift_frequencies.count(frameshift)) stopped_frameshift = key;
-                    if (exon_rest < 3 && (!eg.is_short || eg.is_first) && !has_frameshift) prev_hap_vec = std::move(res.first);
+                    const bool to_prev = exon_rest < 3 && (!eg.is_short || eg.is_first) && !has_frameshift;  // :1445-1454
+                    if (to_prev) prev_hap_vec = std::move(res.first);
                     else hap_vec = std::move(res.first);
+                    hooks.routed(to_prev);
                     if (frameshift != 0 && frameshift_frequencies.count(frameshift) && frameshift_frequencies.at(frameshift).first == 0.0)
                         stopped_frameshift = key;
                 }

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <deque>
 #include <limits>
 #include <map>
@@ -323,6 +324,13 @@ std::pair<std::vector<HaplotypeSeq>, FsFreq> print_haplotypes(
     };
     const uint32_t depth = uint32_t(om.nrows());
 
+    if (const char* tr = std::getenv("MP_TRACE")) {
+        FILE* tf = std::fopen(tr, "a");
+        std::fprintf(tf, "P %s %llu f%llu depth=%u fd=%zu first=%d :", transcript.id.c_str(), (unsigned long long)offset, (unsigned long long)frame, depth, frame_depth, int(is_first_exon_window));
+        for (const auto& hk : haplotypes) std::fprintf(tf, " (%llu,%llu)=%zu", (unsigned long long)hk.first.first, (unsigned long long)hk.first.second, hk.second);
+        std::fprintf(tf, "\n");
+        std::fclose(tf);
+    }
     for (const auto& hk : haplotypes) {  // :434
         uint64_t haplotype = hk.first.first;
         uint64_t haplotype_frame = hk.first.second;
@@ -694,6 +702,13 @@ void phase_gene(const GeneInput& gi, const ReadStore& rs, uint64_t window_len, S
                         using Key = std::tuple<uint64_t, std::string, std::string>;
                         std::map<Key, std::tuple<std::string, IDRecord, std::string>> output_map;
                         std::vector<HaplotypeSeq> new_hap_vec;
+                        if (const char* tr = std::getenv("MP_TRACE")) {
+                            FILE* tf = std::fopen(tr, "a");
+                            std::fprintf(tf, "M %s %llu\n", transcript.id.c_str(), (unsigned long long)offset);
+                            for (const auto& h : first_hap_vec) std::fprintf(tf, "  F %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
+                            for (const auto& h : sec_hap_vec) std::fprintf(tf, "  S %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
+                            std::fclose(tf);
+                        }
                         for (const HaplotypeSeq& hapseq : first_hap_vec) {  // :1527
                             const IDRecord& record = hapseq.record;
                             const std::string& wt_sequence = record.normal_sequence;
