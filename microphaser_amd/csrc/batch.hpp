@@ -46,6 +46,7 @@ struct Batch {
     std::vector<TxDev> tx;
     std::vector<Step> steps;
     std::vector<WinStatic> wins;
+    std::vector<uint32_t> win_cols;       // column lists of the printing windows (gene-relative forward variant indices)
     std::vector<ExonPlan> exons;
     std::vector<uint8_t> str_pool;        // transcript ids
     std::vector<uint32_t> tx_order;       // launch order (longest first)
@@ -61,6 +62,9 @@ struct Batch {
 
 // Build the batch + plan for a list of loaded genes. `mapq_min` = 5 for `somatic`
 // (reference: src/microphasing.rs:910), 0 for `normal`.
-void build_batch(const std::vector<GeneInput>& genes, const ReadStore& reads, uint64_t window_len, uint8_t mapq_min, Batch& out);
+void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& reads, uint64_t window_len, uint8_t mapq_min, Batch& out);
+inline void build_batch(const std::vector<GeneInput>& genes, const ReadStore& reads, uint64_t window_len, uint8_t mapq_min, Batch& out) {
+    build_batch(genes.data(), genes.size(), reads, window_len, mapq_min, out);
+}
 
 }  // namespace mp

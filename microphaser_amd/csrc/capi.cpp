@@ -20,8 +20,7 @@ struct mp_dataset {
     Dataset ds;
 };
 struct mp_batch {
-    Batch batch;
-    std::vector<GeneInput> genes;  // the slice [gene_lo, gene_hi) (GeneHost::input points into it)
+    Batch batch;                   // GeneHost::input points into the data set, which must outlive the batch
     const ReadStore* reads = nullptr;
     bool uploaded = false, ran = false;
     RunTiming timing;
@@ -109,9 +108,8 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
         if (gene_hi > ds->ds.genes.size()) gene_hi = uint32_t(ds->ds.genes.size());
         if (gene_lo > gene_hi) gene_lo = gene_hi;
         std::unique_ptr<mp_batch> b(new mp_batch());
-        b->genes.assign(ds->ds.genes.begin() + gene_lo, ds->ds.genes.begin() + gene_hi);
         b->reads = &ds->ds.bam.reads;
-        build_batch(b->genes, *b->reads, window_len, /*mapq_min=*/5, b->batch);  // src/microphasing.rs:910
+        build_batch(ds->ds.genes.data() + gene_lo, size_t(gene_hi - gene_lo), *b->reads, window_len, /*mapq_min=*/5, b->batch);  // src/microphasing.rs:910
         if (ctx->dev) {
             ctx->dev->upload(b->batch);
             b->uploaded = true;

@@ -157,9 +157,7 @@ struct ConsumerHooks {
         std::vector<const Variant*> variants(ncols);
         for (uint32_t j = 0; j < ncols; j++) {
             uint32_t dq = is_fwd ? j : ncols - 1 - j;
-            uint32_t tr = ws.col_lo + dq;
-            uint32_t f = is_fwd ? tr : b.v_rev2fwd[gh.var_off + tr];
-            variants[j] = &gvars[f];
+            variants[j] = &gvars[b.win_cols[ws.col_off + dq]];
         }
         // haplotype keys of this call (:383-411) from the device groups (ascending (hap, frame0, f1nz))
         struct Key { uint64_t hap, hframe; size_t count; uint64_t slot; };

@@ -87,6 +87,7 @@ void DeviceContext::upload(const Batch& b) {
     d_.tx = up(b.tx);
     d_.steps = up(b.steps);
     d_.wins = up(b.wins);
+    d_.win_cols = up(b.win_cols);
     d_.str_pool = up(b.str_pool);
     d_.tx_order = up(b.tx_order);
     d_.n_reads = uint32_t(b.r_pos.size());

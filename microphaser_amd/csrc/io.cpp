@@ -274,6 +274,16 @@ void ReadBuffer::fetch(const std::string& chrom, uint64_t start, uint64_t end) {
         iter_beg_ = int64_t(start);
         cursor_ = bam_.tid_begin[size_t(tid)];
         cursor_end_ = bam_.tid_begin[size_t(tid) + 1];
+        {   // records that can overlap `start` begin after start - max_ref_span: skip the rest by binary search
+            int64_t span = bam_.max_ref_span;
+            if (span <= 0) {
+                for (size_t i = 0; i < rs.size(); i++) span = std::max<int64_t>(span, std::max<int64_t>(rs.end_pos[i] - rs.pos[i], 1));
+                const_cast<BamData&>(bam_).max_ref_span = span;
+            }
+            int64_t from = int64_t(start) - span;
+            const int64_t* p0 = rs.pos.data();
+            cursor_ = size_t(std::lower_bound(p0 + cursor_, p0 + cursor_end_, from) - p0);
+        }
         iter_valid_ = true;
         inner_.clear();
     } else {
@@ -348,6 +358,17 @@ void load_vcf(const std::string& path, VcfData& out) {
     }
 }
 
+void VcfData::build_index() const {
+    if (indexed) return;
+    by_chrom.clear();
+    for (size_t i = 0; i < records.size(); i++) {
+        ContigIndex& ci = by_chrom[records[i].chrom];
+        if (!ci.recs.empty() && records[ci.recs.back()].pos > records[i].pos) ci.sorted = false;
+        ci.recs.push_back(i);
+    }
+    indexed = true;
+}
+
 static void warn_or_error(const std::string& msg, bool warning_only) {  // common.rs:62-69
     if (warning_only) std::fprintf(stderr, "%s\n", msg.c_str());
     else throw Error(msg);
@@ -410,11 +431,22 @@ void gene_variants(const VcfData& vcf, const std::string& chrom, uint64_t start,
     if (std::find(vcf.contigs.begin(), vcf.contigs.end(), chrom) == vcf.contigs.end())
         throw Error("contig " + chrom + " not found in VCF header");
     std::map<uint64_t, std::vector<Variant>> tree;  // variant_tree.insert(pos, ...) : later record replaces
-    for (const auto& r : vcf.records) {
-        if (r.chrom != chrom || r.pos < start || r.pos > end) continue;
-        std::vector<Variant> vs;
-        variants_from_record(r, warning_only, vs);
-        tree[r.pos] = std::move(vs);
+    vcf.build_index();
+    auto ci = vcf.by_chrom.find(chrom);
+    if (ci != vcf.by_chrom.end()) {
+        const auto& recs = ci->second.recs;
+        size_t a = 0, e = recs.size();
+        if (ci->second.sorted) {
+            a = size_t(std::lower_bound(recs.begin(), recs.end(), start, [&](size_t r, uint64_t p) { return vcf.records[r].pos < p; }) - recs.begin());
+            e = size_t(std::upper_bound(recs.begin(), recs.end(), end, [&](uint64_t p, size_t r) { return p < vcf.records[r].pos; }) - recs.begin());
+        }
+        for (size_t k = a; k < e; k++) {
+            const VcfRecord& r = vcf.records[recs[k]];
+            if (r.pos < start || r.pos > end) continue;
+            std::vector<Variant> vs;
+            variants_from_record(r, warning_only, vs);
+            tree[r.pos] = std::move(vs);
+        }
     }
     out.clear();
     for (auto& kv : tree)

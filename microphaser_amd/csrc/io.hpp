@@ -20,6 +20,7 @@ struct BamData {
     std::vector<int64_t> ref_lens;
     ReadStore reads;                  // mapped + placed records in file (coordinate) order
     std::vector<size_t> tid_begin;    // first read index of each tid (size n_ref+1)
+    int64_t max_ref_span = 0;         // max(end_pos - pos, 1) over all reads (bounds the region-iterator seek)
     int tid_of(const std::string& chrom) const {
         for (size_t i = 0; i < ref_names.size(); i++)
             if (ref_names[i] == chrom) return int(i);
@@ -70,6 +71,11 @@ struct VcfRecord {
 struct VcfData {
     std::vector<std::string> contigs;  // from ##contig header lines (+ contigs seen in records)
     std::vector<VcfRecord> records;    // file order
+    // lazily built per-contig index (record numbers in file order + whether their positions are sorted)
+    struct ContigIndex { std::vector<size_t> recs; bool sorted = true; };
+    mutable std::map<std::string, ContigIndex> by_chrom;
+    mutable bool indexed = false;
+    void build_index() const;
 };
 
 void load_vcf(const std::string& path, VcfData& out);

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
     for (uint32_t k = lo; k < nv && (k - lo) < 64u * W; k++) {
         uint32_t vpos = d.v_pos[vbase + k];
-        if (vpos >= rend) break;
+        // a variant can be a (stale) column of a window the read encloses without lying inside the read's
+        // aligned span; bad_quality still indexes the qualities by reference offset (:82-88)
+        if (vpos >= rend && vpos - rpos >= lseq) break;
         uint32_t info = d.v_info[vbase + k];
         uint32_t kind = info & VI_KIND_MASK;
         bool s = false, q = false;
@@ -485,8 +487,7 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
         auto load_j = [&]() {
             if (j < ncols) {
                 uint32_t dq = is_rev ? (ncols - 1 - j) : j;
-                uint32_t tr = ws.col_lo + dq;
-                f_j = is_rev ? d.v_rev2fwd[vbase + tr] : tr;
+                f_j = d.win_cols[ws.col_off + dq];
                 pos_j = d.v_pos[vbase + f_j];
                 info_j = d.v_info[vbase + f_j];
             }

@@ -23,6 +23,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const TxDev* tx;
     const Step* steps;
     const WinStatic* wins;
+    const uint32_t* win_cols;
     const uint8_t* str_pool;
     const uint32_t* tx_order;
     uint32_t n_reads, n_tx, n_wins, mask_words;

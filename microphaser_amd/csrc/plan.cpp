@@ -20,7 +20,9 @@ struct PlannerHooks {
     bool is_fwd;
     uint32_t tx_idx;
     uint32_t cur_exon = 0;
-    std::deque<uint32_t> cols;  // transcription-order indices of the live columns (oldest first)
+    std::deque<uint32_t> cols;  // forward variant indices (gene-relative) of the live columns, oldest first
+    bool cols_dirty = true;
+    uint32_t cols_off = 0;
     uint32_t col_hi = 0;
     bool fs_seen = false;
     uint64_t prev_cand_lo = 0;
@@ -56,7 +58,12 @@ struct PlannerHooks {
         w.tx = tx_idx;
         w.sso = st.sso;
         w.ncols = uint16_t(cols.size());
-        w.col_lo = col_hi - uint32_t(cols.size());
+        if (cols_dirty) {  // consecutive windows with unchanged columns share one list
+            cols_off = uint32_t(b.win_cols.size());
+            b.win_cols.insert(b.win_cols.end(), cols.begin(), cols.end());
+            cols_dirty = false;
+        }
+        w.col_off = cols_off;
         w.wlen = st.wlen;
         w.ewl = uint8_t(eg.ewl);
         w.splice_pos = uint8_t(sg.splice_pos);
@@ -67,7 +74,7 @@ struct PlannerHooks {
         uint64_t max_len = st.wlen;
         bool non_snv = false;
         for (uint32_t c : cols) {
-            const Variant& v = vars[is_fwd ? c : b.v_rev2fwd[gh.var_off + c]];
+            const Variant& v = vars[c];
             if (v.kind == VK_INS) max_len += v.seq.size();
             if (v.kind == VK_DEL) max_len += v.len + 1;
             if (v.kind != VK_SNV) non_snv = true;
@@ -85,19 +92,23 @@ struct PlannerHooks {
         uint64_t wlen = sg.splice_end - sg.sso;
         if (wlen > 255) throw Error("window longer than 255 nt is not supported");
         st.wlen = uint8_t(wlen);
-        if (sg.deleted > cols.size()) throw Error("reference would panic: drain range out of bounds (shrink_left)");
+        if (sg.deleted > cols.size())
+            throw Error("reference would panic: drain range out of bounds (shrink_left) at sso " + std::to_string(sg.sso) + " end " +
+                        std::to_string(sg.splice_end) + " ncols " + std::to_string(cols.size()) + " deleted " + std::to_string(sg.deleted) +
+                        " added " + std::to_string(sg.added) + " nvars " + std::to_string(sg.nvars) + " first " + std::to_string(sg.is_first_exon_window) +
+                        " last " + std::to_string(sg.is_last_exon_window) + " short " + std::to_string(eg.is_short) + " exon " +
+                        std::to_string(eg.start) + "-" + std::to_string(eg.end) + " ceo " + std::to_string(eg.ceo) + " ewl " + std::to_string(eg.ewl) + (is_fwd ? " fwd" : " rev"));
         if (sg.deleted > 255 || new_cols.size() > 255) throw Error("more than 255 column changes in one step");
         st.n_del = uint8_t(sg.deleted);
         st.n_add = uint8_t(new_cols.size());
         for (size_t k = 0; k < sg.deleted; k++) cols.pop_front();
+        if (sg.deleted || !new_cols.empty()) cols_dirty = true;
         for (size_t k : new_cols) {
-            uint32_t tr = tr_index(k);
-            if (!cols.empty() && cols.back() + 1 != tr) {
-                // columns must stay a contiguous run in transcription order for the packed plan
-                throw Error("non-contiguous variant columns (unsupported scheduler corner case)");
-            }
-            cols.push_back(tr);
-            col_hi = tr + 1;
+            // NOTE: the live columns are not always the window's own variants - the reference can leave a
+            // stale column behind (deleted_vars forced to 0 when offset == old_offset, :1159) - so every
+            // printing window carries an explicit column list (win_cols).
+            cols.push_back(uint32_t(k));
+            col_hi = tr_index(k) + 1;
             if (vars[k].frameshift() > 0) fs_seen = true;
         }
         if (cols.size() > 63) throw Error("more than 63 variant columns in one window (reference overflows its u64 haplotype word)");
@@ -158,12 +169,26 @@ struct PlannerHooks {
 
 }  // namespace
 
-void build_batch(const std::vector<GeneInput>& genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
+void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
     b = Batch();
     b.window_len = window_len;
-    b.genes.resize(genes.size());
+    b.genes.resize(n_genes);
     uint32_t max_span_vars = 0;
-    for (size_t gi_ = 0; gi_ < genes.size(); gi_++) {
+    {   // reserve the big pools once
+        size_t nr = 0, nref = 0, nv = 0;
+        for (size_t g = 0; g < n_genes; g++) { nr += genes[g].reads.size(); nref += genes[g].refseq.size(); nv += genes[g].variants.size(); }
+        for (auto* v : {&b.r_pos, &b.r_end, &b.r_lseq, &b.r_ncig, &b.r_dup}) v->reserve(nr);
+        for (auto* v : {&b.r_cigoff, &b.r_seqoff, &b.r_qualoff}) v->reserve(nr);
+        b.r_src.reserve(nr);
+        b.cigar_pool.reserve(nr * 2);
+        b.seq_pool.reserve(nr * 52);
+        b.qual_pool.reserve(nr * 102);
+        b.ref_pool.reserve(nref);
+        for (auto* v : {&b.v_pos, &b.v_info, &b.v_len, &b.v_insoff, &b.v_rev2fwd}) v->reserve(nv);
+        b.steps.reserve(nref);
+        b.wins.reserve(nref / 3);
+    }
+    for (size_t gi_ = 0; gi_ < n_genes; gi_++) {
         const GeneInput& gi = genes[gi_];
         GeneHost& gh = b.genes[gi_];
         gh.input = &gi;
@@ -238,7 +263,8 @@ void build_batch(const std::vector<GeneInput>& genes, const ReadStore& rs, uint6
             size_t vlo = 0, vhi = 0;
             const auto& vs = gi.variants;
             for (size_t k = 0; k < kept.size(); k++) {
-                uint64_t s = b.r_pos[gh.read_off + k], e = b.r_end[gh.read_off + k];
+                uint64_t s = b.r_pos[gh.read_off + k];
+                uint64_t e = std::max<uint64_t>(b.r_end[gh.read_off + k], s + b.r_lseq[gh.read_off + k]);
                 while (vlo < vs.size() && vs[vlo].pos < s) vlo++;
                 if (vhi < vlo) vhi = vlo;
                 while (vhi < vs.size() && vs[vhi].pos < e) vhi++;

@@ -7,7 +7,9 @@
 //   variants  : v_pos v_info v_len v_insoff (forward = ascending pos, ALT order within a pos)
 //               v_rev2fwd (transcription order of '-' strand genes -> forward index)   + ins pool
 //   refseq    : bytes of [gene.start, gene.end+100) per gene, case preserved
-//   plan      : TxDev per transcript, Step per nt-offset step, WinStatic per printing step
+//   plan      : TxDev per transcript, Step per nt-offset step, WinStatic per printing step,
+//               win_cols = the variant columns of each printing window (not always the window's own
+//               variants: the reference can leave stale columns behind, microphasing.rs:1159)
 //   K1 output : r_varlo, r_sup[W], r_lq[W]            (read x variant predicate bits)
 //   K2 output : WinDyn per printing step, Group per distinct (haplotype, frame) key
 //   K3 output : GroupSum per group, HapRec per group that can be emitted / merged
@@ -64,7 +66,7 @@ static_assert(sizeof(Step) == 28, "Step layout");
 struct WinStatic {       // one per printing step; everything K3 needs that does not depend on reads
     uint32_t tx;
     uint32_t sso;
-    uint32_t col_lo;     // transcription-order index of the OLDEST column
+    uint32_t col_off;    // first entry of this window's column list in win_cols (forward variant indices, oldest first)
     uint16_t ncols;
     uint8_t wlen;
     uint8_t ewl;         // exon_window_len passed to print_haplotypes as window_len

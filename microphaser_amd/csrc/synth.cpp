@@ -71,15 +71,28 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
     ReadStore& rs = ds.bam.reads;
     ds.bam.ref_names = ds.contig_names;
     uint64_t read_serial = 0;
-    struct PendingRead { uint64_t pos; std::vector<uint8_t> seq4, qual; uint8_t mapq; uint64_t serial; };
+    struct PendingRead { uint64_t pos; uint64_t off; uint8_t mapq; uint64_t serial; };  // off: index into the staging pools
     std::vector<uint8_t> seq4((L + 1) / 2), qual(L);
+    std::vector<uint8_t> stage_seq, stage_qual;   // per-gene staging (genes are laid out in ascending coordinates,
+    std::vector<PendingRead> creads;              //  so sorting the reads of one gene keeps the BAM coordinate-sorted)
+    const uint32_t cig = (L << 4) | C_M;
+    {
+        // rough totals, to avoid re-growing multi-GB pools
+        double reads_est = double(cfg.n_transcripts) * cfg.depth * 2750.0 / double(L) * 1.15;
+        rs.pos.reserve(size_t(reads_est)); rs.end_pos.reserve(size_t(reads_est)); rs.tid.reserve(size_t(reads_est));
+        rs.mapq.reserve(size_t(reads_est)); rs.flag.reserve(size_t(reads_est)); rs.l_seq.reserve(size_t(reads_est));
+        rs.n_cigar.reserve(size_t(reads_est)); rs.cigar_off.reserve(size_t(reads_est)); rs.seq_off.reserve(size_t(reads_est));
+        rs.qual_off.reserve(size_t(reads_est)); rs.qname_off.reserve(size_t(reads_est)); rs.cigar_pool.reserve(size_t(reads_est));
+        rs.seq_pool.reserve(size_t(reads_est * ((L + 1) / 2))); rs.qual_pool.reserve(size_t(reads_est * L));
+        rs.qname_pool.reserve(size_t(reads_est * 10));
+    }
     const uint32_t per_contig = (cfg.n_transcripts + n_contigs - 1) / n_contigs;
     uint32_t tx_serial = 0;
     for (uint32_t c = 0; c < n_contigs; c++) {
         std::string& contig = ds.contig_seq[c];
         contig.assign(2000, 'N');
         for (char& ch : contig) ch = BASES[rng.below(4)];
-        std::vector<PendingRead> creads;
+        ds.bam.tid_begin.push_back(rs.size());
         for (uint32_t gi = 0; gi < per_contig && tx_serial < cfg.n_transcripts; gi++, tx_serial++) {
             const bool reverse = (tx_serial & 1) != 0;
             // ---- exon structure
@@ -93,6 +106,11 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
             }
             elen.back() += (3 - cds % 3) % 3;
             cds += (3 - cds % 3) % 3;
+            // A 31-nt exon entered with a 2-nt codon remainder on the '-' strand makes the reference itself
+            // panic (first window == last window, the variants below it are counted but never added, then
+            // shrink_left drains past the end; src/microphasing.rs:1098-1104, 1136-1138, 223): keep the
+            // workload inside what the reference can process.
+            for (auto& e : elen) if (e == 31) { e = 34; cds += 3; }
             const uint64_t utr = 150, margin = 200;
             // genomic layout (ascending): margin | [3'UTR+stop if reverse] exons/introns [stop+3'UTR if forward] | margin
             const uint64_t gene_start = contig.size();
@@ -207,19 +225,22 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
                         seq4[q >> 1] |= uint8_t(code4(bch) << ((q & 1) ? 0 : 4));
                         qual[q] = rng.uni() < 0.02 ? 5 : 35;
                     }
-                    pr.seq4 = seq4;
-                    pr.qual = qual;
-                    creads.push_back(std::move(pr));
+                    pr.off = creads.size();
+                    stage_seq.insert(stage_seq.end(), seq4.begin(), seq4.end());
+                    stage_qual.insert(stage_qual.end(), qual.begin(), qual.end());
+                    creads.push_back(pr);
                 }
             }
-        }
-        std::stable_sort(creads.begin(), creads.end(), [](const PendingRead& a, const PendingRead& b2) { return a.pos < b2.pos; });
-        ds.bam.tid_begin.push_back(rs.size());
-        uint32_t cig = (L << 4) | C_M;
-        for (const PendingRead& pr : creads) {
-            char name[32];
-            std::snprintf(name, sizeof name, "r%llu", (unsigned long long)pr.serial);
-            rs.add(int32_t(c), int64_t(pr.pos), pr.mapq, 0, &cig, 1, pr.seq4.data(), L, pr.qual.data(), name);
+            std::stable_sort(creads.begin(), creads.end(), [](const PendingRead& a, const PendingRead& b2) { return a.pos < b2.pos; });
+            for (const PendingRead& pr : creads) {
+                char name[32];
+                std::snprintf(name, sizeof name, "r%llu", (unsigned long long)pr.serial);
+                rs.add(int32_t(c), int64_t(pr.pos), pr.mapq, 0, &cig, 1, stage_seq.data() + pr.off * seq4.size(), L,
+                       stage_qual.data() + pr.off * L, name);
+            }
+            creads.clear();
+            stage_seq.clear();
+            stage_qual.clear();
         }
         ds.bam.ref_lens.push_back(int64_t(contig.size()));
     }
