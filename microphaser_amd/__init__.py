@@ -202,16 +202,45 @@ class Batch:
 
 
 class Results:
+    """Output streams of one run. Buffers can exceed 2 GiB on whole-exome inputs, so they are copied out of the
+    library lazily (and only if asked for)."""
+
     def __init__(self, h):
         self._h = h
+        self.windows = lib().mp_results_windows(h)
+        self._cache = {}
+
+    def _get(self, name):
+        if name not in self._cache:
+            n = ctypes.c_size_t()
+            p = getattr(lib(), "mp_results_" + name)(self._h, ctypes.byref(n))
+            self._cache[name] = bytes((ctypes.c_char * n.value).from_address(p)) if n.value else b""
+        return self._cache[name]
+
+    def size(self, name):
         n = ctypes.c_size_t()
-        L = lib()
-        p = L.mp_results_fasta(h, ctypes.byref(n))
-        self.fasta = ctypes.string_at(p, n.value) if n.value else b""
-        p = L.mp_results_normal_fasta(h, ctypes.byref(n))
-        self.normal_fasta = ctypes.string_at(p, n.value) if n.value else b""
-        p = L.mp_results_tsv(h, ctypes.byref(n))
-        self.tsv = ctypes.string_at(p, n.value) if n.value else b""
-        self.windows = L.mp_results_windows(h)
-        L.mp_results_free(h)
-        self._h = None
+        getattr(lib(), "mp_results_" + name)(self._h, ctypes.byref(n))
+        return n.value
+
+    @property
+    def fasta(self):
+        return self._get("fasta")
+
+    @property
+    def normal_fasta(self):
+        return self._get("normal_fasta")
+
+    @property
+    def tsv(self):
+        return self._get("tsv")
+
+    def close(self):
+        if self._h:
+            lib().mp_results_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

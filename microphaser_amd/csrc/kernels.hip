@@ -396,61 +396,77 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 }
 
 // ====================================================================== K3
+// One thread per (window, haplotype) group. Per-thread byte strings live in LDS slots with an odd
+// dword stride (bank-conflict free for "same offset in every lane" byte traffic); nothing is
+// spilled to scratch: the reference window is staged into LDS with aligned dword loads, the SHA-1
+// message is streamed through a 64-byte LDS block buffer and compressed with a fully unrolled,
+// register-resident schedule.
 __device__ __forceinline__ bool is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
 __device__ __forceinline__ uint8_t to_lower(uint8_t c) { return is_upper(c) ? uint8_t(c + 32) : c; }
 __device__ __forceinline__ uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? uint8_t(c - 32) : c; }
 __device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
-struct Sha1Dev {
-    uint32_t h[5];
-    uint32_t w[16];
-    uint32_t fill;   // bytes in the current block
-    uint64_t total;
-    __device__ void init() {
-        h[0] = 0x67452301u; h[1] = 0xEFCDAB89u; h[2] = 0x98BADCFEu; h[3] = 0x10325476u; h[4] = 0xC3D2E1F0u;
-        for (int i = 0; i < 16; i++) w[i] = 0;
-        fill = 0; total = 0;
+constexpr int K3_THREADS = 64;                             // one wave per workgroup: LDS granularity 10.5 KB -> 15 waves/CU
+constexpr int K3_REFCAP = 64;                              // staged reference bytes (window + alignment slack);
+                                                           // re-used as the 16-word SHA-1 block buffer after the walk
+constexpr int K3_SLOT_BYTES = K3_REFCAP + 2 * SEQ_CAP;     // ref | seq | germ = 160
+constexpr int K3_SLOT_DW = K3_SLOT_BYTES / 4 + 1;          // 41 dwords: odd stride
+
+struct ShaStream {
+    uint32_t h0, h1, h2, h3, h4;
+    uint64_t q;       // byte queue (big-endian, low `nq` bytes valid)
+    uint32_t nq, widx, total;
+    uint32_t* blk;    // this thread's 16-word block buffer in LDS
+    __device__ __forceinline__ void init(uint32_t* b) {
+        h0 = 0x67452301u; h1 = 0xEFCDAB89u; h2 = 0x98BADCFEu; h3 = 0x10325476u; h4 = 0xC3D2E1F0u;
+        q = 0; nq = 0; widx = 0; total = 0; blk = b;
     }
-    __device__ void block() {
-        uint32_t a = h[0], b = h[1], c = h[2], dd = h[3], e = h[4];
-        uint32_t ww[16];
-        for (int i = 0; i < 16; i++) ww[i] = w[i];
+    __device__ void compress() {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = blk[i];
+        uint32_t a = h0, b = h1, c = h2, d = h3, e = h4;
+#pragma unroll
         for (int i = 0; i < 80; i++) {
             uint32_t wi;
-            if (i < 16) wi = ww[i];
+            if (i < 16) wi = w[i];
             else {
-                wi = rol32(ww[(i + 13) & 15] ^ ww[(i + 8) & 15] ^ ww[(i + 2) & 15] ^ ww[i & 15], 1);
-                ww[i & 15] = wi;
+                wi = rol32(w[(i + 13) & 15] ^ w[(i + 8) & 15] ^ w[(i + 2) & 15] ^ w[i & 15], 1);
+                w[i & 15] = wi;
             }
             uint32_t f, k;
-            if (i < 20) { f = (b & c) | (~b & dd); k = 0x5A827999u; }
-            else if (i < 40) { f = b ^ c ^ dd; k = 0x6ED9EBA1u; }
-            else if (i < 60) { f = (b & c) | (b & dd) | (c & dd); k = 0x8F1BBCDCu; }
-            else { f = b ^ c ^ dd; k = 0xCA62C1D6u; }
-            uint32_t tmp = rol32(a, 5) + f + e + k + wi;
-            e = dd; dd = c; c = rol32(b, 30); b = a; a = tmp;
+            if (i < 20) { f = (b & c) | (~b & d); k = 0x5A827999u; }
+            else if (i < 40) { f = b ^ c ^ d; k = 0x6ED9EBA1u; }
+            else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8F1BBCDCu; }
+            else { f = b ^ c ^ d; k = 0xCA62C1D6u; }
+            uint32_t t = rol32(a, 5) + f + e + k + wi;
+            e = d; d = c; c = rol32(b, 30); b = a; a = t;
         }
-        h[0] += a; h[1] += b; h[2] += c; h[3] += dd; h[4] += e;
-        for (int i = 0; i < 16; i++) w[i] = 0;
-        fill = 0;
+        h0 += a; h1 += b; h2 += c; h3 += d; h4 += e;
     }
-    __device__ void put(uint8_t byte) {
-        w[fill >> 2] |= uint32_t(byte) << (24 - 8 * (fill & 3));
-        fill++; total++;
-        if (fill == 64) block();
+    // append n <= 4 bytes given as a big-endian integer
+    __device__ __forceinline__ void feed(uint32_t v, uint32_t n) {
+        q = (q << (8 * n)) | v;
+        nq += n;
+        total += n;
+        if (nq >= 4) {
+            uint32_t wv = uint32_t(q >> (8 * (nq - 4)));
+            nq -= 4;
+            blk[widx++] = wv;
+            if (widx == 16) { compress(); widx = 0; }
+        }
     }
-    __device__ void put_dec(uint32_t v) {
-        char tmp[10];
-        int n = 0;
-        do { tmp[n++] = char('0' + v % 10); v /= 10; } while (v);
-        while (n) put(uint8_t(tmp[--n]));
+    __device__ void feed_dec(uint32_t v) {  // decimal digits of v, most significant first
+        uint32_t div = 1000000000u;
+        while (div > 1 && v < div) div /= 10;
+        while (div) { feed('0' + (v / div) % 10, 1); div /= 10; }
     }
     __device__ void finish() {
-        uint64_t bits = total * 8;
-        // put() keeps counting `total`; the length was captured above
-        put(0x80);
-        while (fill != 56) put(0);
-        for (int i = 0; i < 8; i++) put(uint8_t(bits >> (56 - 8 * i)));
+        uint32_t bits = total * 8;
+        feed(0x80, 1);
+        while (!(nq == 0 && widx == 14)) feed(0, 1);
+        feed(0, 4);
+        feed(bits, 4);
     }
 };
 
@@ -460,14 +476,21 @@ __device__ __forceinline__ bool stop_codon_at(const uint8_t* s, uint32_t c, bool
     return (a == 'T' && b == 'C' && e == 'A') || (a == 'C' && b == 'T' && e == 'A') || (a == 'T' && b == 'T' && e == 'A');
 }
 
-__global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_slots) {
-    uint64_t g = uint64_t(blockIdx.x) * 256u + threadIdx.x;
-    uint32_t lane = threadIdx.x & 63;
-    uint32_t w = g < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
-    bool live = w != 0xFFFFFFFFu;
+__global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint64_t n_slots) {
+    __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t g = uint64_t(blockIdx.x) * K3_THREADS + tid;
+    const uint32_t lane = tid & 63;
+    uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
+    uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
+    uint8_t* seq = refb + K3_REFCAP;
+    uint8_t* germ = seq + SEQ_CAP;
+    const uint32_t w = g < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
+    const bool live = w != 0xFFFFFFFFu;
     uint32_t sumflags = 0;
     bool need_rec = false;
-    HapRec rec;
+    uint64_t prof_set = 0, id60 = 0;
+    uint32_t seq_len = 0, germ_len = 0, prof_len = 0, nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
     if (live) {
         const WinStatic ws = d.wins[w];
         const TxDev T = d.tx[ws.tx];
@@ -478,23 +501,36 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
         const bool is_rev = T.strand != 0;
         const uint32_t ncols = ws.ncols;
         const uint32_t window_end = ws.sso + ws.wlen;
-        uint32_t i = ws.sso, j = 0;
-        uint32_t ns = 0, ngm = 0;
-        uint32_t nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
-        uint64_t prof_set = 0;
+        // stage the reference window [sso, sso + wlen) with aligned dword loads
+        const uint8_t* wref = ref + (ws.sso - gstart);
+        const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(wref) & 3u);
+        {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(wref - mis);
+            const uint32_t ndw = (mis + ws.wlen + 3) >> 2;
+            for (uint32_t k = 0; k < ndw && k < K3_REFCAP / 4; k++) slot[k] = src[k];
+        }
+        const uint32_t staged = min(uint32_t(ws.wlen), uint32_t(K3_REFCAP) - mis);
+        auto ref_at = [&](uint32_t pos) -> uint8_t {  // reference base at absolute position pos (>= sso)
+            uint32_t k = pos - ws.sso;
+            return k < staged ? refb[mis + k] : ref[pos - gstart];
+        };
+        uint32_t i = ws.sso, j = 0, ns = 0, ngm = 0;
         bool indel = false, insertion = false, broke_flag = false;
-        uint32_t pos_j = 0, info_j = 0, f_j = 0;
+        uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
         auto load_j = [&]() {
             if (j < ncols) {
                 uint32_t dq = is_rev ? (ncols - 1 - j) : j;
                 f_j = d.win_cols[ws.col_off + dq];
                 pos_j = d.v_pos[vbase + f_j];
                 info_j = d.v_info[vbase + f_j];
+            } else {
+                pos_j = 0xFFFFFFFFu;
             }
         };
-        auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) rec.seq[ns] = c; ns++; };
-        auto push_g = [&](uint8_t c) { if (ngm < SEQ_CAP) rec.germ[ngm] = c; ngm++; };
+        auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) seq[ns] = c; ns++; };
+        auto push_g = [&](uint8_t c) { if (ngm < SEQ_CAP) germ[ngm] = c; ngm++; };
         load_j();
+        // sequence walk of print_haplotypes (:473-601); runs of plain reference bases are copied in bulk
         while (i < window_end) {
             while (j < ncols && i == pos_j) {
                 uint32_t fs = (info_j & VI_FS_MASK) >> VI_FS_SHIFT;
@@ -504,7 +540,7 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
                 if ((hap >> bit) & 1) {
                     uint32_t kind = info_j & VI_KIND_MASK;
                     bool germline = info_j & VI_GERMLINE;
-                    uint8_t r = ref[i - gstart];
+                    uint8_t r = ref_at(i);
                     bool brk = false;
                     if (kind == 0) {
                         uint8_t alt = uint8_t(info_j >> VI_ALT_SHIFT);
@@ -530,7 +566,7 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
                         else {
                             if (germline || i == window_end - 1) push_g(r);
                             else {
-                                for (uint32_t k = 0; k < dl + 1; k++) push_g(ref[i - gstart + k]);
+                                for (uint32_t k = 0; k < dl + 1; k++) push_g(ref_at(i + k));
                                 indel = true;
                             }
                             push_s(r);
@@ -546,13 +582,15 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
                 load_j();
             }
             if (i < window_end) {
-                uint8_t r = ref[i - gstart];
-                push_s(r);
-                push_g(r);
-                i++;
+                // the next position at which anything other than a reference copy can happen
+                // (a stuck cursor - pos_j <= i, e.g. after the incomplete-deletion break - never matches again)
+                uint32_t stop_at = (j < ncols && pos_j > i) ? min(pos_j, window_end) : window_end;
+                for (; i < stop_at; i++) { uint8_t r = ref_at(i); push_s(r); push_g(r); }
             }
         }
-        uint32_t seq_len = min(ns, uint32_t(SEQ_CAP)), germ_len = min(ngm, uint32_t(SEQ_CAP));
+        seq_len = min(ns, uint32_t(SEQ_CAP));
+        germ_len = min(ngm, uint32_t(SEQ_CAP));
+        prof_len = j;
         // neopeptide slice and stop scan (:686-697, :42-76)
         uint32_t this_len = seq_len < ws.ewl ? seq_len : ws.ewl;
         uint32_t nlo = 0, nhi = seq_len;
@@ -563,44 +601,36 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
         if (nlen >= 3) {
             if (!is_rev) {
                 for (uint32_t c = 0; c + 3 <= nlen; c += 3)
-                    if (stop_codon_at(rec.seq + nlo, c, true)) { stop = true; break; }
+                    if (stop_codon_at(seq + nlo, c, true)) { stop = true; break; }
             } else {
                 for (int c = int(nlen) - 3; c >= 0; c -= 3)
-                    if (stop_codon_at(rec.seq + nlo, uint32_t(c), false)) { stop = true; break; }
+                    if (stop_codon_at(seq + nlo, uint32_t(c), false)) { stop = true; break; }
             }
         }
         bool differs = seq_len != germ_len;
         if (!differs)
             for (uint32_t k = 0; k < seq_len; k++)
-                if (rec.seq[k] != rec.germ[k]) { differs = true; break; }
+                if (seq[k] != germ[k]) { differs = true; break; }
         sumflags = GS_VALID | (stop ? GS_STOP : 0) | (differs ? GS_DIFFERS : 0) | (indel ? GS_INDEL : 0) |
                    (insertion ? GS_INSERTION : 0) | (broke_flag ? GS_BROKE : 0);
-        const bool want_all = ws.need_recs != 0;
-        need_rec = nsom > 0 || want_all;
-        rec.prof_set = prof_set;
-        rec.seq_len = uint8_t(seq_len);
-        rec.germ_len = uint8_t(germ_len);
-        rec.prof_len = uint8_t(j);
-        rec.nvar = uint8_t(nvar);
-        rec.nsom = uint8_t(nsom);
-        rec.first_fs = uint8_t(first_fs);
-        rec.first_fs_j = uint8_t(first_fs_j);
-        rec.pad = 0;
-        rec.id60 = 0;
+        need_rec = nsom > 0 || ws.need_recs != 0;
         if (need_rec && (nsom > 0 || (ws.need_recs & WS_ALL_IDS))) {
             // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (:667-675)
-            Sha1Dev sh;
-            sh.init();
-            sh.put('[');
+            ShaStream sh;
+            sh.init(slot);  // the staged reference bytes are dead by now
+            sh.feed('[', 1);
             for (uint32_t k = 0; k < seq_len; k++) {
-                if (k) { sh.put(','); sh.put(' '); }
-                sh.put_dec(rec.seq[k]);
+                uint32_t v = seq[k];
+                if (k) sh.feed((uint32_t(',') << 8) | ' ', 2);
+                if (v >= 100) sh.feed((uint32_t('0' + v / 100) << 16) | (uint32_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10), 3);
+                else if (v >= 10) sh.feed((uint32_t('0' + v / 10) << 8) | ('0' + v % 10), 2);
+                else sh.feed('0' + v, 1);
             }
-            sh.put(']');
-            for (uint32_t k = 0; k < T.id_len; k++) sh.put(d.str_pool[T.id_off + k]);
-            sh.put_dec(ws.sso);
+            sh.feed(']', 1);
+            for (uint32_t k = 0; k < T.id_len; k++) sh.feed(d.str_pool[T.id_off + k], 1);
+            sh.feed_dec(ws.sso);
             sh.finish();
-            rec.id60 = (uint64_t(sh.h[0]) << 28) | (uint64_t(sh.h[1]) >> 4);
+            id60 = (uint64_t(sh.h0) << 28) | (uint64_t(sh.h1) >> 4);
             sumflags |= GS_ID_VALID;
         }
         if (stop && ws.splice_pos != 2 && !(ws.flags & SF_FIRST_EXON_WIN)) atomicMin(&d.tx_first_stop[ws.tx], w);
@@ -617,7 +647,14 @@ __global__ __launch_bounds__(256) void k3_window_seq(DeviceBatch d, uint64_t n_s
         uint64_t mine = b + lanes_below(m, lane);
         if (need_rec) {
             if (mine < d.rec_cap) {
-                d.recs[mine] = rec;
+                uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + mine);
+                out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
+                out[2] = uint32_t(id60); out[3] = uint32_t(id60 >> 32);
+                out[4] = seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24);
+                out[5] = nsom | (first_fs << 8) | (first_fs_j << 16);
+                const uint32_t* sq = slot + K3_REFCAP / 4;
+#pragma unroll
+                for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[6 + k] = sq[k];
                 sumflags |= GS_HAS_REC;
                 recidx = uint32_t(mine);
             } else {
@@ -667,7 +704,7 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
 
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {
     if (n_group_slots == 0) return;
-    dim3 grid(uint32_t((n_group_slots + 255) / 256)), block(256);
+    dim3 grid(uint32_t((n_group_slots + K3_THREADS - 1) / K3_THREADS)), block(K3_THREADS);
     hipLaunchKernelGGL(k3_window_seq, grid, block, 0, stream, d, n_group_slots);
     HIP_CHECK_LAUNCH();
 }
