@@ -18,6 +18,7 @@ struct ExonPlan {           // host-only: geometry of one scheduled exon pass
 struct GeneHost {           // host-only per-gene bookkeeping
     const GeneInput* input = nullptr;
     uint64_t max_read_len = 0;
+    uint64_t max_ref_span = 0;            // max(end_pos - pos) over the kept reads
     uint32_t read_off = 0, n_reads = 0;   // into the batch read arrays
     uint32_t var_off = 0, n_vars = 0;
     uint64_t ref_off = 0;

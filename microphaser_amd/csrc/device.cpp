@@ -104,7 +104,7 @@ void DeviceContext::upload(const Batch& b) {
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
     rpl_ = 1;
-    while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_ + max_rows_bound_ / 8 + 2) rpl_ *= 2;
+    while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + chunk slack per transcript
     group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 4096 + 4096;
     rec_cap_ = group_cap_ / 2 + 4096;

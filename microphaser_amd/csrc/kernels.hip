@@ -341,29 +341,56 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 const uint64_t gbase = chunk_pos;
                 uint32_t ng = has_zero ? 0u : 1u;  // lane 0 stages the zero-count reference group
                 uint32_t sg_hi = 0, sg_lo = 0, sg_aux = 0, sg_cnt = 0;
+                // Distinct keys in ascending (haplotype, frame) order = the reference's BTreeMap order (:383).
+                // Repeated minimum extraction by bitwise descent: starting from all remaining rows, keep the
+                // rows whose key has a 0 at each bit (MSB first) whenever any such row exists. The survivors
+                // all carry the minimum key; their number is that haplotype's count. Wave-wide ballots only.
+                bool aux_here = false;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) aux_here |= act[r] && (fr0[r] != 0 || (fl[r] & RF_F1));
+                const bool any_aux = __ballot(aux_here) != 0;
                 for (;;) {
-                    uint32_t khi = 0xFFFFFFFFu, klo = 0xFFFFFFFFu, ka = 0xFFFFFFFFu;
+                    bool c[RPL];
+                    bool any_c = false;
 #pragma unroll
-                    for (int r = 0; r < RPL; r++)
-                        if (act[r]) {
-                            uint32_t h = uint32_t(hap[r] >> 32), l = uint32_t(hap[r]);
-                            uint32_t a = (fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u);
-                            if (h < khi || (h == khi && (l < klo || (l == klo && a < ka)))) { khi = h; klo = l; ka = a; }
+                    for (int r = 0; r < RPL; r++) { c[r] = act[r]; any_c |= c[r]; }
+                    if (!__ballot(any_c)) break;
+                    for (int bit = int(ncols) - 1; bit >= 0; bit--) {
+                        const uint64_t mk = 1ull << bit;
+                        bool z = false;
+#pragma unroll
+                        for (int r = 0; r < RPL; r++) z |= c[r] && !(hap[r] & mk);
+                        if (__ballot(z)) {
+#pragma unroll
+                            for (int r = 0; r < RPL; r++) c[r] = c[r] && !(hap[r] & mk);
                         }
-                    if (!__ballot(khi != 0xFFFFFFFFu)) break;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        uint32_t oh = __shfl_xor(khi, off), ol = __shfl_xor(klo, off), oa = __shfl_xor(ka, off);
-                        if (oh < khi || (oh == khi && (ol < klo || (ol == klo && oa < ka)))) { khi = oh; klo = ol; ka = oa; }
                     }
-                    uint64_t kh = (uint64_t(khi) << 32) | klo;
-                    uint32_t cnt = 0;
+                    if (any_aux) {
+                        for (int bit = 31; bit >= 0; bit--) {
+                            const uint32_t mk = 1u << bit;
+                            bool z = false;
+#pragma unroll
+                            for (int r = 0; r < RPL; r++) z |= c[r] && !(((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u)) & mk);
+                            if (__ballot(z)) {
+#pragma unroll
+                                for (int r = 0; r < RPL; r++) c[r] = c[r] && !(((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u)) & mk);
+                            }
+                        }
+                    }
+                    uint32_t cnt = 0, khi = 0, klo = 0, ka = 0;
+                    bool have_key = false;
 #pragma unroll
                     for (int r = 0; r < RPL; r++) {
-                        uint32_t a = (fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u);
-                        bool m = act[r] && hap[r] == kh && a == ka;
-                        cnt += __popcll(__ballot(m));
-                        if (m) act[r] = false;
+                        uint64_t m = __ballot(c[r]);
+                        cnt += __popcll(m);
+                        if (m && !have_key) {
+                            uint32_t l = __builtin_ctzll(m);
+                            khi = rdlane(uint32_t(hap[r] >> 32), l);
+                            klo = rdlane(uint32_t(hap[r]), l);
+                            ka = rdlane((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u), l);
+                            have_key = true;
+                        }
+                        if (c[r]) act[r] = false;
                     }
                     if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_aux = ka; sg_cnt = cnt; }
                     ng++;

@@ -143,7 +143,11 @@ struct PlannerHooks {
         cur_step = b.steps.size();
         b.steps.push_back(st);
         // live-row bound: reads whose start lies in the full candidate key range of this step
-        uint64_t span = uint64_t(read_lower(sg.cand_hi)) - read_lower(sg.sso >= (gh.max_read_len) ? sg.sso - gh.max_read_len : 0);
+        // rows enclose the window (start <= sso, end >= splice_end, so start >= splice_end - max reference span);
+        // pending reverse-strand candidates have start >= sso - (max_read_len - ewl)
+        uint64_t lo_rows = sg.splice_end > gh.max_ref_span ? sg.splice_end - gh.max_ref_span : 0;
+        uint64_t lo_cand = sg.sso > gh.max_read_len - eg.ewl ? sg.sso - (gh.max_read_len - eg.ewl) : 0;
+        uint64_t span = uint64_t(read_lower(sg.cand_hi)) - read_lower(std::min(lo_rows, lo_cand));
         max_live = std::max(max_live, span);
         if (fs_seen) ensure_window(eg, sg);
     }
@@ -198,6 +202,7 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
         for (size_t r : gi.reads) {
             if (rs.mapq[r] < mapq_min) continue;
             gh.max_read_len = std::max<uint64_t>(gh.max_read_len, rs.l_seq[r]);
+            gh.max_ref_span = std::max<uint64_t>(gh.max_ref_span, uint64_t(rs.end_pos[r] - rs.pos[r]));
             kept.push_back(r);
         }
         std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t c) { return rs.pos[a] < rs.pos[c]; });
