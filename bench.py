@@ -104,12 +104,13 @@ def main():
         st = batch.run()
     sync_all()
     t0 = time.perf_counter()
-    k1 = k2 = k3 = 0.0
+    k1 = k2 = k3 = k3b = 0.0
     for _ in range(args.steps):
         st = batch.run()          # returns after the launch stream has drained (results in HBM)
         k1 += st.k1_ms
         k2 += st.k2_ms
         k3 += st.k3_ms
+        k3b += st.k3b_ms
     sync_all()
     elapsed = time.perf_counter() - t0
 
@@ -138,7 +139,7 @@ def main():
         ms_per_step = elapsed_max / steps * 1e3
         value = total_windows * steps / elapsed_max
         kern = {"k1_pileup_bits": (k1 / steps, st.bytes_k1), "k2_window_replay": (k2 / steps, st.bytes_k2),
-                "k3_window_seq": (k3 / steps, st.bytes_k3)}
+                "k3_window_seq": (k3 / steps, st.bytes_k3), "k3b_haplotype_ids": (k3b / steps, st.bytes_k3b)}
         dom = max(kern, key=lambda k: kern[k][0])
         dom_ms, dom_bytes = kern[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

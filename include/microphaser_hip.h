@@ -50,11 +50,11 @@ void mp_dataset_free(mp_dataset* ds);
 
 /* Statistics of one pass of the hot path (filled by mp_batch_run). */
 typedef struct mp_run_stats {
-    double k1_ms, k2_ms, k3_ms, total_ms;  /* HIP-event times on the launch stream */
+    double k1_ms, k2_ms, k3_ms, k3b_ms, total_ms;  /* HIP-event times on the launch stream */
     uint64_t n_windows_planned;            /* main-ORF windows in the speculative schedule */
     uint64_t n_steps, n_transcripts, n_reads, n_variants;
     uint64_t n_groups, n_records;
-    uint64_t bytes_k1, bytes_k2, bytes_k3; /* algorithmic HBM bytes per launch */
+    uint64_t bytes_k1, bytes_k2, bytes_k3, bytes_k3b; /* algorithmic HBM bytes per launch */
     uint64_t hbm_bytes;                    /* device memory held by the batch */
     uint32_t rows_per_lane, mask_words, attempts;
 } mp_run_stats;

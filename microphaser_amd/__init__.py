@@ -29,11 +29,11 @@ def build(verbose=False):
 
 class RunStats(ctypes.Structure):
     _fields_ = [
-        ("k1_ms", ctypes.c_double), ("k2_ms", ctypes.c_double), ("k3_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+        ("k1_ms", ctypes.c_double), ("k2_ms", ctypes.c_double), ("k3_ms", ctypes.c_double), ("k3b_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
         ("n_windows_planned", ctypes.c_uint64),
         ("n_steps", ctypes.c_uint64), ("n_transcripts", ctypes.c_uint64), ("n_reads", ctypes.c_uint64), ("n_variants", ctypes.c_uint64),
         ("n_groups", ctypes.c_uint64), ("n_records", ctypes.c_uint64),
-        ("bytes_k1", ctypes.c_uint64), ("bytes_k2", ctypes.c_uint64), ("bytes_k3", ctypes.c_uint64),
+        ("bytes_k1", ctypes.c_uint64), ("bytes_k2", ctypes.c_uint64), ("bytes_k3", ctypes.c_uint64), ("bytes_k3b", ctypes.c_uint64),
         ("hbm_bytes", ctypes.c_uint64),
         ("rows_per_lane", ctypes.c_uint32), ("mask_words", ctypes.c_uint32), ("attempts", ctypes.c_uint32),
     ]

@@ -128,7 +128,7 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
             const Batch& b = batch->batch;
             const RunTiming& t = batch->timing;
             *st = mp_run_stats();
-            st->k1_ms = t.k1_ms; st->k2_ms = t.k2_ms; st->k3_ms = t.k3_ms; st->total_ms = t.total_ms;
+            st->k1_ms = t.k1_ms; st->k2_ms = t.k2_ms; st->k3_ms = t.k3_ms; st->k3b_ms = t.k3b_ms; st->total_ms = t.total_ms;
             st->n_windows_planned = b.n_main_windows;
             st->n_steps = b.steps.size(); st->n_transcripts = b.tx.size();
             st->n_reads = b.r_pos.size(); st->n_variants = b.v_pos.size();
@@ -139,6 +139,7 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                            b.wins.size() * sizeof(WinDyn) + t.n_group_slots * (sizeof(Group) + 4);
             // K3: group + window + refseq window reads, summary + record writes
             st->bytes_k3 = t.n_group_slots * (sizeof(Group) + 4 + sizeof(WinStatic) + 32 + sizeof(GroupSum)) + t.n_recs * sizeof(HapRec);
+            st->bytes_k3b = t.n_recs * (sizeof(HapRec) / 2 + sizeof(WinStatic) + 8);  // seq half of the record + window + id write
             st->hbm_bytes = dev.hbm_bytes();
             st->rows_per_lane = uint32_t(t.rows_per_lane); st->mask_words = b.mask_words; st->attempts = t.attempts;
         }

@@ -106,7 +106,7 @@ void DeviceContext::upload(const Batch& b) {
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + chunk slack per transcript
-    group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 4096 + 4096;
+    group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 1024 + 4096;
     rec_cap_ = group_cap_ / 2 + 4096;
     alloc_outputs();
     HIP_OK(hipStreamSynchronize(stream_));
@@ -166,10 +166,14 @@ void DeviceContext::run(RunTiming& t) {
             alloc_outputs();
             continue;
         }
+        launch_k3b_haplotype_ids(d_, cur[1], stream_);
+        HIP_OK(hipEventRecord(ev_[4], stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
         HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
-        HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[3]));
+        HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         t.n_group_slots = last_slots_ = slots;
         t.n_recs = last_recs_ = cur[1];
         return;

@@ -117,7 +117,7 @@ enum : uint32_t { ST_EMPTY = 0, ST_PENDING = 1, ST_ROW = 2, ST_MASK = 3, RF_BAD 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 
-constexpr uint32_t GROUP_CHUNK = 4096;
+constexpr uint32_t GROUP_CHUNK = 1024;  // >= 64 * max rows per lane (16)
 
 template <int RPL>
 __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
@@ -132,12 +132,13 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     __shared__ uint32_t colf[64];     // forward variant index (gene-relative) of each live column
     __shared__ uint32_t colinfo[64];  // v_info | start-loss bit 31
 
-    uint32_t fl[RPL], rs[RPL], re[RPL], rvl[RPL], rdup[RPL], ridx[RPL], fr0[RPL];
+    uint32_t fl[RPL], rs[RPL], re[RPL], rvl[RPL], rdup[RPL], ridx[RPL], fr0[RPL], pver[RPL];
     uint64_t hap[RPL], msup[RPL], mlq[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) { fl[r] = ST_EMPTY; rs[r] = re[r] = rvl[r] = rdup[r] = ridx[r] = fr0[r] = 0; hap[r] = msup[r] = mlq[r] = 0; }
+    for (int r = 0; r < RPL; r++) { fl[r] = ST_EMPTY; rs[r] = re[r] = rvl[r] = rdup[r] = ridx[r] = fr0[r] = pver[r] = 0; hap[r] = msup[r] = mlq[r] = 0; }
 
     uint32_t ncols = 0, head = 0;
+    uint32_t colver = 1;  // bumped whenever the column set changes
     uint64_t chunk_pos = 0, chunk_end = 0;
     uint32_t sticky_err = 0;
 
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 }
             }
             // ---- shrink_left (:220-229)
+            if (n_del | n_add) colver++;
             if (n_del) {
                 ncols -= n_del;
                 head = (head + n_del) & 63;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                             rdup[r] = d.r_dup[gi];
                             if (W == 1) { msup[r] = d.r_sup[gi]; mlq[r] = d.r_lq[gi]; }
                             fl[r] = ST_PENDING;
+                            pver[r] = 0;
                         }
                         uint32_t took = min(uint32_t(__popcll(freem)), left);
                         c += took;
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
             bool any_att = false;
 #pragma unroll
             for (int r = 0; r < RPL; r++) {
-                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso;
+                // a read rejected for bad quality stays rejected until the column set changes (:192-195, :333-335)
+                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso && pver[r] != colver;
                 any_att |= att[r];
             }
             if (__ballot(any_att)) {
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 #pragma unroll
                 for (int r = 0; r < RPL; r++)
                     if (att[r]) {
-                        if (fl[r] & RF_BAD) fl[r] = is_rev ? uint32_t(ST_PENDING) : uint32_t(ST_EMPTY);  // :333-335 not inserted
+                        if (fl[r] & RF_BAD) { fl[r] = is_rev ? uint32_t(ST_PENDING) : uint32_t(ST_EMPTY); pver[r] = colver; }  // :333-335 not inserted
                         else fl[r] = (fl[r] & ~ST_MASK) | ST_ROW;
                     }
             }
@@ -516,7 +520,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     const bool live = w != 0xFFFFFFFFu;
     uint32_t sumflags = 0;
     bool need_rec = false;
-    uint64_t prof_set = 0, id60 = 0;
+    uint64_t prof_set = 0;
+    bool want_id = false;
     uint32_t seq_len = 0, germ_len = 0, prof_len = 0, nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
     if (live) {
         const WinStatic ws = d.wins[w];
@@ -641,25 +646,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         sumflags = GS_VALID | (stop ? GS_STOP : 0) | (differs ? GS_DIFFERS : 0) | (indel ? GS_INDEL : 0) |
                    (insertion ? GS_INSERTION : 0) | (broke_flag ? GS_BROKE : 0);
         need_rec = nsom > 0 || ws.need_recs != 0;
-        if (need_rec && (nsom > 0 || (ws.need_recs & WS_ALL_IDS))) {
-            // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (:667-675)
-            ShaStream sh;
-            sh.init(slot);  // the staged reference bytes are dead by now
-            sh.feed('[', 1);
-            for (uint32_t k = 0; k < seq_len; k++) {
-                uint32_t v = seq[k];
-                if (k) sh.feed((uint32_t(',') << 8) | ' ', 2);
-                if (v >= 100) sh.feed((uint32_t('0' + v / 100) << 16) | (uint32_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10), 3);
-                else if (v >= 10) sh.feed((uint32_t('0' + v / 10) << 8) | ('0' + v % 10), 2);
-                else sh.feed('0' + v, 1);
-            }
-            sh.feed(']', 1);
-            for (uint32_t k = 0; k < T.id_len; k++) sh.feed(d.str_pool[T.id_off + k], 1);
-            sh.feed_dec(ws.sso);
-            sh.finish();
-            id60 = (uint64_t(sh.h0) << 28) | (uint64_t(sh.h1) >> 4);
-            sumflags |= GS_ID_VALID;
-        }
+        want_id = need_rec && (nsom > 0 || (ws.need_recs & WS_ALL_IDS));  // hashed by k3b_haplotype_ids
         if (stop && ws.splice_pos != 2 && !(ws.flags & SF_FIRST_EXON_WIN)) atomicMin(&d.tx_first_stop[ws.tx], w);
     }
     // compact record allocation: one atomic per wave
@@ -676,13 +663,15 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
             if (mine < d.rec_cap) {
                 uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + mine);
                 out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
-                out[2] = uint32_t(id60); out[3] = uint32_t(id60 >> 32);
+                out[2] = 0; out[3] = 0;
                 out[4] = seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24);
                 out[5] = nsom | (first_fs << 8) | (first_fs_j << 16);
                 const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
                 for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[6 + k] = sq[k];
-                sumflags |= GS_HAS_REC;
+                out[30] = w;
+                out[31] = want_id ? 1u : 0u;
+                sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
                 recidx = uint32_t(mine);
             } else {
                 atomicOr(d.err, WD_GROUP_OVERFLOW);
@@ -695,6 +684,43 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         gs.rec = recidx;
         d.gsum[g] = gs;
     }
+}
+
+// K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
+// id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
+__global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t n_recs) {
+    __shared__ uint32_t lds_blk[64 * 17];
+    const uint64_t r = uint64_t(blockIdx.x) * 64 + threadIdx.x;
+    if (r >= n_recs) return;
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(d.recs + r);
+    if (rec[31] == 0) return;
+    const uint32_t seq_len = rec[4] & 0xFF;
+    const WinStatic ws = d.wins[rec[30]];
+    const TxDev T = d.tx[ws.tx];
+    uint32_t sq[SEQ_CAP / 4];
+#pragma unroll
+    for (int k = 0; k < SEQ_CAP / 4; k++) sq[k] = rec[6 + k];
+    ShaStream sh;
+    sh.init(lds_blk + threadIdx.x * 17);
+    sh.feed('[', 1);
+#pragma unroll
+    for (int k = 0; k < SEQ_CAP; k++) {
+        if (uint32_t(k) < seq_len) {
+            uint32_t v = (sq[k >> 2] >> (8 * (k & 3))) & 0xFF;
+            if (k) sh.feed((uint32_t(',') << 8) | ' ', 2);
+            if (v >= 100) sh.feed((uint32_t('0' + v / 100) << 16) | (uint32_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10), 3);
+            else if (v >= 10) sh.feed((uint32_t('0' + v / 10) << 8) | ('0' + v % 10), 2);
+            else sh.feed('0' + v, 1);
+        }
+    }
+    sh.feed(']', 1);
+    for (uint32_t k = 0; k < T.id_len; k++) sh.feed(d.str_pool[T.id_off + k], 1);
+    sh.feed_dec(ws.sso);
+    sh.finish();
+    uint64_t id60 = (uint64_t(sh.h0) << 28) | (uint64_t(sh.h1) >> 4);
+    uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + r);
+    out[2] = uint32_t(id60);
+    out[3] = uint32_t(id60 >> 32);
 }
 
 // ====================================================================== launchers
@@ -733,6 +759,13 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStrea
     if (n_group_slots == 0) return;
     dim3 grid(uint32_t((n_group_slots + K3_THREADS - 1) / K3_THREADS)), block(K3_THREADS);
     hipLaunchKernelGGL(k3_window_seq, grid, block, 0, stream, d, n_group_slots);
+    HIP_CHECK_LAUNCH();
+}
+
+void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream) {
+    if (n_recs == 0) return;
+    dim3 grid(uint32_t((n_recs + 63) / 64)), block(64);
+    hipLaunchKernelGGL(k3b_haplotype_ids, grid, block, 0, stream, d, n_recs);
     HIP_CHECK_LAUNCH();
 }
 

@@ -47,5 +47,6 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream);
+void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream);
 
 }  // namespace mp

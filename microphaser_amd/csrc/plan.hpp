@@ -118,7 +118,8 @@ struct HapRec {          // K3 output for groups whose sequence the host needs
     uint8_t seq_len, germ_len, prof_len, nvar, nsom, first_fs, first_fs_j, pad;
     uint8_t seq[SEQ_CAP];
     uint8_t germ[SEQ_CAP];
-    uint8_t pad2[8];
+    uint32_t win;        // window index (K3b hashes transcript id + offset of that window)
+    uint32_t want_id;    // 1: K3b computes id60
 };
 static_assert(sizeof(HapRec) == 128, "HapRec layout");
 
