@@ -36,7 +36,7 @@ void* DeviceContext::dalloc(size_t bytes) {
 
 template <class T>
 T* DeviceContext::up(const std::vector<T>& v) {
-    T* p = static_cast<T*>(dalloc(v.size() * sizeof(T)));
+    T* p = static_cast<T*>(dalloc(v.size() * sizeof(T) + 64));  // +64: kernels stage pools with 16-byte loads
     allocs_.push_back(p);
     if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
     return p;

@@ -343,73 +343,104 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 const bool can_write = chunk_end <= d.group_cap && nvalid <= GROUP_CHUNK;
                 if (!can_write) werr |= WD_GROUP_OVERFLOW;
                 const uint64_t gbase = chunk_pos;
-                uint32_t ng = has_zero ? 0u : 1u;  // lane 0 stages the zero-count reference group
-                uint32_t sg_hi = 0, sg_lo = 0, sg_aux = 0, sg_cnt = 0;
-                // Distinct keys in ascending (haplotype, frame) order = the reference's BTreeMap order (:383).
-                // Repeated minimum extraction by bitwise descent: starting from all remaining rows, keep the
-                // rows whose key has a 0 at each bit (MSB first) whenever any such row exists. The survivors
-                // all carry the minimum key; their number is that haplotype's count. Wave-wide ballots only.
-                bool aux_here = false;
-#pragma unroll
-                for (int r = 0; r < RPL; r++) aux_here |= act[r] && (fr0[r] != 0 || (fl[r] & RF_F1));
-                const bool any_aux = __ballot(aux_here) != 0;
-                for (;;) {
-                    bool c[RPL];
-                    bool any_c = false;
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) { c[r] = act[r]; any_c |= c[r]; }
-                    if (!__ballot(any_c)) break;
-                    for (int bit = int(ncols) - 1; bit >= 0; bit--) {
-                        const uint64_t mk = 1ull << bit;
-                        bool z = false;
-#pragma unroll
-                        for (int r = 0; r < RPL; r++) z |= c[r] && !(hap[r] & mk);
-                        if (__ballot(z)) {
-#pragma unroll
-                            for (int r = 0; r < RPL; r++) c[r] = c[r] && !(hap[r] & mk);
-                        }
+                uint32_t ng = 0;
+                if constexpr (RPL == 1) {
+                    // <= 64 rows: (1) leader loop - pick any remaining row, ballot the rows with the same key (its count),
+                    // stage the key in lane `ng`; (2) rank every staged key among the others (all-pairs via readlane) and
+                    // store it at its rank, so memory holds the keys in the reference's ascending BTreeMap order (:383).
+                    uint32_t khi_s = 0, klo_s = 0, ka_s = 0, cnt_s = 0;   // lane g stages group g
+                    if (!has_zero) ng = 1;                                // lane 0 = zero-count reference haplotype (0, frame 0)
+                    const uint32_t my_hi = uint32_t(hap[0] >> 32), my_lo = uint32_t(hap[0]);
+                    const uint32_t my_a = (fr0[0] << 1) | ((fl[0] & RF_F1) ? 1u : 0u);
+                    uint64_t rem = __ballot(act[0]);
+                    while (rem) {
+                        const uint32_t l = __builtin_ctzll(rem);
+                        const uint32_t kh = rdlane(my_hi, l), kl = rdlane(my_lo, l), ka = rdlane(my_a, l);
+                        const uint64_t m = __ballot(act[0] && my_hi == kh && my_lo == kl && my_a == ka);
+                        rem &= ~m;
+                        if (lane == ng) { khi_s = kh; klo_s = kl; ka_s = ka; cnt_s = uint32_t(__popcll(m)); }
+                        ng++;
                     }
-                    if (any_aux) {
-                        for (int bit = 31; bit >= 0; bit--) {
-                            const uint32_t mk = 1u << bit;
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < ng; j++) {
+                        const uint32_t oh = rdlane(khi_s, j), ol = rdlane(klo_s, j), oa = rdlane(ka_s, j);
+                        rank += (oh < khi_s || (oh == khi_s && (ol < klo_s || (ol == klo_s && oa < ka_s)))) ? 1u : 0u;
+                    }
+                    if (can_write && lane < ng) {
+                        const uint64_t gi = gbase + rank;
+                        Group G; G.hap = (uint64_t(khi_s) << 32) | klo_s; G.count = cnt_s; G.aux = ka_s;
+                        d.groups[gi] = G;
+                        d.g_win[gi] = win;
+                    }
+                } else {
+                    ng = has_zero ? 0u : 1u;  // lane 0 stages the zero-count reference group
+                    uint32_t sg_hi = 0, sg_lo = 0, sg_aux = 0, sg_cnt = 0;
+                    // Distinct keys in ascending (haplotype, frame) order = the reference's BTreeMap order (:383).
+                    // Repeated minimum extraction by bitwise descent: starting from all remaining rows, keep the
+                    // rows whose key has a 0 at each bit (MSB first) whenever any such row exists. The survivors
+                    // all carry the minimum key; their number is that haplotype's count. Wave-wide ballots only.
+                    bool aux_here = false;
+    #pragma unroll
+                    for (int r = 0; r < RPL; r++) aux_here |= act[r] && (fr0[r] != 0 || (fl[r] & RF_F1));
+                    const bool any_aux = __ballot(aux_here) != 0;
+                    for (;;) {
+                        bool c[RPL];
+                        bool any_c = false;
+    #pragma unroll
+                        for (int r = 0; r < RPL; r++) { c[r] = act[r]; any_c |= c[r]; }
+                        if (!__ballot(any_c)) break;
+                        for (int bit = int(ncols) - 1; bit >= 0; bit--) {
+                            const uint64_t mk = 1ull << bit;
                             bool z = false;
-#pragma unroll
-                            for (int r = 0; r < RPL; r++) z |= c[r] && !(((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u)) & mk);
+    #pragma unroll
+                            for (int r = 0; r < RPL; r++) z |= c[r] && !(hap[r] & mk);
                             if (__ballot(z)) {
-#pragma unroll
-                                for (int r = 0; r < RPL; r++) c[r] = c[r] && !(((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u)) & mk);
+    #pragma unroll
+                                for (int r = 0; r < RPL; r++) c[r] = c[r] && !(hap[r] & mk);
                             }
                         }
-                    }
-                    uint32_t cnt = 0, khi = 0, klo = 0, ka = 0;
-                    bool have_key = false;
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) {
-                        uint64_t m = __ballot(c[r]);
-                        cnt += __popcll(m);
-                        if (m && !have_key) {
-                            uint32_t l = __builtin_ctzll(m);
-                            khi = rdlane(uint32_t(hap[r] >> 32), l);
-                            klo = rdlane(uint32_t(hap[r]), l);
-                            ka = rdlane((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u), l);
-                            have_key = true;
+                        if (any_aux) {
+                            for (int bit = 31; bit >= 0; bit--) {
+                                const uint32_t mk = 1u << bit;
+                                bool z = false;
+    #pragma unroll
+                                for (int r = 0; r < RPL; r++) z |= c[r] && !(((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u)) & mk);
+                                if (__ballot(z)) {
+    #pragma unroll
+                                    for (int r = 0; r < RPL; r++) c[r] = c[r] && !(((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u)) & mk);
+                                }
+                            }
                         }
-                        if (c[r]) act[r] = false;
+                        uint32_t cnt = 0, khi = 0, klo = 0, ka = 0;
+                        bool have_key = false;
+    #pragma unroll
+                        for (int r = 0; r < RPL; r++) {
+                            uint64_t m = __ballot(c[r]);
+                            cnt += __popcll(m);
+                            if (m && !have_key) {
+                                uint32_t l = __builtin_ctzll(m);
+                                khi = rdlane(uint32_t(hap[r] >> 32), l);
+                                klo = rdlane(uint32_t(hap[r]), l);
+                                ka = rdlane((fr0[r] << 1) | ((fl[r] & RF_F1) ? 1u : 0u), l);
+                                have_key = true;
+                            }
+                            if (c[r]) act[r] = false;
+                        }
+                        if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_aux = ka; sg_cnt = cnt; }
+                        ng++;
+                        if ((ng & 63) == 0 && can_write) {
+                            uint64_t gi = gbase + ng - 64 + lane;
+                            Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
+                            d.groups[gi] = G;
+                            d.g_win[gi] = win;
+                        }
                     }
-                    if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_aux = ka; sg_cnt = cnt; }
-                    ng++;
-                    if ((ng & 63) == 0 && can_write) {
-                        uint64_t gi = gbase + ng - 64 + lane;
+                    if ((ng & 63) && can_write && lane < (ng & 63)) {
+                        uint64_t gi = gbase + (ng & ~63u) + lane;
                         Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
                         d.groups[gi] = G;
                         d.g_win[gi] = win;
                     }
-                }
-                if ((ng & 63) && can_write && lane < (ng & 63)) {
-                    uint64_t gi = gbase + (ng & ~63u) + lane;
-                    Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
-                    d.groups[gi] = G;
-                    d.g_win[gi] = win;
                 }
                 if (lane == 0) {
                     WinDyn wd;
