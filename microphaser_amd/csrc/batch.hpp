@@ -47,7 +47,7 @@ struct Batch {
     std::vector<TxDev> tx;
     std::vector<Step> steps;
     std::vector<WinStatic> wins;
-    std::vector<uint32_t> win_cols;       // column lists of the printing windows (gene-relative forward variant indices)
+    std::vector<WinCol> win_cols;         // column lists of the printing windows
     std::vector<ExonPlan> exons;
     std::vector<uint8_t> str_pool;        // transcript ids
     std::vector<uint32_t> tx_order;       // launch order (longest first)

@@ -132,15 +132,15 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
             st->n_windows_planned = b.n_main_windows;
             st->n_steps = b.steps.size(); st->n_transcripts = b.tx.size();
             st->n_reads = b.r_pos.size(); st->n_variants = b.v_pos.size();
-            st->n_groups = t.n_group_slots; st->n_records = t.n_recs;
+            st->n_groups = t.n_groups; st->n_records = t.n_recs;
             // algorithmic (compulsory) HBM bytes per launch, every byte counted once
             uint64_t sum_wlen = 0, sum_cols = 0;
             for (const WinStatic& w : b.wins) { sum_wlen += w.wlen; sum_cols += w.ncols; }
             st->bytes_k1 = b.bytes_k1_in() + b.bytes_k1_out();
             st->bytes_k2 = b.steps.size() * sizeof(Step) + b.r_pos.size() * (20 + 16ull * b.mask_words) +
-                           b.wins.size() * sizeof(WinDyn) + t.n_group_slots * (sizeof(Group) + 4);
-            st->bytes_k3 = t.n_group_slots * (sizeof(Group) + 4 + sizeof(GroupSum)) +
-                           b.wins.size() * sizeof(WinStatic) + sum_wlen + 4 * sum_cols + t.n_recs * sizeof(HapRec);
+                           b.wins.size() * sizeof(WinDyn) + t.n_groups * (sizeof(Group) + 4);
+            st->bytes_k3 = t.n_groups * (sizeof(Group) + 4 + sizeof(GroupSum)) +
+                           b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols + t.n_recs * sizeof(HapRec);
             st->bytes_k3b = t.n_recs * (sizeof(HapRec) / 2 + 8);
             st->hbm_bytes = dev.hbm_bytes();
             st->rows_per_lane = uint32_t(t.rows_per_lane); st->mask_words = b.mask_words; st->attempts = t.attempts;

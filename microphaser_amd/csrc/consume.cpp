@@ -157,7 +157,7 @@ struct ConsumerHooks {
         std::vector<const Variant*> variants(ncols);
         for (uint32_t j = 0; j < ncols; j++) {
             uint32_t dq = is_fwd ? j : ncols - 1 - j;
-            variants[j] = &gvars[b.win_cols[ws.col_off + dq]];
+            variants[j] = &gvars[b.win_cols[ws.col_off + dq].f];
         }
         // haplotype keys of this call (:383-411) from the device groups (ascending (hap, frame0, f1nz))
         struct Key { uint64_t hap, hframe; size_t count; uint64_t slot; };
@@ -234,7 +234,10 @@ struct ConsumerHooks {
             const bool emit_pre = (n_somatic > 0 || has_frameshift) && !eg.is_short && germ_ne_seq && (!stop_gain || has_frameshift);
             std::string normal_peptide, neopeptide;
             const bool need_strings = rec && (indel || boundary || emit_pre);
-            if ((indel || boundary || emit_pre) && !rec) throw Error("internal error: missing haplotype record");
+            if ((indel || boundary || emit_pre) && !rec)
+                throw Error("internal error: missing haplotype record (window sso " + std::to_string(ws.sso) + ", hap " + std::to_string(key.hap) +
+                            ", need_recs " + std::to_string(ws.need_recs) + ", group flags " + std::to_string(gs.flags) + ", step flags " +
+                            std::to_string(st.flags) + ", count " + std::to_string(key.count) + ")");
             if (need_strings) {
                 auto sl = [](const uint8_t* p, uint64_t n, uint64_t a, uint64_t e) {
                     if (a > e || e > n) throw Error("reference would panic: slice index out of range");

@@ -99,15 +99,15 @@ void DeviceContext::upload(const Batch& b) {
     d_.r_sup = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_sup);
     d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);
     d_.win_dyn = static_cast<WinDyn*>(dalloc(size_t(d_.n_wins) * sizeof(WinDyn))); allocs_.push_back(d_.win_dyn);
-    d_.cursors = static_cast<unsigned long long*>(dalloc(16)); allocs_.push_back(d_.cursors);
+    d_.cursors = static_cast<unsigned long long*>(dalloc(32)); allocs_.push_back(d_.cursors);
     d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + chunk slack per transcript
-    group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 1024 + 4096;
-    rec_cap_ = group_cap_ / 2 + 4096;
+    group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 1024 + 4096;  // slack: one partly used chunk per transcript
+    rec_cap_ = group_cap_ / 3 + uint64_t(d_.n_tx + 1) * 128 + 4096;
     alloc_outputs();
     HIP_OK(hipStreamSynchronize(stream_));
 }
@@ -117,6 +117,7 @@ void DeviceContext::alloc_outputs() {
     auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); return p; };
     d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
     d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
+    d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
     d_.recs = static_cast<HapRec*>(oalloc(rec_cap_ * sizeof(HapRec)));
     d_.group_cap = group_cap_;
@@ -129,7 +130,7 @@ void DeviceContext::run(RunTiming& t) {
     for (int attempt = 0; attempt < 8; attempt++) {
         t.attempts = uint32_t(attempt + 1);
         t.rows_per_lane = rpl_;
-        HIP_OK(hipMemsetAsync(d_.cursors, 0, 16, stream_));
+        HIP_OK(hipMemsetAsync(d_.cursors, 0, 32, stream_));
         HIP_OK(hipMemsetAsync(d_.err, 0, 4, stream_));
         HIP_OK(hipMemsetAsync(d_.g_win, 0xFF, group_cap_ * 4, stream_));
         HIP_OK(hipMemsetAsync(d_.win_dyn, 0, size_t(d_.n_wins) * sizeof(WinDyn), stream_));
@@ -139,9 +140,9 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(ev_[1], stream_));
         launch_k2_window_replay(d_, rpl_, stream_);
         HIP_OK(hipEventRecord(ev_[2], stream_));
-        unsigned long long cur[2] = {0, 0};
+        unsigned long long cur[4] = {0, 0, 0, 0};
         uint32_t err = 0;
-        HIP_OK(hipMemcpyAsync(cur, d_.cursors, 8, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(cur, d_.cursors, 32, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
         if (err & WD_ROW_OVERFLOW) {
@@ -149,33 +150,28 @@ void DeviceContext::run(RunTiming& t) {
             rpl_ *= 2;
             continue;
         }
-        if ((err & WD_GROUP_OVERFLOW) || cur[0] > group_cap_) {
-            group_cap_ = std::max<uint64_t>(group_cap_ * 2, cur[0] + 4096);
-            rec_cap_ = std::max(rec_cap_, group_cap_ / 2);
+        if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || cur[0] > group_cap_ || cur[1] > rec_cap_) {
+            if ((err & WD_GROUP_OVERFLOW) || cur[0] > group_cap_) group_cap_ = std::max<uint64_t>(group_cap_ * 2, cur[0] + 4096);
+            if ((err & WD_REC_OVERFLOW) || cur[1] > rec_cap_) rec_cap_ = std::max<uint64_t>(rec_cap_ * 2, cur[1] + 4096);
             alloc_outputs();
             continue;
         }
-        uint64_t slots = cur[0];
+        const uint64_t slots = cur[0], rec_slots = cur[1];
         launch_k3_window_seq(d_, slots, stream_);
         HIP_OK(hipEventRecord(ev_[3], stream_));
-        HIP_OK(hipMemcpyAsync(cur, d_.cursors, 16, hipMemcpyDeviceToHost, stream_));
+        launch_k3b_haplotype_ids(d_, rec_slots, stream_);
+        HIP_OK(hipEventRecord(ev_[4], stream_));
         HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
-        if ((err & WD_GROUP_OVERFLOW) || cur[1] > rec_cap_) {
-            rec_cap_ = std::max<uint64_t>(rec_cap_ * 2, cur[1] + 4096);
-            alloc_outputs();
-            continue;
-        }
-        launch_k3b_haplotype_ids(d_, cur[1], stream_);
-        HIP_OK(hipEventRecord(ev_[4], stream_));
-        HIP_OK(hipStreamSynchronize(stream_));
+        if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
         HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         t.n_group_slots = last_slots_ = slots;
-        t.n_recs = last_recs_ = cur[1];
+        t.n_recs = last_recs_ = rec_slots;
+        t.n_groups = cur[2];
         return;
     }
     throw Error("device result buffers kept overflowing");

@@ -19,7 +19,7 @@ struct HostResults {         // device results copied back for the consumer
 
 struct RunTiming {
     float k1_ms = 0, k2_ms = 0, k3_ms = 0, k3b_ms = 0, total_ms = 0;
-    uint64_t n_group_slots = 0, n_recs = 0;
+    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0;
     int rows_per_lane = 1;
     uint32_t attempts = 0;
 };

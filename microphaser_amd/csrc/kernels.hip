@@ -117,10 +117,11 @@ enum : uint32_t { ST_EMPTY = 0, ST_PENDING = 1, ST_ROW = 2, ST_MASK = 3, RF_BAD 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 
-constexpr uint32_t GROUP_CHUNK = 1024;  // >= 64 * max rows per lane (16)
+constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: one emit call)
 
 template <int RPL>
 __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
+    constexpr uint32_t GROUP_CHUNK = RPL <= 4 ? 256u : 64u * RPL;  // group slots per allocation (>= rows of one window)
     const uint32_t lane = threadIdx.x;
     const uint32_t t = d.tx_order[blockIdx.x];
     const TxDev T = d.tx[t];
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 
     uint32_t ncols = 0, head = 0;
     uint32_t colver = 1;  // bumped whenever the column set changes
-    uint64_t chunk_pos = 0, chunk_end = 0;
+    uint64_t chunk_pos = 0, chunk_end = 0;   // group slots (per-wave chunk allocator: one atomic per GROUP_CHUNK groups)
+    uint64_t rec_pos = 0, rec_end = 0;       // haplotype-record slots, same scheme (K3 then needs no atomics at all)
+    uint64_t som_mask = 0;                   // bit c set <=> live column c is a somatic variant (same bit order as hap)
+    uint64_t n_groups_tx = 0;
     uint32_t sticky_err = 0;
 
     // support / low-quality bit of row slot r for forward variant index f
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 ncols -= n_del;
                 head = (head + n_del) & 63;
                 uint64_t mask = (1ull << ncols) - 1ull;
+                som_mask &= mask;
 #pragma unroll
                 for (int r = 0; r < RPL; r++) hap[r] &= mask;
             }
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 __syncthreads();
                 if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
                 ncols++;
+                som_mask = (som_mask << 1) | ((info & VI_GERMLINE) ? 0ull : 1ull);
 #pragma unroll
                 for (int r = 0; r < RPL; r++)
                     if ((fl[r] & ST_MASK) == ST_ROW) {
@@ -344,6 +350,37 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 if (!can_write) werr |= WD_GROUP_OVERFLOW;
                 const uint64_t gbase = chunk_pos;
                 uint32_t ng = 0;
+                const bool need_all = (sflags & SF_NEED_RECS) != 0;
+                // write the staged groups of the `on` lanes; groups whose sequence the host may need (a somatic column
+                // is set, or the planner asked for every haplotype of this window) get a HapRec slot here
+                auto emit = [&](bool on, uint64_t gi, uint32_t kh, uint32_t kl, uint32_t ka, uint32_t cnt) {
+                    const uint64_t key = (uint64_t(kh) << 32) | kl;
+                    const bool need = on && can_write && (need_all || (key & som_mask) != 0);
+                    const uint64_t nm = __ballot(need);
+                    const uint32_t nneed = __popcll(nm);
+                    if (nneed && rec_pos + nneed > rec_end) {
+                        for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the chunk's unused tail
+                            if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q)[31] = 0;
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)REC_CHUNK);
+                        uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                        rec_pos = (uint64_t(bhi) << 32) | blo;
+                        rec_end = rec_pos + REC_CHUNK;
+                    }
+                    uint32_t rec = 0xFFFFFFFFu;
+                    if (need) {
+                        const uint64_t r = rec_pos + lanes_below(nm, lane);
+                        if (r < d.rec_cap) rec = uint32_t(r);
+                    }
+                    if (nneed && rec_pos + nneed > d.rec_cap) sticky_err |= WD_REC_OVERFLOW;
+                    rec_pos += nneed;
+                    if (on && can_write) {
+                        Group G; G.hap = key; G.count = cnt; G.aux = ka;
+                        d.groups[gi] = G;
+                        d.g_win[gi] = win;
+                        d.g_rec[gi] = rec;
+                    }
+                };
                 if constexpr (RPL == 1) {
                     // <= 64 rows: (1) leader loop - pick any remaining row, ballot the rows with the same key (its count),
                     // stage the key in lane `ng`; (2) rank every staged key among the others (all-pairs via readlane) and
@@ -366,12 +403,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                         const uint32_t oh = rdlane(khi_s, j), ol = rdlane(klo_s, j), oa = rdlane(ka_s, j);
                         rank += (oh < khi_s || (oh == khi_s && (ol < klo_s || (ol == klo_s && oa < ka_s)))) ? 1u : 0u;
                     }
-                    if (can_write && lane < ng) {
-                        const uint64_t gi = gbase + rank;
-                        Group G; G.hap = (uint64_t(khi_s) << 32) | klo_s; G.count = cnt_s; G.aux = ka_s;
-                        d.groups[gi] = G;
-                        d.g_win[gi] = win;
-                    }
+                    emit(lane < ng, gbase + rank, khi_s, klo_s, ka_s, cnt_s);
                 } else {
                     ng = has_zero ? 0u : 1u;  // lane 0 stages the zero-count reference group
                     uint32_t sg_hi = 0, sg_lo = 0, sg_aux = 0, sg_cnt = 0;
@@ -428,19 +460,9 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                         }
                         if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_aux = ka; sg_cnt = cnt; }
                         ng++;
-                        if ((ng & 63) == 0 && can_write) {
-                            uint64_t gi = gbase + ng - 64 + lane;
-                            Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
-                            d.groups[gi] = G;
-                            d.g_win[gi] = win;
-                        }
+                        if ((ng & 63) == 0) emit(true, gbase + ng - 64 + lane, sg_hi, sg_lo, sg_aux, sg_cnt);
                     }
-                    if ((ng & 63) && can_write && lane < (ng & 63)) {
-                        uint64_t gi = gbase + (ng & ~63u) + lane;
-                        Group G; G.hap = (uint64_t(sg_hi) << 32) | sg_lo; G.count = sg_cnt; G.aux = sg_aux;
-                        d.groups[gi] = G;
-                        d.g_win[gi] = win;
-                    }
+                    if (ng & 63) emit(lane < (ng & 63), gbase + (ng & ~63u) + lane, sg_hi, sg_lo, sg_aux, sg_cnt);
                 }
                 if (lane == 0) {
                     WinDyn wd;
@@ -450,10 +472,13 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     wd.flags = WD_DONE | werr;
                     d.win_dyn[win] = wd;
                 }
-                if (can_write) chunk_pos += ng;
+                if (can_write) { chunk_pos += ng; n_groups_tx += ng; }
             }
         }
     }
+    for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the last record chunk's unused tail
+        if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q)[31] = 0;
+    if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
 
@@ -556,16 +581,13 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     uint32_t seq_len = 0, germ_len = 0, prof_len = 0, nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
     if (live) {
         const WinStatic ws = d.wins[w];
-        const TxDev T = d.tx[ws.tx];
-        const uint32_t vbase = d.g_var_off[T.gene];
-        const uint32_t gstart = d.g_start[T.gene];
-        const uint8_t* ref = d.ref_pool + d.g_ref_off[T.gene];
+        const uint32_t vbase = ws.vbase;
         const uint64_t hap = d.groups[g].hap;
-        const bool is_rev = T.strand != 0;
+        const bool is_rev = (ws.flags & WSF_REVERSE) != 0;
         const uint32_t ncols = ws.ncols;
         const uint32_t window_end = ws.sso + ws.wlen;
         // stage the reference window [sso, sso + wlen) with aligned dword loads
-        const uint8_t* wref = ref + (ws.sso - gstart);
+        const uint8_t* wref = d.ref_pool + ws.ref_off;
         const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(wref) & 3u);
         {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(wref - mis);
@@ -575,7 +597,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         const uint32_t staged = min(uint32_t(ws.wlen), uint32_t(K3_REFCAP) - mis);
         auto ref_at = [&](uint32_t pos) -> uint8_t {  // reference base at absolute position pos (>= sso)
             uint32_t k = pos - ws.sso;
-            return k < staged ? refb[mis + k] : ref[pos - gstart];
+            return k < staged ? refb[mis + k] : wref[k];
         };
         uint32_t i = ws.sso, j = 0, ns = 0, ngm = 0;
         bool indel = false, insertion = false, broke_flag = false;
@@ -583,9 +605,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         auto load_j = [&]() {
             if (j < ncols) {
                 uint32_t dq = is_rev ? (ncols - 1 - j) : j;
-                f_j = d.win_cols[ws.col_off + dq];
-                pos_j = d.v_pos[vbase + f_j];
-                info_j = d.v_info[vbase + f_j];
+                const WinCol wc = d.win_cols[ws.col_off + dq];
+                f_j = wc.f;
+                pos_j = wc.pos;
+                info_j = wc.info;
             } else {
                 pos_j = 0xFFFFFFFFu;
             }
@@ -680,19 +703,13 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         want_id = need_rec && (nsom > 0 || (ws.need_recs & WS_ALL_IDS));  // hashed by k3b_haplotype_ids
         if (stop && ws.splice_pos != 2 && !(ws.flags & SF_FIRST_EXON_WIN)) atomicMin(&d.tx_first_stop[ws.tx], w);
     }
-    // compact record allocation: one atomic per wave
-    uint64_t m = __ballot(need_rec);
+    // the record slot (if any) was assigned by K2; a slot K3 turns out not to need is marked "no id"
     uint32_t recidx = 0;
-    if (m) {
-        unsigned long long base = 0;
-        uint32_t leader = __builtin_ctzll(m);
-        if (lane == leader) base = atomicAdd(d.cursors + 1, (unsigned long long)__popcll(m));
-        uint32_t blo = __shfl(uint32_t(base), leader), bhi = __shfl(uint32_t(base >> 32), leader);
-        uint64_t b = (uint64_t(bhi) << 32) | blo;
-        uint64_t mine = b + lanes_below(m, lane);
-        if (need_rec) {
-            if (mine < d.rec_cap) {
-                uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + mine);
+    if (live) {
+        const uint32_t slot_idx = d.g_rec[g];
+        if (slot_idx != 0xFFFFFFFFu) {
+            uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + slot_idx);
+            if (need_rec) {
                 out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
                 out[2] = 0; out[3] = 0;
                 out[4] = seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24);
@@ -703,10 +720,12 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                 out[30] = w;
                 out[31] = want_id ? 1u : 0u;
                 sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
-                recidx = uint32_t(mine);
+                recidx = slot_idx;
             } else {
-                atomicOr(d.err, WD_GROUP_OVERFLOW);
+                out[31] = 0;
             }
+        } else if (need_rec) {
+            atomicOr(d.err, WD_REC_OVERFLOW);  // K2's superset rule missed a haplotype (must not happen) or the record buffer is full
         }
     }
     if (live) {

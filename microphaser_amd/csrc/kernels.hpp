@@ -23,7 +23,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const TxDev* tx;
     const Step* steps;
     const WinStatic* wins;
-    const uint32_t* win_cols;
+    const WinCol* win_cols;
     const uint8_t* str_pool;
     const uint32_t* tx_order;
     uint32_t n_reads, n_tx, n_wins, mask_words;
@@ -34,7 +34,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     WinDyn* win_dyn;
     Group* groups;
     uint32_t* g_win;              // window of each group slot (0xFFFFFFFF = unused slot)
-    unsigned long long* cursors;  // [0] group cursor, [1] record cursor
+    uint32_t* g_rec;              // HapRec slot reserved for the group by K2 (0xFFFFFFFF = none)
+    unsigned long long* cursors;  // [0] group-slot cursor, [1] record-slot cursor, [2] number of groups
     uint64_t group_cap, rec_cap;
     uint32_t* err;                // sticky error word (WD_* bits)
     // K3 output

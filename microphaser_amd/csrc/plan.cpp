@@ -60,15 +60,18 @@ struct PlannerHooks {
         w.ncols = uint16_t(cols.size());
         if (cols_dirty) {  // consecutive windows with unchanged columns share one list
             cols_off = uint32_t(b.win_cols.size());
-            b.win_cols.insert(b.win_cols.end(), cols.begin(), cols.end());
+            for (uint32_t c : cols) b.win_cols.push_back(WinCol{c, b.v_pos[gh.var_off + c], b.v_info[gh.var_off + c]});
             cols_dirty = false;
         }
         w.col_off = cols_off;
+        w.ref_off = uint32_t(gh.ref_off + (st.sso - uint32_t(gh.input->gene.start())));
+        w.vbase = gh.var_off;
+        w.step = uint32_t(cur_step);
         w.wlen = st.wlen;
         w.ewl = uint8_t(eg.ewl);
         w.splice_pos = uint8_t(sg.splice_pos);
         w.splice_gap = uint8_t(sg.splice_gap);
-        w.flags = st.flags;
+        w.flags = uint8_t((st.flags & 0x7F) | (is_fwd ? 0 : WSF_REVERSE));
         b.wins.push_back(w);
         // upper bound of the sequence lengths print_haplotypes can build for this window
         uint64_t max_len = st.wlen;
@@ -80,6 +83,7 @@ struct PlannerHooks {
             if (v.kind != VK_SNV) non_snv = true;
         }
         b.wins.back().need_recs = (non_snv || fs_seen) ? WS_ALL_IDS : 0;
+        if (b.wins.back().need_recs) b.steps[cur_step].flags |= SF_NEED_RECS;
         if (max_len > SEQ_CAP)
             throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
                         " nt; this build supports at most " + std::to_string(SEQ_CAP) + " (long indel in window)");
@@ -166,8 +170,11 @@ struct PlannerHooks {
     // the merge reads the full records of both carried-over windows (:1527-1540)
     void splice_merge(const ExonGeom&, const StepGeom&, uint64_t, std::map<uint64_t, uint64_t>&, FsFreq&, std::vector<HapSeq>&,
                       std::vector<HapSeq>&) {
-        if (held_prev != 0xFFFFFFFFu) b.wins[held_prev].need_recs |= WS_CARRY;
-        if (held_hap != 0xFFFFFFFFu) b.wins[held_hap].need_recs |= WS_CARRY;
+        for (uint32_t wi : {held_prev, held_hap})
+            if (wi != 0xFFFFFFFFu) {
+                b.wins[wi].need_recs |= WS_CARRY;
+                b.steps[b.wins[wi].step].flags |= SF_NEED_RECS;
+            }
     }
 };
 

@@ -45,6 +45,7 @@ enum : uint8_t {
     SF_SHORT_EXON = 16,
     SF_FIRST_EXON = 32,
     SF_LAST_EXON = 64,
+    SF_NEED_RECS = 128,  // K2 reserves a HapRec slot for every haplotype of this window (WinStatic.need_recs != 0)
 };
 
 struct Step {            // one per nt-offset step of the window scheduler (reference: microphasing.rs:1030-1914)
@@ -63,23 +64,32 @@ struct Step {            // one per nt-offset step of the window scheduler (refe
 };
 static_assert(sizeof(Step) == 28, "Step layout");
 
-struct WinStatic {       // one per printing step; everything K3 needs that does not depend on reads
+struct WinStatic {       // one per printing step; everything K3 needs that does not depend on reads (flattened: one hop)
     uint32_t tx;
     uint32_t sso;
-    uint32_t col_off;    // first entry of this window's column list in win_cols (forward variant indices, oldest first)
+    uint32_t col_off;    // first entry of this window's column list in win_cols (oldest column first)
+    uint32_t ref_off;    // index into ref_pool of the reference base at sso
+    uint32_t vbase;      // gene's first variant in the v_* arrays
     uint16_t ncols;
     uint8_t wlen;
     uint8_t ewl;         // exon_window_len passed to print_haplotypes as window_len
     uint8_t splice_pos;
     uint8_t splice_gap;
-    uint8_t flags;       // SF_* of the step
+    uint8_t flags;       // SF_* of the step | WSF_REVERSE
     uint8_t need_recs;   // WS_* : K3 writes a HapRec for EVERY haplotype of this window
+    uint32_t step;       // the Step this window belongs to
 };
 enum : uint8_t {
     WS_ALL_IDS = 1,      // indel / frameshift context: every haplotype can be emitted -> records + SHA-1 ids
     WS_CARRY = 2,        // the window's haplotypes are carried into a splice-side merge -> records
 };
-static_assert(sizeof(WinStatic) == 20, "WinStatic layout");
+constexpr uint8_t WSF_REVERSE = 128;  // transcript on the '-' strand (SF_* use bits 0..6)
+struct WinCol {          // one live variant column of a printing window
+    uint32_t f;          // gene-relative forward variant index
+    uint32_t pos;        // v_pos
+    uint32_t info;       // v_info
+};
+static_assert(sizeof(WinStatic) == 32, "WinStatic layout");
 
 struct WinDyn {          // K2 output per printing step
     uint32_t group_off;  // first Group
@@ -87,7 +97,7 @@ struct WinDyn {          // K2 output per printing step
     uint32_t nrows;      // ObservationMatrix::nrows() (depth column)
     uint32_t flags;      // WD_*
 };
-enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4 };
+enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4, WD_REC_OVERFLOW = 8 };
 
 struct Group {           // K2 output: one distinct (haplotype, frame.0, frame.1 != 0) key of one window, ascending
     uint64_t hap;
