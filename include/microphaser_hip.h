@@ -42,6 +42,16 @@ int mp_dataset_load(mp_ctx* ctx, const char* bam_path, const char* vcf_path, con
                     int unsupported_allele_warning_only, mp_dataset** out);
 /* Deterministic synthetic exome: the benchmark workload. */
 int mp_dataset_synth(mp_ctx* ctx, uint64_t seed, uint32_t n_transcripts, double depth, double var_spacing, mp_dataset** out);
+/* Same generator with the test-only knobs (short indels incl. frameshifts, multi-allelic sites, soft-masked
+ * reference stretches) that exercise the less common branches of print_haplotypes / phase_gene. */
+typedef struct mp_synth_config {
+    uint64_t seed;
+    uint32_t n_transcripts;
+    uint32_t read_len;           /* 0 = 101 */
+    double depth, var_spacing;
+    double indel_rate, multiallelic_rate, softmask_rate;
+} mp_synth_config;
+int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* cfg, mp_dataset** out);
 /* Write prefix.{bam,vcf,gtf,fa,fa.fai} so that a CLI run sees the same inputs. */
 int mp_dataset_write(mp_ctx* ctx, const mp_dataset* ds, const char* prefix);
 uint32_t mp_dataset_num_genes(const mp_dataset* ds);   /* protein-coding genes, GTF order */

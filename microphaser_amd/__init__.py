@@ -27,6 +27,12 @@ def build(verbose=False):
         raise RuntimeError("building libmicrophaser_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
 
 
+class SynthConfig(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("n_transcripts", ctypes.c_uint32), ("read_len", ctypes.c_uint32),
+                ("depth", ctypes.c_double), ("var_spacing", ctypes.c_double),
+                ("indel_rate", ctypes.c_double), ("multiallelic_rate", ctypes.c_double), ("softmask_rate", ctypes.c_double)]
+
+
 class RunStats(ctypes.Structure):
     _fields_ = [
         ("k1_ms", ctypes.c_double), ("k2_ms", ctypes.c_double), ("k3_ms", ctypes.c_double), ("k3b_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
@@ -62,6 +68,7 @@ def lib():
         "mp_last_error": (cp, [vp]),
         "mp_dataset_load": (i32, [vp, cp, cp, cp, cp, i32, pp]),
         "mp_dataset_synth": (i32, [vp, u64, u32, dbl, dbl, pp]),
+        "mp_dataset_synth_ex": (i32, [vp, ctypes.POINTER(SynthConfig), pp]),
         "mp_dataset_write": (i32, [vp, vp, cp]),
         "mp_dataset_num_genes": (u32, [vp]),
         "mp_dataset_num_reads": (u64, [vp]),
@@ -86,7 +93,7 @@ def lib():
 
 
 C_ABI_SYMBOLS = [
-    "mp_create", "mp_destroy", "mp_last_error", "mp_dataset_load", "mp_dataset_synth", "mp_dataset_write",
+    "mp_create", "mp_destroy", "mp_last_error", "mp_dataset_load", "mp_dataset_synth", "mp_dataset_synth_ex", "mp_dataset_write",
     "mp_dataset_num_genes", "mp_dataset_num_reads", "mp_dataset_free", "mp_batch_create", "mp_batch_run",
     "mp_batch_results", "mp_batch_free", "mp_phase_dataset", "mp_results_fasta", "mp_results_normal_fasta",
     "mp_results_tsv", "mp_results_windows", "mp_results_free",
@@ -130,9 +137,13 @@ class Context:
                                           int(unsupported_allele_warning_only), ctypes.byref(h)))
         return Dataset(self, h)
 
-    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4):
+    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0):
         h = ctypes.c_void_p()
-        self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))
+        if indel_rate or multiallelic_rate or softmask_rate:
+            cfg = SynthConfig(seed, n_transcripts, 0, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate)
+            self._check(lib().mp_dataset_synth_ex(self._h, ctypes.byref(cfg), ctypes.byref(h)))
+        else:
+            self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))
         return Dataset(self, h)
 
 

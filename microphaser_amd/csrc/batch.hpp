@@ -52,6 +52,7 @@ struct Batch {
     std::vector<uint8_t> str_pool;        // transcript ids
     std::vector<uint32_t> tx_order;       // launch order (longest first)
     // ---- sizing
+    uint32_t seq_cap = 48;                // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks
     uint32_t max_rows_bound = 0;          // upper bound on simultaneously live rows (+pending) of any transcript
     uint64_t n_main_windows = 0;          // main-ORF printing steps in the plan (speculative upper bound)

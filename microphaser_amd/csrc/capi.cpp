@@ -94,6 +94,23 @@ int mp_dataset_synth(mp_ctx* ctx, uint64_t seed, uint32_t n_transcripts, double 
     });
 }
 
+int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* c, mp_dataset** out) {
+    return guarded(ctx, [&] {
+        std::unique_ptr<mp_dataset> d(new mp_dataset());
+        SynthConfig cfg;
+        cfg.seed = c->seed;
+        cfg.n_transcripts = c->n_transcripts;
+        if (c->read_len) cfg.read_len = c->read_len;
+        cfg.depth = c->depth;
+        cfg.var_spacing = c->var_spacing;
+        cfg.indel_rate = c->indel_rate;
+        cfg.multiallelic_rate = c->multiallelic_rate;
+        cfg.softmask_rate = c->softmask_rate;
+        synth_generate(cfg, d->ds);
+        *out = d.release();
+    });
+}
+
 int mp_dataset_write(mp_ctx* ctx, const mp_dataset* ds, const char* prefix) {
     return guarded(ctx, [&] { dataset_write_files(ds->ds, prefix); });
 }
@@ -140,8 +157,8 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
             st->bytes_k2 = b.steps.size() * sizeof(Step) + b.r_pos.size() * (20 + 16ull * b.mask_words) +
                            b.wins.size() * sizeof(WinDyn) + t.n_groups * (sizeof(Group) + 4);
             st->bytes_k3 = t.n_groups * (sizeof(Group) + 4 + sizeof(GroupSum)) +
-                           b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols + t.n_recs * sizeof(HapRec);
-            st->bytes_k3b = t.n_recs * (sizeof(HapRec) / 2 + 8);
+                           b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols + t.n_recs * hap_rec_stride(b.seq_cap);
+            st->bytes_k3b = t.n_recs * (32 + b.seq_cap + 8);
             st->hbm_bytes = dev.hbm_bytes();
             st->rows_per_lane = uint32_t(t.rows_per_lane); st->mask_words = b.mask_words; st->attempts = t.attempts;
         }

@@ -199,7 +199,9 @@ struct ConsumerHooks {
         for (const Key& key : keys) {
             const GroupSum& gs = res.gsum[key.slot];
             if (!(gs.flags & GS_VALID)) throw Error("internal error: haplotype was not processed by the window-sequence kernel");
-            const HapRec* rec = (gs.flags & GS_HAS_REC) ? &res.recs[gs.rec] : nullptr;
+            const HapRecHdr* rec = (gs.flags & GS_HAS_REC) ? res.rec(gs.rec) : nullptr;
+            const uint8_t* rseq = rec ? res.rec_seq(gs.rec) : nullptr;
+            const uint8_t* rgerm = rec ? res.rec_germ(gs.rec) : nullptr;
             const bool indel = gs.flags & GS_INDEL, insertion = gs.flags & GS_INSERTION, stop_gain = gs.flags & GS_STOP;
             const bool differs = gs.flags & GS_DIFFERS, broke = gs.flags & GS_BROKE;
             if ((ws.need_recs & WS_ALL_IDS) && !rec) throw Error("internal error: missing haplotype record for an indel window");
@@ -244,13 +246,13 @@ struct ConsumerHooks {
                     return std::string(reinterpret_cast<const char*>(p) + a, e - a);
                 };
                 if (germ_len != 0) {
-                    if (splice_pos == 1) normal_peptide = sl(rec->germ, germ_len, splice_gap, germ_len);
-                    else if (splice_pos == 0) normal_peptide = sl(rec->germ, germ_len, 0, normal_window_len);
-                    else normal_peptide = sl(rec->germ, germ_len, 0, germ_len);
+                    if (splice_pos == 1) normal_peptide = sl(rgerm, germ_len, splice_gap, germ_len);
+                    else if (splice_pos == 0) normal_peptide = sl(rgerm, germ_len, 0, normal_window_len);
+                    else normal_peptide = sl(rgerm, germ_len, 0, germ_len);
                 }
-                if (splice_pos == 1) neopeptide = sl(rec->seq, seq_len, splice_gap, seq_len);
-                else if (splice_pos == 0) neopeptide = insertion ? sl(rec->seq, seq_len, 0, seq_len) : sl(rec->seq, seq_len, 0, this_window_len);
-                else neopeptide = sl(rec->seq, seq_len, 0, seq_len);
+                if (splice_pos == 1) neopeptide = sl(rseq, seq_len, splice_gap, seq_len);
+                else if (splice_pos == 0) neopeptide = insertion ? sl(rseq, seq_len, 0, seq_len) : sl(rseq, seq_len, 0, this_window_len);
+                else neopeptide = sl(rseq, seq_len, 0, seq_len);
             }
             bool remove_peptide = false;  // :702-718
             if (stop_gain && splice_pos != 2 && (wl == this_window_len || indel) && !is_first_exon_window &&
@@ -291,7 +293,7 @@ struct ConsumerHooks {
                     std::snprintf(idb, sizeof idb, "%015llx%c", (unsigned long long)rec->id60, strand[0]);
                     r.id = idb;
                 } else {
-                    r.id = haplotype_id(rec->seq, seq_len, transcript.id, offset, strand[0]);
+                    r.id = haplotype_id(rseq, seq_len, transcript.id, offset, strand[0]);
                 }
                 r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
                 r.offset = splice_pos == 0 ? offset + 1 : offset + 1 + splice_gap;
@@ -307,24 +309,24 @@ struct ConsumerHooks {
                 if (emit) {  // :839-875
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, r.id, rec->seq + splice_gap, seq_len - splice_gap);
+                        write_fasta(out.fasta, r.id, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
-                        write_fasta(out.fasta, r.id, rec->seq, this_window_len);
+                        write_fasta(out.fasta, r.id, rseq, this_window_len);
                     }
                     if (germ_len != 0) {
                         if (splice_pos == 1) {
                             if (splice_gap > germ_len) throw Error("reference would panic: slice index out of range");
-                            write_fasta(out.normal_fasta, r.id, rec->germ + splice_gap, germ_len - splice_gap);
+                            write_fasta(out.normal_fasta, r.id, rgerm + splice_gap, germ_len - splice_gap);
                         } else if (splice_pos == 0) {
                             if (this_window_len > germ_len) throw Error("reference would panic: slice index out of range");
-                            write_fasta(out.normal_fasta, r.id, rec->germ, this_window_len);
+                            write_fasta(out.normal_fasta, r.id, rgerm, this_window_len);
                         }
                     }
                     write_tsv_record(out, r);
                 }
                 // the carried-over record holds the UNSLICED sequences (:807-832)
-                r.normal_sequence.assign(reinterpret_cast<const char*>(rec->germ), germ_len);
-                r.mutant_sequence.assign(reinterpret_cast<const char*>(rec->seq), seq_len);
+                r.normal_sequence.assign(reinterpret_cast<const char*>(rgerm), germ_len);
+                r.mutant_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);
             }
             if (!remove_peptide || frame == 0) haplotypes_vec.push_back(std::move(hs));  // :835-837
         }

@@ -94,8 +94,11 @@ void DeviceContext::upload(const Batch& b) {
     d_.n_tx = uint32_t(b.tx.size());
     d_.n_wins = uint32_t(b.wins.size());
     d_.mask_words = b.mask_words;
+    d_.seq_cap = b.seq_cap;
+    d_.rec_stride = hap_rec_stride(b.seq_cap);
     // K1 outputs
     d_.r_varlo = static_cast<uint32_t*>(dalloc(size_t(d_.n_reads) * 4)); allocs_.push_back(d_.r_varlo);
+    d_.r_ncov = static_cast<uint32_t*>(dalloc(size_t(d_.n_reads) * 4)); allocs_.push_back(d_.r_ncov);
     d_.r_sup = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_sup);
     d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);
     d_.win_dyn = static_cast<WinDyn*>(dalloc(size_t(d_.n_wins) * sizeof(WinDyn))); allocs_.push_back(d_.win_dyn);
@@ -119,7 +122,7 @@ void DeviceContext::alloc_outputs() {
     d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
-    d_.recs = static_cast<HapRec*>(oalloc(rec_cap_ * sizeof(HapRec)));
+    d_.recs = static_cast<uint8_t*>(oalloc(rec_cap_ * d_.rec_stride));
     d_.group_cap = group_cap_;
     d_.rec_cap = rec_cap_;
 }
@@ -184,13 +187,15 @@ void DeviceContext::download(HostResults& r) {
     r.win_dyn.resize(d_.n_wins);
     r.groups.resize(last_slots_);
     r.gsum.resize(last_slots_);
-    r.recs.resize(last_recs_);
+    r.seq_cap = d_.seq_cap;
+    r.rec_stride = d_.rec_stride;
+    r.recs.resize(last_recs_ * d_.rec_stride);
     if (d_.n_wins) HIP_OK(hipMemcpyAsync(r.win_dyn.data(), d_.win_dyn, size_t(d_.n_wins) * sizeof(WinDyn), hipMemcpyDeviceToHost, stream_));
     if (last_slots_) {
         HIP_OK(hipMemcpyAsync(r.groups.data(), d_.groups, last_slots_ * sizeof(Group), hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipMemcpyAsync(r.gsum.data(), d_.gsum, last_slots_ * sizeof(GroupSum), hipMemcpyDeviceToHost, stream_));
     }
-    if (last_recs_) HIP_OK(hipMemcpyAsync(r.recs.data(), d_.recs, last_recs_ * sizeof(HapRec), hipMemcpyDeviceToHost, stream_));
+    if (last_recs_) HIP_OK(hipMemcpyAsync(r.recs.data(), d_.recs, last_recs_ * d_.rec_stride, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipStreamSynchronize(stream_));
 }
 

@@ -13,7 +13,11 @@ struct HostResults {         // device results copied back for the consumer
     std::vector<WinDyn> win_dyn;
     std::vector<Group> groups;
     std::vector<GroupSum> gsum;
-    std::vector<HapRec> recs;
+    std::vector<uint8_t> recs;   // n_recs records of rec_stride bytes (HapRecHdr + seq + germ)
+    uint32_t seq_cap = 48, rec_stride = 128;
+    const HapRecHdr* rec(uint64_t i) const { return reinterpret_cast<const HapRecHdr*>(recs.data() + i * rec_stride); }
+    const uint8_t* rec_seq(uint64_t i) const { return recs.data() + i * rec_stride + 32; }
+    const uint8_t* rec_germ(uint64_t i) const { return recs.data() + i * rec_stride + 32 + seq_cap; }
     uint64_t n_group_slots = 0, n_recs = 0;
 };
 

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     uint64_t sup[W], lq[W];
 #pragma unroll
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
+    uint32_t ncov = 0;  // variants actually evaluated (K2 must not read mask bits beyond them)
     for (uint32_t k = lo; k < nv && (k - lo) < 64u * W; k++) {
         uint32_t vpos = d.v_pos[vbase + k];
         // a variant can be a (stale) column of a window the read encloses without lying inside the read's
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
                 if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
         }
         uint32_t b = k - lo;
+        ncov = b + 1;
 #pragma unroll
         for (int w = 0; w < W; w++)
             if ((b >> 6) == uint32_t(w)) {
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             }
     }
     d.r_varlo[i] = lo;
+    d.r_ncov[i] = ncov;
 #pragma unroll
     for (int w = 0; w < W; w++) {
         d.r_sup[uint64_t(i) * W + w] = sup[w];
@@ -133,10 +136,10 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     __shared__ uint32_t colf[64];     // forward variant index (gene-relative) of each live column
     __shared__ uint32_t colinfo[64];  // v_info | start-loss bit 31
 
-    uint32_t fl[RPL], rs[RPL], re[RPL], rvl[RPL], rdup[RPL], ridx[RPL], fr0[RPL], pver[RPL];
+    uint32_t fl[RPL], rs[RPL], re[RPL], rvl[RPL], rcov[RPL], rdup[RPL], ridx[RPL], fr0[RPL], pver[RPL];
     uint64_t hap[RPL], msup[RPL], mlq[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) { fl[r] = ST_EMPTY; rs[r] = re[r] = rvl[r] = rdup[r] = ridx[r] = fr0[r] = pver[r] = 0; hap[r] = msup[r] = mlq[r] = 0; }
+    for (int r = 0; r < RPL; r++) { fl[r] = ST_EMPTY; rs[r] = re[r] = rvl[r] = rcov[r] = rdup[r] = ridx[r] = fr0[r] = pver[r] = 0; hap[r] = msup[r] = mlq[r] = 0; }
 
     uint32_t ncols = 0, head = 0;
     uint32_t colver = 1;  // bumped whenever the column set changes
@@ -147,14 +150,26 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     uint32_t sticky_err = 0;
 
     // support / low-quality bit of row slot r for forward variant index f
-    auto bits_of = [&](int r, uint32_t f, bool& s, bool& q) {
+    auto bits_of = [&](int r, uint32_t f, uint32_t info, bool& s, bool& q) {
         uint32_t b = f - rvl[r];
         s = false; q = false;
-        if (f < rvl[r] || b >= 64u * W) return;
-        if (W == 1) { s = (msup[r] >> b) & 1; q = (mlq[r] >> b) & 1; }
-        else {
-            uint64_t a = d.r_sup[uint64_t(ridx[r]) * W + (b >> 6)], c = d.r_lq[uint64_t(ridx[r]) * W + (b >> 6)];
-            s = (a >> (b & 63)) & 1; q = (c >> (b & 63)) & 1;
+        if (f >= rvl[r] && b < rcov[r]) {
+            if (W == 1) { s = (msup[r] >> b) & 1; q = (mlq[r] >> b) & 1; }
+            else {
+                uint64_t a = d.r_sup[uint64_t(ridx[r]) * W + (b >> 6)], c = d.r_lq[uint64_t(ridx[r]) * W + (b >> 6)];
+                s = (a >> (b & 63)) & 1; q = (c >> (b & 63)) & 1;
+            }
+            return;
+        }
+        // Outside what K1 evaluated (a stale column beyond the read, :1159): an SNV there is neither supported nor
+        // low-quality, but indel support is position-independent - any I / D op of that length (:113-137).
+        const uint32_t kind = info & VI_KIND_MASK;
+        if (kind != 0) {
+            const uint32_t want = kind == 1 ? 1u : 2u, vlen = d.v_len[vbase + f];
+            const uint32_t* cig = d.cigar_pool + d.r_cigoff[ridx[r]];
+            const uint32_t ncig = d.r_ncig[ridx[r]];
+            for (uint32_t c = 0; c < ncig; c++)
+                if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
         }
     };
     // Observation::update_haplotype for one variant (reference: microphasing.rs:157-197); hap already shifted
@@ -223,6 +238,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                             rs[r] = d.r_pos[gi];
                             re[r] = d.r_end[gi];
                             rvl[r] = d.r_varlo[gi];
+                            rcov[r] = d.r_ncov[gi];
                             rdup[r] = d.r_dup[gi];
                             if (W == 1) { msup[r] = d.r_sup[gi]; mlq[r] = d.r_lq[gi]; }
                             fl[r] = ST_PENDING;
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     for (int r = 0; r < RPL; r++)
                         if (att[r]) {
                             bool s, q;
-                            bits_of(r, f, s, q);
+                            bits_of(r, f, info, s, q);
                             hap[r] <<= 1;
                             update_row(r, s, q, info);
                         }
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 for (int r = 0; r < RPL; r++)
                     if ((fl[r] & ST_MASK) == ST_ROW) {
                         bool s, q;
-                        bits_of(r, f, s, q);
+                        bits_of(r, f, info, s, q);
                         hap[r] <<= 1;
                         update_row(r, s, q, info);
                     }
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     const uint32_t nneed = __popcll(nm);
                     if (nneed && rec_pos + nneed > rec_end) {
                         for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the chunk's unused tail
-                            if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q)[31] = 0;
+                            if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
                         unsigned long long base = 0;
                         if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)REC_CHUNK);
                         uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
         }
     }
     for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the last record chunk's unused tail
-        if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q)[31] = 0;
+        if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
     if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
@@ -496,8 +512,10 @@ __device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) |
 constexpr int K3_THREADS = 64;                             // one wave per workgroup: LDS granularity 10.5 KB -> 15 waves/CU
 constexpr int K3_REFCAP = 64;                              // staged reference bytes (window + alignment slack);
                                                            // re-used as the 16-word SHA-1 block buffer after the walk
-constexpr int K3_SLOT_BYTES = K3_REFCAP + 2 * SEQ_CAP;     // ref | seq | germ = 160
-constexpr int K3_SLOT_DW = K3_SLOT_BYTES / 4 + 1;          // 41 dwords: odd stride
+template <int CAP> struct K3Cfg {
+    static constexpr int SLOT_BYTES = K3_REFCAP + 2 * CAP;  // ref | seq | germ  (160 bytes at CAP = 48)
+    static constexpr int SLOT_DW = SLOT_BYTES / 4 + 1;      // odd dword stride (41 at CAP = 48)
+};
 
 struct ShaStream {
     uint32_t h0, h1, h2, h3, h4;
@@ -563,7 +581,9 @@ __device__ __forceinline__ bool stop_codon_at(const uint8_t* s, uint32_t c, bool
     return (a == 'T' && b == 'C' && e == 'A') || (a == 'C' && b == 'T' && e == 'A') || (a == 'T' && b == 'T' && e == 'A');
 }
 
+template <int SEQ_CAP>
 __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint64_t n_slots) {
+    constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t g = uint64_t(blockIdx.x) * K3_THREADS + tid;
@@ -708,21 +728,21 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     if (live) {
         const uint32_t slot_idx = d.g_rec[g];
         if (slot_idx != 0xFFFFFFFFu) {
-            uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + slot_idx);
+            uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
             if (need_rec) {
                 out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
                 out[2] = 0; out[3] = 0;
                 out[4] = seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24);
                 out[5] = nsom | (first_fs << 8) | (first_fs_j << 16);
+                out[6] = w;
+                out[7] = want_id ? 1u : 0u;
                 const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
-                for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[6 + k] = sq[k];
-                out[30] = w;
-                out[31] = want_id ? 1u : 0u;
+                for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
                 sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
                 recidx = slot_idx;
             } else {
-                out[31] = 0;
+                out[7] = 0;
             }
         } else if (need_rec) {
             atomicOr(d.err, WD_REC_OVERFLOW);  // K2's superset rule missed a haplotype (must not happen) or the record buffer is full
@@ -738,29 +758,31 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
 
 // K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
 // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
+template <int SEQ_CAP>
 __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t n_recs) {
     __shared__ uint32_t lds_blk[64 * 17];
     const uint64_t r = uint64_t(blockIdx.x) * 64 + threadIdx.x;
     if (r >= n_recs) return;
-    const uint32_t* rec = reinterpret_cast<const uint32_t*>(d.recs + r);
-    if (rec[31] == 0) return;
+    uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
+    if (rec[7] == 0) return;
     const uint32_t seq_len = rec[4] & 0xFF;
-    const WinStatic ws = d.wins[rec[30]];
+    const WinStatic ws = d.wins[rec[6]];
     const TxDev T = d.tx[ws.tx];
-    uint32_t sq[SEQ_CAP / 4];
-#pragma unroll
-    for (int k = 0; k < SEQ_CAP / 4; k++) sq[k] = rec[6 + k];
     ShaStream sh;
     sh.init(lds_blk + threadIdx.x * 17);
     sh.feed('[', 1);
+    for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP) && k0 < seq_len; k0 += 4) {
+        const uint32_t dw = rec[8 + (k0 >> 2)];
 #pragma unroll
-    for (int k = 0; k < SEQ_CAP; k++) {
-        if (uint32_t(k) < seq_len) {
-            uint32_t v = (sq[k >> 2] >> (8 * (k & 3))) & 0xFF;
-            if (k) sh.feed((uint32_t(',') << 8) | ' ', 2);
-            if (v >= 100) sh.feed((uint32_t('0' + v / 100) << 16) | (uint32_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10), 3);
-            else if (v >= 10) sh.feed((uint32_t('0' + v / 10) << 8) | ('0' + v % 10), 2);
-            else sh.feed('0' + v, 1);
+        for (int b = 0; b < 4; b++) {
+            const uint32_t k = k0 + b;
+            if (k < seq_len) {
+                uint32_t v = (dw >> (8 * b)) & 0xFF;
+                if (k) sh.feed((uint32_t(',') << 8) | ' ', 2);
+                if (v >= 100) sh.feed((uint32_t('0' + v / 100) << 16) | (uint32_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10), 3);
+                else if (v >= 10) sh.feed((uint32_t('0' + v / 10) << 8) | ('0' + v % 10), 2);
+                else sh.feed('0' + v, 1);
+            }
         }
     }
     sh.feed(']', 1);
@@ -768,9 +790,8 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
     sh.feed_dec(ws.sso);
     sh.finish();
     uint64_t id60 = (uint64_t(sh.h0) << 28) | (uint64_t(sh.h1) >> 4);
-    uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + r);
-    out[2] = uint32_t(id60);
-    out[3] = uint32_t(id60 >> 32);
+    rec[2] = uint32_t(id60);
+    rec[3] = uint32_t(id60 >> 32);
 }
 
 // ====================================================================== launchers
@@ -808,14 +829,24 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {
     if (n_group_slots == 0) return;
     dim3 grid(uint32_t((n_group_slots + K3_THREADS - 1) / K3_THREADS)), block(K3_THREADS);
-    hipLaunchKernelGGL(k3_window_seq, grid, block, 0, stream, d, n_group_slots);
+    switch (d.seq_cap) {
+        case 48: hipLaunchKernelGGL(k3_window_seq<48>, grid, block, 0, stream, d, n_group_slots); break;
+        case 112: hipLaunchKernelGGL(k3_window_seq<112>, grid, block, 0, stream, d, n_group_slots); break;
+        case 240: hipLaunchKernelGGL(k3_window_seq<240>, grid, block, 0, stream, d, n_group_slots); break;
+        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
     HIP_CHECK_LAUNCH();
 }
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream) {
     if (n_recs == 0) return;
     dim3 grid(uint32_t((n_recs + 63) / 64)), block(64);
-    hipLaunchKernelGGL(k3b_haplotype_ids, grid, block, 0, stream, d, n_recs);
+    switch (d.seq_cap) {
+        case 48: hipLaunchKernelGGL(k3b_haplotype_ids<48>, grid, block, 0, stream, d, n_recs); break;
+        case 112: hipLaunchKernelGGL(k3b_haplotype_ids<112>, grid, block, 0, stream, d, n_recs); break;
+        case 240: hipLaunchKernelGGL(k3b_haplotype_ids<240>, grid, block, 0, stream, d, n_recs); break;
+        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
     HIP_CHECK_LAUNCH();
 }
 

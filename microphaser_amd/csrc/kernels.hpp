@@ -29,6 +29,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     uint32_t n_reads, n_tx, n_wins, mask_words;
     // K1 output
     uint32_t* r_varlo;
+    uint32_t* r_ncov;             // number of variants (from r_varlo on) whose bits K1 evaluated
     uint64_t *r_sup, *r_lq;  // [read * mask_words + w]
     // K2 output
     WinDyn* win_dyn;
@@ -40,7 +41,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     uint32_t* err;                // sticky error word (WD_* bits)
     // K3 output
     GroupSum* gsum;
-    HapRec* recs;
+    uint8_t* recs;                // HapRecHdr + seq[seq_cap] + germ[seq_cap], rec_stride bytes apart
+    uint32_t seq_cap, rec_stride;
     uint32_t* tx_first_stop;      // per transcript: smallest window index with a main-ORF stop (0xFFFFFFFF none)
 };
 

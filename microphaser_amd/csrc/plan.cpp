@@ -29,6 +29,7 @@ struct PlannerHooks {
     bool have_prev_cand = false;
     size_t cur_step = 0;
     uint64_t max_live = 0;
+    uint64_t max_seq_len = 0;
     // windows whose haplotypes currently sit in prev_hap_vec / hap_vec (they feed the next splice-side merge)
     uint32_t last_print_win = 0xFFFFFFFFu, held_prev = 0xFFFFFFFFu, held_hap = 0xFFFFFFFFu;
 
@@ -73,20 +74,22 @@ struct PlannerHooks {
         w.splice_gap = uint8_t(sg.splice_gap);
         w.flags = uint8_t((st.flags & 0x7F) | (is_fwd ? 0 : WSF_REVERSE));
         b.wins.push_back(w);
-        // upper bound of the sequence lengths print_haplotypes can build for this window
+        // upper bound of the sequence lengths print_haplotypes can build for this window: the window itself, plus the
+        // inserted bases, plus the reference bases a somatic deletion restores in the germline sequence (:547-577)
         uint64_t max_len = st.wlen;
         bool non_snv = false;
         for (uint32_t c : cols) {
             const Variant& v = vars[c];
-            if (v.kind == VK_INS) max_len += v.seq.size();
-            if (v.kind == VK_DEL) max_len += v.len + 1;
+            if (v.kind == VK_INS) max_len += v.len;
+            if (v.kind == VK_DEL) max_len += v.len;
             if (v.kind != VK_SNV) non_snv = true;
         }
         b.wins.back().need_recs = (non_snv || fs_seen) ? WS_ALL_IDS : 0;
         if (b.wins.back().need_recs) b.steps[cur_step].flags |= SF_NEED_RECS;
-        if (max_len > SEQ_CAP)
+        if (max_len > SEQ_CAPS[2])
             throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
-                        " nt; this build supports at most " + std::to_string(SEQ_CAP) + " (long indel in window)");
+                        " nt; this build supports at most " + std::to_string(SEQ_CAPS[2]) + " (very long indel in a window)");
+        max_seq_len = std::max<uint64_t>(max_seq_len, max_len);
     }
 
     void on_step(const ExonGeom& eg, const StepGeom& sg, const std::vector<size_t>& new_cols) {
@@ -318,6 +321,7 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
             walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks);
             td.n_steps = uint32_t(b.steps.size()) - td.step_off;
             b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
+            while (b.seq_cap < hooks.max_seq_len) b.seq_cap = b.seq_cap == SEQ_CAPS[0] ? SEQ_CAPS[1] : SEQ_CAPS[2];
             b.tx.push_back(td);
             gh.tx_src.push_back(uint32_t(ti));
         }

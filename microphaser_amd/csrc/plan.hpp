@@ -12,7 +12,7 @@
 //               variants: the reference can leave stale columns behind, microphasing.rs:1159)
 //   K1 output : r_varlo, r_sup[W], r_lq[W]            (read x variant predicate bits)
 //   K2 output : WinDyn per printing step, Group per distinct (haplotype, frame) key
-//   K3 output : GroupSum per group, HapRec per group that can be emitted / merged
+//   K3 output : GroupSum per group, HapRec (header + seq + germ) per group that can be emitted / merged
 #pragma once
 #include <cstdint>
 
@@ -121,16 +121,18 @@ struct GroupSum {        // K3 output per group
     uint32_t rec;        // HapRec index if GS_HAS_REC
 };
 
-constexpr int SEQ_CAP = 48;
-struct HapRec {          // K3 output for groups whose sequence the host needs
+// K3 output for groups whose sequence the host needs: a 32-byte header followed by seq[cap] and germ[cap], where
+// cap (the batch's sequence capacity) is 48, 112 or 240 bytes - the smallest that holds the longest sequence any
+// window of the batch can build (window + inserted bases + bases restored by somatic deletions).
+struct HapRecHdr {
     uint64_t prof_set;   // bit c set <=> variant_profile[c] != 0 (c < prof_len)
     uint64_t id60;       // first 60 bits of the SHA-1 (15 hex digits), big-endian in the low 60 bits
     uint8_t seq_len, germ_len, prof_len, nvar, nsom, first_fs, first_fs_j, pad;
-    uint8_t seq[SEQ_CAP];
-    uint8_t germ[SEQ_CAP];
     uint32_t win;        // window index (K3b hashes transcript id + offset of that window)
     uint32_t want_id;    // 1: K3b computes id60
 };
-static_assert(sizeof(HapRec) == 128, "HapRec layout");
+static_assert(sizeof(HapRecHdr) == 32, "HapRecHdr layout");
+constexpr uint32_t SEQ_CAPS[3] = {48, 112, 240};
+inline uint32_t hap_rec_stride(uint32_t cap) { return 32u + 2u * cap; }
 
 }  // namespace mp

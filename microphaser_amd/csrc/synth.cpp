@@ -55,7 +55,13 @@ inline bool is_stop(char a, char b, char c) { return a == 'T' && ((b == 'A' && (
 const char* AA3[20] = {"Ala", "Arg", "Asn", "Asp", "Cys", "Gln", "Glu", "Gly", "His", "Ile",
                        "Leu", "Lys", "Met", "Phe", "Pro", "Ser", "Thr", "Trp", "Tyr", "Val"};
 
-struct SynVar { uint64_t pos; char alt; bool somatic; int hap; /* 0 = A, 1 = B, 2 = both */ };
+struct SynVar {
+    uint64_t pos; char alt; bool somatic; int hap; /* 0 = A, 1 = B, 2 = both */
+    int kind = 0;          // 0 SNV, 1 insertion, 2 deletion
+    uint32_t len = 0;      // indel length
+    std::string ins;       // inserted bases (without the anchor)
+    char alt2 = 0;         // second ALT of a multi-allelic SNV site (never carried by a read)
+};
 
 }  // namespace
 
@@ -71,11 +77,10 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
     ReadStore& rs = ds.bam.reads;
     ds.bam.ref_names = ds.contig_names;
     uint64_t read_serial = 0;
-    struct PendingRead { uint64_t pos; uint64_t off; uint8_t mapq; uint64_t serial; };  // off: index into the staging pools
+    struct PendingRead { uint64_t pos; uint64_t off; uint8_t mapq; uint64_t serial; std::vector<uint32_t> cigar; };  // off: index into the staging pools
     std::vector<uint8_t> seq4((L + 1) / 2), qual(L);
     std::vector<uint8_t> stage_seq, stage_qual;   // per-gene staging (genes are laid out in ascending coordinates,
     std::vector<PendingRead> creads;              //  so sorting the reads of one gene keeps the BAM coordinate-sorted)
-    const uint32_t cig = (L << 4) | C_M;
     {
         // rough totals, to avoid re-growing multi-GB pools
         double reads_est = double(cfg.n_transcripts) * cfg.depth * 2750.0 / double(L) * 1.15;
@@ -169,26 +174,58 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
                 consumed += ex.second - ex.first;
             }
             line("three_prime_utr", utr_lo, utr_hi, ".", attr_t);
-            // ---- variants: SNV sites inside the CDS
+            // ---- soft-masked stretch (test-only): case changes only
+            if (cfg.softmask_rate > 0 && rng.uni() < cfg.softmask_rate) {
+                const auto& ex = gexons[rng.below(gexons.size())];
+                uint64_t a = ex.first + rng.below(ex.second - ex.first), e = std::min<uint64_t>(gene_end, a + 40 + rng.below(260));
+                for (uint64_t q = a; q < e; q++) contig[q] = char(contig[q] | 0x20);
+            }
+            // ---- variants: SNV sites inside the CDS (+ optional short indels / second ALT alleles)
             std::vector<SynVar> vars;
             const double p_site = 1.0 / cfg.var_spacing;
-            for (auto& ex : gexons)
+            for (auto& ex : gexons) {
+                uint64_t blocked_until = 0;  // positions covered by a deletion carry no further variant
                 for (uint64_t p = ex.first; p < ex.second; p++) {
                     if (rng.uni() >= p_site) continue;
+                    if (p < blocked_until) continue;
                     SynVar v;
                     v.pos = p;
-                    do { v.alt = BASES[rng.below(4)]; } while (v.alt == contig[p]);
+                    const char refb = char(contig[p] & ~0x20);
+                    do { v.alt = BASES[rng.below(4)]; } while (v.alt == refb);
                     v.somatic = rng.uni() < 0.2;
                     if (v.somatic) v.hap = int(rng.below(2));
                     else v.hap = rng.uni() < 0.1 ? 2 : int(rng.below(2));
+                    if (cfg.indel_rate > 0 && rng.uni() < cfg.indel_rate && p + 8 < ex.second) {
+                        static const uint32_t lens[6] = {1, 2, 3, 3, 4, 6};
+                        v.len = lens[rng.below(6)];
+                        if (rng.uni() < 0.5) {
+                            v.kind = 1;
+                            for (uint32_t k = 0; k < v.len; k++) v.ins.push_back(BASES[rng.below(4)]);
+                        } else {
+                            v.kind = 2;
+                            blocked_until = p + v.len + 1;
+                        }
+                    } else if (cfg.multiallelic_rate > 0 && rng.uni() < cfg.multiallelic_rate) {
+                        do { v.alt2 = BASES[rng.below(4)]; } while (v.alt2 == refb || v.alt2 == v.alt);
+                    }
                     vars.push_back(v);
                 }
+            }
             for (const SynVar& v : vars) {
                 VcfRecord r;
                 r.chrom = chrom;
                 r.pos = v.pos;
-                r.ref = std::string(1, contig[v.pos]);
-                r.alts = {std::string(1, v.alt)};
+                if (v.kind == 0) {
+                    r.ref = std::string(1, contig[v.pos]);
+                    r.alts = {std::string(1, v.alt)};
+                    if (v.alt2) r.alts.push_back(std::string(1, v.alt2));
+                } else if (v.kind == 1) {
+                    r.ref = std::string(1, contig[v.pos]);
+                    r.alts = {std::string(1, contig[v.pos]) + v.ins};
+                } else {
+                    r.ref = contig.substr(v.pos, v.len + 1);
+                    r.alts = {std::string(1, contig[v.pos])};
+                }
                 r.somatic = v.somatic;
                 uint32_t aa = uint32_t((v.pos * 2654435761ull) >> 7);
                 char ann[160];
@@ -211,19 +248,39 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
                     pr.mapq = rng.uni() < 0.01 ? 0 : 60;
                     pr.serial = read_serial++;
                     std::fill(seq4.begin(), seq4.end(), 0);
-                    // variants overlapping this read
+                    // walk the reference from pr.pos, applying the variants this read's haplotype carries
                     auto it = std::lower_bound(vars.begin(), vars.end(), pr.pos, [](const SynVar& v, uint64_t p) { return v.pos < p; });
-                    for (uint32_t q = 0; q < L; q++) {
-                        uint64_t p = pr.pos + q;
-                        char bch = contig[p];
-                        while (it != vars.end() && it->pos < p) ++it;
-                        if (it != vars.end() && it->pos == p) {
-                            bool carries = it->somatic ? (it->hap == hap && tumor) : (it->hap == 2 || it->hap == hap);
-                            if (carries) bch = it->alt;
-                        }
+                    pr.cigar.clear();
+                    auto add_op = [&](uint32_t op, uint32_t l) {
+                        if (!l) return;
+                        if (!pr.cigar.empty() && (pr.cigar.back() & 0xF) == op) pr.cigar.back() += l << 4;
+                        else pr.cigar.push_back((l << 4) | op);
+                    };
+                    uint32_t q = 0;
+                    uint64_t p = pr.pos;
+                    auto put = [&](char bch) {
                         if (rng.uni() < 0.001) { char e; do { e = BASES[rng.below(4)]; } while (e == bch); bch = e; }
                         seq4[q >> 1] |= uint8_t(code4(bch) << ((q & 1) ? 0 : 4));
                         qual[q] = rng.uni() < 0.02 ? 5 : 35;
+                        q++;
+                    };
+                    while (q < L) {
+                        char bch = char(contig[p] & ~0x20);
+                        while (it != vars.end() && it->pos < p) ++it;
+                        const SynVar* v = (it != vars.end() && it->pos == p) ? &*it : nullptr;
+                        bool carries = v && (v->somatic ? (v->hap == hap && tumor) : (v->hap == 2 || v->hap == hap));
+                        if (carries && v->kind == 0) bch = v->alt;
+                        put(bch);
+                        add_op(C_M, 1);
+                        p++;
+                        if (carries && v->kind == 1 && q < L) {
+                            uint32_t n = std::min<uint32_t>(v->len, L - q);
+                            for (uint32_t k = 0; k < n; k++) put(v->ins[k]);
+                            add_op(C_I, n);
+                        } else if (carries && v->kind == 2 && q < L) {
+                            add_op(C_D, v->len);
+                            p += v->len;
+                        }
                     }
                     pr.off = creads.size();
                     stage_seq.insert(stage_seq.end(), seq4.begin(), seq4.end());
@@ -235,7 +292,7 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
             for (const PendingRead& pr : creads) {
                 char name[32];
                 std::snprintf(name, sizeof name, "r%llu", (unsigned long long)pr.serial);
-                rs.add(int32_t(c), int64_t(pr.pos), pr.mapq, 0, &cig, 1, stage_seq.data() + pr.off * seq4.size(), L,
+                rs.add(int32_t(c), int64_t(pr.pos), pr.mapq, 0, pr.cigar.data(), uint32_t(pr.cigar.size()), stage_seq.data() + pr.off * seq4.size(), L,
                        stage_qual.data() + pr.off * L, name);
             }
             creads.clear();

@@ -15,6 +15,9 @@ struct SynthConfig {
     double depth = 30.0;
     double var_spacing = 5.4;  // mean nt between SNV sites inside the CDS
     uint32_t read_len = 101;
+    // test-only extensions (all 0 in the benchmark workloads): fraction of variant sites that are short indels,
+    // fraction of SNV sites with a second ALT allele, fraction of genes with a lower-case (soft-masked) stretch
+    double indel_rate = 0.0, multiallelic_rate = 0.0, softmask_rate = 0.0;
 };
 
 struct Dataset {

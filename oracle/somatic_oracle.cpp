@@ -599,7 +599,7 @@ void phase_gene(const GeneInput& gi, const ReadStore& rs, uint64_t window_len, S
                     uint64_t lo, hi = splice_side_offset + 1;
                     bool first_of_exon = is_fwd ? offset == exon.start + current_exon_offset : true;
                     if (!is_fwd || first_of_exon) {
-                        if (splice_side_offset < max_read_len - exon_window_len) ref_panic("attempt to subtract with overflow");
+                        if (splice_side_offset < max_read_len - exon_window_len) ref_panic("attempt to subtract with overflow (#1)");
                         lo = splice_side_offset - (max_read_len - exon_window_len);
                     } else {
                         lo = splice_side_offset;
@@ -628,7 +628,7 @@ void phase_gene(const GeneInput& gi, const ReadStore& rs, uint64_t window_len, S
                                 for (const Variant* v : it->second) all.push_back(v);
                             }
                         }
-                        if (added_vars > nvars) ref_panic("attempt to subtract with overflow");
+                        if (added_vars > nvars) ref_panic("attempt to subtract with overflow (#2)");
                         for (size_t k = nvars - added_vars; k < all.size(); k++) variants.push_back(all[k]);
                     }
                     for (const Variant* variant : variants) {  // :1299-1342
@@ -774,13 +774,13 @@ void phase_gene(const GeneInput& gi, const ReadStore& rs, uint64_t window_len, S
                                             if (is_fwd) splice_offset = 0; else end_offset = 0;
                                         }
                                         for (;;) {  // :1743
-                                            if (end_offset > new_mt.size()) ref_panic("attempt to subtract with overflow");
+                                            if (end_offset > new_mt.size()) ref_panic("attempt to subtract with overflow (#3)");
                                             if (!(splice_offset + window_len <= uint64_t(new_mt.size() - end_offset))) break;
                                             std::string out_wt_seq;
                                             if (splice_offset + window_len <= uint64_t(new_wt.size())) {
                                                 if (is_fwd) out_wt_seq = new_wt.substr(size_t(splice_offset), size_t(window_len));
                                                 else {
-                                                    if (new_wt.size() < end_offset + window_len) ref_panic("attempt to subtract with overflow");
+                                                    if (new_wt.size() < end_offset + window_len) ref_panic("attempt to subtract with overflow (#4)");
                                                     out_wt_seq = new_wt.substr(new_wt.size() - end_offset - size_t(window_len), size_t(window_len));
                                                 }
                                             }

@@ -65,3 +65,45 @@ def test_gpu_gene_sharding_is_order_preserving(ctx, tmp_path):
     assert b"".join(p.fasta for p in parts) == whole.fasta
     assert tsv == whole.tsv
     assert sum(p.windows for p in parts) == whole.windows
+
+
+def oracle_synth_ex(tmp, seed, n, indel, multi, soft, depth=30.0, spacing=5.4):
+    prefix = os.path.join(tmp, "oracle_ex_%d_%d" % (seed, n))
+    r = subprocess.run([ORACLE_CLI, "synth", "--seed", str(seed), "--transcripts", str(n), "--depth", str(depth), "--spacing", str(spacing),
+                        "--indel-rate", str(indel), "--multiallelic-rate", str(multi), "--softmask-rate", str(soft),
+                        "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    st = json.loads(r.stdout)
+    return {e: open(prefix + "." + e, "rb").read() for e in ("fa", "normal.fa", "tsv")}, st
+
+
+@pytest.mark.parametrize("seed,n,indel,multi,soft", [(17, 60, 0.05, 0.0, 0.0), (23, 50, 0.0, 0.15, 0.0), (29, 50, 0.0, 0.0, 0.5),
+                                                       (17, 60, 0.08, 0.05, 0.2), (57, 40, 0.2, 0.1, 0.3)])
+def test_gpu_matches_oracle_with_indels_multiallelic_and_softmasked_reference(ctx, tmp_path, seed, n, indel, multi, soft):
+    """Short indels (incl. frameshifts -> shifted ORFs, frame > 0 rows), multi-allelic sites (j-stuck cursor) and lower-case
+    reference stretches. Genes on which the reference itself would panic (slice / subtraction overflow in the splice merge
+    of indel haplotypes) are dropped by the oracle harness; the engine must fail on exactly those genes too."""
+    import microphaser_amd as m
+    from microphaser_amd.shard import merge_streams
+    exp, st = oracle_synth_ex(str(tmp_path), seed, n, indel, multi, soft)
+    ds = ctx.synth(seed, n, indel_rate=indel, multiallelic_rate=multi, softmask_rate=soft)
+    skipped = st["skipped"]
+    parts, windows, lo = [], 0, 0
+    for g in skipped + [ds.num_genes]:
+        if g > lo:
+            b = ds.batch(gene_lo=lo, gene_hi=g)
+            b.run()
+            r = b.results()
+            parts.append(dict(fasta=r.fasta, normal_fasta=r.normal_fasta, tsv=r.tsv))
+            windows += r.windows
+        if g < ds.num_genes:
+            with pytest.raises(m.MicrophaserError):
+                b = ds.batch(gene_lo=g, gene_hi=g + 1)
+                b.run()
+                b.results()
+        lo = g + 1
+    got = merge_streams(parts)
+    assert windows == st["windows"]
+    assert got["fasta"] == exp["fa"]
+    assert got["normal_fasta"] == exp["normal.fa"]
+    assert got["tsv"] == exp["tsv"]
+    assert exp["tsv"].count(b"\n") > 100
