@@ -93,6 +93,19 @@ const char* mp_results_tsv(const mp_results* r, size_t* len);           /* --tsv
 uint64_t mp_results_windows(const mp_results* r);  /* main-ORF print_haplotypes calls actually made */
 void mp_results_free(mp_results* r);
 
+/* `microphaser build_reference` (reference: peptides::build, src/peptides.rs:148-186 <- run_build, src/main.rs:146-169):
+ * translate every 3-nt-step window of every record of a nucleotide FASTA (reverse-complemented when the id does not
+ * end in 'F', stop codons -> 'X') and build the set of distinct peptides. Translation and de-duplication run on the
+ * GPU. peptide_len <= 12. */
+typedef struct mp_peptides mp_peptides;
+int mp_build_reference(mp_ctx* ctx, const char* fasta_path, uint32_t peptide_len, mp_peptides** out);
+const char* mp_peptides_fasta(const mp_peptides* p, size_t* len);     /* stdout of build_reference            */
+const char* mp_peptides_binary(const mp_peptides* p, size_t* len);    /* --output: bincode HashSet<Vec<u8>>   */
+const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n);    /* sorted distinct keys (5 bits/residue): the unit
+                                                                         exchanged in the multi-GPU peptidome union */
+uint64_t mp_peptides_count(const mp_peptides* p);                     /* translated windows                   */
+void mp_peptides_free(mp_peptides* p);
+
 #ifdef __cplusplus
 }
 #endif

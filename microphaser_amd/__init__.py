@@ -83,6 +83,12 @@ def lib():
         "mp_results_tsv": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_results_windows": (u64, [vp]),
         "mp_results_free": (None, [vp]),
+        "mp_build_reference": (i32, [vp, cp, u32, pp]),
+        "mp_peptides_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_peptides_binary": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_peptides_keys": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_peptides_count": (u64, [vp]),
+        "mp_peptides_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -97,6 +103,7 @@ C_ABI_SYMBOLS = [
     "mp_dataset_num_genes", "mp_dataset_num_reads", "mp_dataset_free", "mp_batch_create", "mp_batch_run",
     "mp_batch_results", "mp_batch_free", "mp_phase_dataset", "mp_results_fasta", "mp_results_normal_fasta",
     "mp_results_tsv", "mp_results_windows", "mp_results_free",
+    "mp_build_reference", "mp_peptides_fasta", "mp_peptides_binary", "mp_peptides_keys", "mp_peptides_count", "mp_peptides_free",
 ]
 
 
@@ -137,6 +144,12 @@ class Context:
                                           int(unsupported_allele_warning_only), ctypes.byref(h)))
         return Dataset(self, h)
 
+    def build_reference(self, fasta_path, peptide_len=9):
+        """`microphaser build_reference`: translation + peptide de-duplication on the GPU."""
+        h = ctypes.c_void_p()
+        self._check(lib().mp_build_reference(self._h, fasta_path.encode(), peptide_len, ctypes.byref(h)))
+        return Peptides(h)
+
     def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0):
         h = ctypes.c_void_p()
         if indel_rate or multiallelic_rate or softmask_rate:
@@ -145,6 +158,52 @@ class Context:
         else:
             self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))
         return Dataset(self, h)
+
+
+def _bytes_at(p, n):
+    return bytes((ctypes.c_char * n).from_address(p)) if n else b""
+
+
+class Peptides:
+    """Result of `build_reference`: translated FASTA, bincode peptide set, and the sorted distinct u64 keys."""
+
+    def __init__(self, h):
+        L = lib()
+        n = ctypes.c_size_t()
+        p = L.mp_peptides_fasta(h, ctypes.byref(n))
+        self.fasta = _bytes_at(p, n.value)
+        p = L.mp_peptides_binary(h, ctypes.byref(n))
+        self.binary = _bytes_at(p, n.value)
+        p = L.mp_peptides_keys(h, ctypes.byref(n))
+        self.keys = list((ctypes.c_uint64 * n.value).from_address(p)) if n.value else []
+        self.count = L.mp_peptides_count(h)
+        L.mp_peptides_free(h)
+
+
+def key_to_peptide(key, length):
+    return "".join(chr(65 + ((key >> (5 * (length - 1 - j))) & 31)) for j in range(length))
+
+
+def keys_to_bincode(keys, length):
+    """bincode v1 HashSet<Vec<u8>> (reference: src/peptides.rs:183): u64 count, then u64 length + bytes per peptide."""
+    import struct
+    out = [struct.pack("<Q", len(keys))]
+    for k in keys:
+        out.append(struct.pack("<Q", length))
+        out.append(key_to_peptide(k, length).encode())
+    return b"".join(out)
+
+
+def decode_bincode_set(data):
+    import struct
+    n = struct.unpack_from("<Q", data, 0)[0]
+    off, out = 8, set()
+    for _ in range(n):
+        l = struct.unpack_from("<Q", data, off)[0]
+        out.add(data[off + 8: off + 8 + l])
+        off += 8 + l
+    assert off == len(data)
+    return out
 
 
 class Dataset:

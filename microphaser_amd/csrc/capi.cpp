@@ -4,10 +4,12 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <sstream>
 
 #include "batch.hpp"
 #include "consume.hpp"
 #include "device.hpp"
+#include "pep.hpp"
 #include "synth.hpp"
 
 using namespace mp;
@@ -27,6 +29,10 @@ struct mp_batch {
 };
 struct mp_results {
     SomaticOutput out;
+};
+struct mp_peptides {
+    PeptideResult res;
+    std::string bin;
 };
 
 namespace {
@@ -193,5 +199,24 @@ const char* mp_results_normal_fasta(const mp_results* r, size_t* len) { if (len)
 const char* mp_results_tsv(const mp_results* r, size_t* len) { if (len) *len = r->out.tsv.size(); return r->out.tsv.data(); }
 uint64_t mp_results_windows(const mp_results* r) { return r->out.n_windows; }
 void mp_results_free(mp_results* r) { delete r; }
+
+int mp_build_reference(mp_ctx* ctx, const char* fasta_path, uint32_t peptide_len, mp_peptides** out) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        std::ifstream in(fasta_path);
+        if (!in) throw Error(std::string("cannot open ") + fasta_path);
+        std::stringstream ss;
+        ss << in.rdbuf();
+        std::unique_ptr<mp_peptides> p(new mp_peptides());
+        build_reference_device(dev.device(), ss.str(), peptide_len, p->res);
+        p->bin = p->res.binary();
+        *out = p.release();
+    });
+}
+const char* mp_peptides_fasta(const mp_peptides* p, size_t* len) { if (len) *len = p->res.fasta.size(); return p->res.fasta.data(); }
+const char* mp_peptides_binary(const mp_peptides* p, size_t* len) { if (len) *len = p->bin.size(); return p->bin.data(); }
+const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n) { if (n) *n = p->res.keys.size(); return p->res.keys.data(); }
+uint64_t mp_peptides_count(const mp_peptides* p) { return p->res.n_peptides; }
+void mp_peptides_free(mp_peptides* p) { delete p; }
 
 }  // extern "C"

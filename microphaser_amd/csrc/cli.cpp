@@ -29,8 +29,42 @@ int main(int argc, char** argv) {
         return 1;
     }
     std::string sub = argv[1];
+    if (sub == "build_reference") {
+        // microphaser build_reference --reference peptides.fasta -l 9 --output peptides.bin > translated.fasta
+        // (reference: src/build_ref_cli.yaml:10-31, src/main.rs:146-169)
+        std::string ref, outp;
+        unsigned peptide_len = 9;
+        int device = 0;
+        for (int i = 2; i < argc; i++) {
+            std::string a = argv[i];
+            auto val = [&]() -> const char* {
+                if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(1); }
+                return argv[++i];
+            };
+            if (a == "--reference" || a == "-r") ref = val();
+            else if (a == "--output" || a == "-o") outp = val();
+            else if (a == "--peptide-length" || a == "-l") peptide_len = unsigned(std::atoi(val()));
+            else if (a.rfind("-l", 0) == 0 && a.size() > 2) peptide_len = unsigned(std::atoi(a.c_str() + 2));
+            else if (a == "--device") device = std::atoi(val());
+            else if (a == "-v" || a == "--verbose") {}
+            else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
+        }
+        if (ref.empty() || outp.empty()) { std::fprintf(stderr, "--reference and --output are required\n"); return 1; }
+        mp_ctx* ctx = nullptr;
+        if (mp_create(device, &ctx) != 0) { int rc = fail(ctx, "mp_create"); mp_destroy(ctx); return rc; }
+        mp_peptides* pep = nullptr;
+        if (mp_build_reference(ctx, ref.c_str(), peptide_len, &pep) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
+        size_t n = 0;
+        const char* p = mp_peptides_fasta(pep, &n);
+        std::fwrite(p, 1, n, stdout);
+        p = mp_peptides_binary(pep, &n);
+        if (!write_file(outp, p, n)) { std::fprintf(stderr, "cannot write %s\n", outp.c_str()); return 1; }
+        mp_peptides_free(pep);
+        mp_destroy(ctx);
+        return 0;
+    }
     if (sub != "somatic") {
-        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic` is available\n", sub.c_str());
+        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic` and `build_reference` are available\n", sub.c_str());
         return 1;
     }
     std::string bam, vcf, ref, tsv = "info.tsv", normal = "normal.fasta";

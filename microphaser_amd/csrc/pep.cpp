@@ -1,0 +1,118 @@
+#include "pep.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <sstream>
+
+#include "kernels_pep.hpp"
+
+namespace mp {
+
+[[noreturn]] void throw_hip(hipError_t e, const char* file, int line);
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__); } while (0)
+
+std::string peptide_from_key(uint64_t key, uint32_t L) {
+    std::string s(L, 'A');
+    for (uint32_t j = 0; j < L; j++) s[L - 1 - j] = char('A' + ((key >> (5 * j)) & 31));
+    return s;
+}
+uint64_t peptide_to_key(const std::string& pep) {
+    uint64_t k = 0;
+    for (char c : pep) k = (k << 5) | uint64_t((c - 'A') & 31);
+    return k;
+}
+
+std::string PeptideResult::binary() const {
+    std::string b;
+    auto u64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) b.push_back(char(v >> (8 * i))); };
+    u64(keys.size());
+    for (uint64_t k : keys) { u64(peptide_len); b += peptide_from_key(k, peptide_len); }
+    return b;
+}
+
+void build_reference_device(int device, const std::string& fasta_text, uint32_t L, PeptideResult& out) {
+    if (L == 0 || L > 12) throw Error("peptide length must be 1..12 for the device peptidome (5-bit residue keys in a u64)");
+    out = PeptideResult();
+    out.peptide_len = L;
+    // parse records (bio::io::fasta::Reader), lay out the windows: i = 0, 3, ... while i + 3L <= len  (:165-174)
+    std::vector<uint8_t> nt;
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> rev;
+    std::vector<std::pair<std::string, uint64_t>> recs;  // (id, number of windows)
+    {
+        std::istringstream in(fasta_text);
+        std::string line, id, seq;
+        bool have = false;
+        auto flush = [&]() {
+            if (!have) return;
+            uint8_t r = (!id.empty() && id.back() == 'F') ? 0 : 1;  // :161-164
+            uint64_t base = nt.size(), nwin = 0;
+            nt.insert(nt.end(), seq.begin(), seq.end());
+            for (uint64_t i = 0; i + 3ull * L <= seq.size(); i += 3) { off.push_back(base + i); rev.push_back(r); nwin++; }
+            recs.emplace_back(id, nwin);
+        };
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty() && line[0] == '>') {
+                flush();
+                size_t sp = line.find_first_of(" \t");
+                id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+                seq.clear();
+                have = true;
+            } else {
+                seq += line;
+            }
+        }
+        flush();
+    }
+    const uint64_t n = off.size();
+    out.n_peptides = n;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw Error("no HIP device available: peptide translation runs on the GPU, there is no CPU fallback");
+    HIP_OK(hipSetDevice(device));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    hipEvent_t e0, e1, e2;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
+    uint8_t *d_nt = nullptr, *d_rev = nullptr, *d_aa = nullptr;
+    uint64_t *d_off = nullptr, *d_keys = nullptr, *d_tmp = nullptr, *d_out = nullptr;
+    uint32_t* d_err = nullptr;
+    std::vector<uint8_t> aa(n * L);
+    if (n) {
+        HIP_OK(hipMalloc(&d_nt, nt.size() + 64)); HIP_OK(hipMalloc(&d_rev, n)); HIP_OK(hipMalloc(&d_aa, n * L));
+        HIP_OK(hipMalloc(&d_off, n * 8)); HIP_OK(hipMalloc(&d_keys, n * 8)); HIP_OK(hipMalloc(&d_tmp, n * 8)); HIP_OK(hipMalloc(&d_out, n * 8));
+        HIP_OK(hipMalloc(&d_err, 4));
+        HIP_OK(hipMemcpyAsync(d_nt, nt.data(), nt.size(), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(d_rev, rev.data(), n, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemsetAsync(d_err, 0, 4, stream));
+        HIP_OK(hipEventRecord(e0, stream));
+        device_translate(d_nt, d_off, d_rev, n, L, d_aa, d_keys, d_err, stream);
+        HIP_OK(hipEventRecord(e1, stream));
+        uint64_t nu = device_sort_unique(d_keys, d_tmp, d_out, n, 5 * L, stream);
+        HIP_OK(hipEventRecord(e2, stream));
+        uint32_t err = 0;
+        out.keys.resize(nu);
+        HIP_OK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(aa.data(), d_aa, n * L, hipMemcpyDeviceToHost, stream));
+        if (nu) HIP_OK(hipMemcpyAsync(out.keys.data(), d_out, nu * 8, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipEventElapsedTime(&out.translate_ms, e0, e1));
+        HIP_OK(hipEventElapsedTime(&out.dedup_ms, e1, e2));
+        for (void* p : {(void*)d_nt, (void*)d_rev, (void*)d_aa, (void*)d_off, (void*)d_keys, (void*)d_tmp, (void*)d_out, (void*)d_err}) hipFree(p);
+        if (err) throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (codon with a base other than A, C, G, T)");
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    hipStreamDestroy(stream);
+    // FASTA in record order (fasta_writer.write(id, None, pepseq), :171)
+    uint64_t k = 0;
+    for (const auto& r : recs)
+        for (uint64_t w = 0; w < r.second; w++, k++) {
+            out.fasta += ">" + r.first + "\n";
+            out.fasta.append(reinterpret_cast<const char*>(aa.data() + k * L), L);
+            out.fasta += "\n";
+        }
+}
+
+}  // namespace mp

@@ -37,3 +37,25 @@ def gather_streams(local, dist=None, dst=0):
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(local, out, dst=dst)
     return out
+
+
+def union_keys(local_keys, dist=None, device="cpu"):
+    """Peptidome union, the one real exchange step of the path (config E): every rank contributes its sorted
+    distinct u64 peptide keys, all ranks end up with the sorted distinct union. Variable-length all-gather = exchange the
+    counts, pad to the maximum, all_gather (RCCL over xGMI on GPUs; ~10 MB per rank, so a single direct all-gather),
+    then one merge-unique."""
+    import torch
+    t = torch.tensor(sorted(set(local_keys)), dtype=torch.int64, device=device)  # keys < 2^60: safe as int64
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t.tolist()
+    world = dist.get_world_size()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    m = int(max(c.item() for c in counts))
+    padded = torch.full((max(m, 1),), -1, dtype=torch.int64, device=device)
+    padded[: t.numel()] = t
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    allk = torch.cat([b[: int(c.item())] for b, c in zip(bufs, counts)])
+    return torch.unique(allk, sorted=True).tolist()

@@ -5,9 +5,12 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <set>
+#include <sstream>
 
 #include "../microphaser_amd/csrc/io.hpp"
 #include "../microphaser_amd/csrc/synth.hpp"
+#include "peptides_oracle.hpp"
 #include "somatic_oracle.hpp"
 
 using namespace mp;
@@ -82,7 +85,31 @@ int main(int argc, char** argv) {
             else std::fputs(js.c_str(), stdout);
             return 0;
         }
-        if (sub != "somatic") throw Error("oracle_cli: only `somatic` and `synth` are available");
+        if (sub == "build_reference") {
+            // oracle_cli build_reference -r peptides.fasta -o peptides.bin [-l 9] > translated.fasta   (src/build_ref_cli.yaml)
+            std::string ref, outp;
+            size_t l = 9;
+            for (int i = 2; i < argc; i++) {
+                std::string a = argv[i];
+                auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + a); return argv[++i]; };
+                if (a == "--reference" || a == "-r") ref = val();
+                else if (a == "--output" || a == "-o") outp = val();
+                else if (a == "--peptide-length" || a == "-l") l = std::stoull(val());
+                else if (a.rfind("-l", 0) == 0 && a.size() > 2) l = std::stoull(a.substr(2));
+                else if (a == "-v" || a == "--verbose") {}
+                else throw Error("unknown argument " + a);
+            }
+            std::ifstream in(ref);
+            if (!in) throw Error("cannot open " + ref);
+            std::stringstream ss;
+            ss << in.rdbuf();
+            std::set<std::string> set;
+            std::string fa = mp_oracle::build_reference(ss.str(), l, set);
+            std::fwrite(fa.data(), 1, fa.size(), stdout);
+            write_file(outp, mp_oracle::bincode_set(set));
+            return 0;
+        }
+        if (sub != "somatic") throw Error("oracle_cli: only `somatic`, `synth` and `build_reference` are available");
         std::string bam_path, vcf_path, ref_path, tsv_path = "info.tsv", normal_path = "normal.fasta", stats_path;
         uint64_t window_len = 27;
         bool warn_only = false;

@@ -69,3 +69,31 @@ def test_two_rank_gloo_shard_and_merge(built, tmp_path):
     for ext in ("fa", "normal.fa", "tsv"):
         assert (tmp_path / ("merged." + ext)).read_bytes() == open(str(whole) + "." + ext, "rb").read()
     assert (tmp_path / "merged.tsv").read_bytes().count(b"\n") > 50
+
+
+UNION_WORKER = r'''
+import json, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from microphaser_amd.shard import union_keys
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+local = [3, 5, 9, 1 << 44] if rank == 0 else [5, 7, 11, 12, (1 << 44) + 1, 9]
+u = union_keys(local, dist)
+open(%(tmp)r + "/union%%d.json" %% rank, "w").write(json.dumps(u))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_peptidome_union(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / "uworker.py"
+    script.write_text(UNION_WORKER % dict(root=ROOT, port=port, tmp=str(tmp_path)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err.decode()[-2000:]
+    want = sorted({3, 5, 9, 1 << 44, 7, 11, 12, (1 << 44) + 1})
+    for r in range(2):
+        assert json.loads((tmp_path / ("union%d.json" % r)).read_text()) == want

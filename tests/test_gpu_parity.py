@@ -107,3 +107,36 @@ def test_gpu_matches_oracle_with_indels_multiallelic_and_softmasked_reference(ct
     assert got["normal_fasta"] == exp["normal.fa"]
     assert got["tsv"] == exp["tsv"]
     assert exp["tsv"].count(b"\n") > 100
+
+
+def test_gpu_build_reference_matches_reference_fixture(ctx):
+    import microphaser_amd as m
+    pep = ctx.build_reference(os.path.join(GOLDEN, "test_build", "reference.fa"), 4)
+    assert pep.fasta == open(os.path.join(GOLDEN, "test_build", "expected_output", "reference_peptides.fasta"), "rb").read()
+    want = m.decode_bincode_set(open(os.path.join(GOLDEN, "test_filter", "reference.binary"), "rb").read())
+    assert m.decode_bincode_set(pep.binary) == want
+    assert [m.key_to_peptide(k, 4) for k in pep.keys] == sorted(p.decode() for p in want)
+
+
+def test_gpu_build_reference_matches_oracle_on_somatic_output(ctx, tmp_path):
+    """Config-E shaped input: the FASTA that `somatic` emits (ids ending in F and R, lower-case variant bases), 9-mers."""
+    import microphaser_amd as m
+    res = ctx.synth(77, 30).phase()
+    fa = tmp_path / "tumor.fa"
+    fa.write_bytes(res.fasta)
+    assert res.fasta.count(b">") > 1000
+    out = tmp_path / "o.bin"
+    r = subprocess.run([ORACLE_CLI, "build_reference", "-r", str(fa), "-l", "9", "-o", str(out)], capture_output=True, check=True)
+    pep = ctx.build_reference(str(fa), 9)
+    assert pep.fasta == r.stdout
+    assert m.decode_bincode_set(pep.binary) == m.decode_bincode_set(out.read_bytes())
+    assert pep.keys == sorted(set(pep.keys)) and len(pep.keys) == len(m.decode_bincode_set(pep.binary))
+    assert m.keys_to_bincode(pep.keys, 9) == pep.binary
+
+
+def test_gpu_build_reference_rejects_non_acgt_codons(ctx, tmp_path):
+    import microphaser_amd as m
+    fa = tmp_path / "n.fa"
+    fa.write_text(">x_F\nACGTNACGTACG\n")
+    with pytest.raises(m.MicrophaserError, match="reference would panic"):
+        ctx.build_reference(str(fa), 4)

@@ -41,3 +41,14 @@ def test_oracle_unsorted_gtf_fails(built, tmp_path):
     with open(os.path.join(d, "chr14.sorted.DHRS2_BDKRB2.gtf"), "rb") as f:
         r = subprocess.run(base, stdin=f, capture_output=True)
     assert r.returncode == 0
+
+
+def test_oracle_build_reference_matches_reference_fixture(built, tmp_path):
+    # tests/lib.rs:132-143 (test_build_ref): translated FASTA is diffed; the peptide set is the one the filter fixtures hold
+    import microphaser_amd as m
+    out = tmp_path / "ref.bin"
+    r = subprocess.run([ORACLE_CLI, "build_reference", "-r", os.path.join(GOLDEN, "test_build", "reference.fa"), "-l4", "-o", str(out)],
+                       capture_output=True, check=True)
+    assert r.stdout == open(os.path.join(GOLDEN, "test_build", "expected_output", "reference_peptides.fasta"), "rb").read()
+    want = m.decode_bincode_set(open(os.path.join(GOLDEN, "test_filter", "reference.binary"), "rb").read())
+    assert m.decode_bincode_set(out.read_bytes()) == want == {b"MRRR", b"PEXD", b"LWHL", b"STDQ"}
