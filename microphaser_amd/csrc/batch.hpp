@@ -10,6 +10,9 @@
 
 namespace mp {
 
+// Host worker threads for planning / consuming (MP_THREADS, default = hardware concurrency capped at 32).
+size_t host_threads();
+
 struct ExonPlan {           // host-only: geometry of one scheduled exon pass
     ExonGeom geom;
     uint32_t tx = 0;

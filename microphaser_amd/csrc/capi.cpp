@@ -26,6 +26,7 @@ struct mp_batch {
     const ReadStore* reads = nullptr;
     bool uploaded = false, ran = false;
     RunTiming timing;
+    uint64_t sum_wlen = 0, sum_cols = 0;  // cached for the byte accounting
 };
 struct mp_results {
     SomaticOutput out;
@@ -157,8 +158,9 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
             st->n_reads = b.r_pos.size(); st->n_variants = b.v_pos.size();
             st->n_groups = t.n_groups; st->n_records = t.n_recs;
             // algorithmic (compulsory) HBM bytes per launch, every byte counted once
-            uint64_t sum_wlen = 0, sum_cols = 0;
-            for (const WinStatic& w : b.wins) { sum_wlen += w.wlen; sum_cols += w.ncols; }
+            if (batch->sum_wlen == 0 && !b.wins.empty())
+                for (const WinStatic& w : b.wins) { batch->sum_wlen += w.wlen; batch->sum_cols += w.ncols; }
+            const uint64_t sum_wlen = batch->sum_wlen, sum_cols = batch->sum_cols;
             st->bytes_k1 = b.bytes_k1_in() + b.bytes_k1_out();
             st->bytes_k2 = b.steps.size() * sizeof(Step) + b.r_pos.size() * (20 + 16ull * b.mask_words) +
                            b.wins.size() * sizeof(WinDyn) + t.n_groups * (sizeof(Group) + 4);

@@ -12,7 +12,9 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <limits>
+#include <thread>
 #include <tuple>
 
 #include "util.hpp"
@@ -462,8 +464,10 @@ struct ConsumerHooks {
 
 }  // namespace
 
-void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
-    for (const GeneHost& gh : b.genes) {
+namespace {
+void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1, SomaticOutput& out) {
+    for (size_t g = g0; g < g1; g++) {
+        const GeneHost& gh = b.genes[g];
         const GeneInput& gi = *gh.input;
         VarIndex vi{&gi.variants};
         for (uint32_t k = 0; k < gh.n_tx; k++) {
@@ -472,6 +476,53 @@ void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
             ConsumerHooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
             walk_transcript(gi.gene, t, vi, gh.max_read_len, b.window_len, hooks);
         }
+    }
+}
+}  // namespace
+
+// Genes are independent (no state crosses phase_gene calls), so the host walk is sharded over threads by gene range and
+// the per-range streams are concatenated in gene order; the TSV header is kept from the first range that wrote a record.
+void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
+    size_t nthreads = host_threads();
+    const size_t ng = b.genes.size();
+    if (nthreads > ng) nthreads = ng ? ng : 1;
+    if (nthreads <= 1) { consume_range(b, res, 0, ng, out); return; }
+    // balance by planned steps
+    std::vector<uint64_t> cost(ng + 1, 0);
+    for (size_t g = 0; g < ng; g++) {
+        uint64_t c = 0;
+        for (uint32_t k = 0; k < b.genes[g].n_tx; k++) c += b.tx[b.genes[g].tx_off + k].n_steps;
+        cost[g + 1] = cost[g] + c + 1;
+    }
+    std::vector<size_t> cut(nthreads + 1, ng);
+    cut[0] = 0;
+    for (size_t t = 1; t < nthreads; t++) {
+        uint64_t target = cost[ng] * t / nthreads;
+        cut[t] = size_t(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
+        if (cut[t] > ng) cut[t] = ng;
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    std::vector<SomaticOutput> parts(nthreads);
+    std::vector<std::string> errors(nthreads);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; t++)
+        th.emplace_back([&, t] {
+            try { consume_range(b, res, cut[t], cut[t + 1], parts[t]); }
+            catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+        });
+    for (auto& x : th) x.join();
+    for (size_t t = 0; t < nthreads; t++)
+        if (!errors[t].empty()) throw Error(errors[t]);  // the first failing gene range in gene order, like a sequential run
+    for (size_t t = 0; t < nthreads; t++) {
+        SomaticOutput& p = parts[t];
+        out.fasta += p.fasta;
+        out.normal_fasta += p.normal_fasta;
+        out.n_windows += p.n_windows;
+        if (!p.tsv.empty()) {
+            if (!out.tsv_header_written) { out.tsv += p.tsv; out.tsv_header_written = true; }
+            else out.tsv.append(p.tsv, p.tsv.find('\n') + 1, std::string::npos);
+        }
+        p = SomaticOutput();
     }
 }
 

@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <deque>
 #include <map>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
 
 #include "batch.hpp"
 
@@ -183,7 +185,7 @@ struct PlannerHooks {
 
 }  // namespace
 
-void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
+static void build_batch_range(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
     b = Batch();
     b.window_len = window_len;
     b.genes.resize(n_genes);
@@ -331,6 +333,89 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
     b.g_var_off.push_back(uint32_t(b.v_pos.size()));
     b.mask_words = max_span_vars <= 64 ? 1 : max_span_vars <= 128 ? 2 : 4;
     if (max_span_vars > 256) throw Error("a read spans more than 256 variants; mask width not supported");
+    b.tx_order.resize(b.tx.size());
+    std::iota(b.tx_order.begin(), b.tx_order.end(), 0u);
+    std::stable_sort(b.tx_order.begin(), b.tx_order.end(), [&](uint32_t a, uint32_t c) { return b.tx[a].n_steps > b.tx[c].n_steps; });
+}
+
+size_t host_threads() {
+    if (const char* e = std::getenv("MP_THREADS")) {
+        long v = std::atol(e);
+        if (v >= 1) return size_t(v);
+    }
+    unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 1 : std::min<unsigned>(hc, 32);
+}
+
+namespace {
+template <class T> void append(std::vector<T>& a, const std::vector<T>& b) { a.insert(a.end(), b.begin(), b.end()); }
+
+// Concatenate a sub-batch (genes planned by another thread) onto `b`, rebasing every absolute index.
+void merge_batch(Batch& b, Batch& s) {
+    const uint32_t gOff = uint32_t(b.genes.size()), rOff = uint32_t(b.r_pos.size()), vOff = uint32_t(b.v_pos.size());
+    const uint64_t refOff = b.ref_pool.size(), cigOff = b.cigar_pool.size(), seqOff = b.seq_pool.size(), qualOff = b.qual_pool.size();
+    const uint32_t insOff = uint32_t(b.ins_pool.size()), tOff = uint32_t(b.tx.size()), sOff = uint32_t(b.steps.size());
+    const uint32_t wOff = uint32_t(b.wins.size()), wcOff = uint32_t(b.win_cols.size()), eOff = uint32_t(b.exons.size());
+    const uint32_t strOff = uint32_t(b.str_pool.size());
+    if (refOff + s.ref_pool.size() > 0xFFFFFFF0ull) throw Error("reference bytes of one batch exceed 4 GiB: split the batch by genes");
+    if (uint64_t(sOff) + s.steps.size() > 0xFFFFFFF0ull || uint64_t(rOff) + s.r_pos.size() > 0xFFFFFFF0ull)
+        throw Error("batch too large for 32-bit indices: split the batch by genes");
+    for (GeneHost& g : s.genes) { g.read_off += rOff; g.var_off += vOff; g.ref_off += refOff; g.tx_off += tOff; b.genes.push_back(std::move(g)); }
+    for (size_t i = 0; i + 1 < s.g_read_off.size(); i++) b.g_read_off.push_back(s.g_read_off[i] + rOff);
+    for (size_t i = 0; i + 1 < s.g_var_off.size(); i++) b.g_var_off.push_back(s.g_var_off[i] + vOff);
+    append(b.g_start, s.g_start);
+    for (uint64_t o : s.g_ref_off) b.g_ref_off.push_back(o + refOff);
+    append(b.r_pos, s.r_pos); append(b.r_end, s.r_end); append(b.r_lseq, s.r_lseq); append(b.r_ncig, s.r_ncig); append(b.r_dup, s.r_dup);
+    for (uint64_t o : s.r_cigoff) b.r_cigoff.push_back(o + cigOff);
+    for (uint64_t o : s.r_seqoff) b.r_seqoff.push_back(o + seqOff);
+    for (uint64_t o : s.r_qualoff) b.r_qualoff.push_back(o + qualOff);
+    append(b.cigar_pool, s.cigar_pool); append(b.seq_pool, s.seq_pool); append(b.qual_pool, s.qual_pool); append(b.r_src, s.r_src);
+    append(b.v_pos, s.v_pos); append(b.v_info, s.v_info); append(b.v_len, s.v_len); append(b.v_rev2fwd, s.v_rev2fwd);
+    for (uint32_t o : s.v_insoff) b.v_insoff.push_back(o + insOff);
+    append(b.ins_pool, s.ins_pool); append(b.ref_pool, s.ref_pool);
+    for (TxDev t : s.tx) { t.gene += gOff; t.step_off += sOff; t.id_off += strOff; b.tx.push_back(t); }
+    for (Step st : s.steps) { if (st.win != 0xFFFFFFFFu) st.win += wOff; st.exon += eOff; b.steps.push_back(st); }
+    for (WinStatic w : s.wins) { w.tx += tOff; w.col_off += wcOff; w.ref_off += uint32_t(refOff); w.vbase += vOff; w.step += sOff; b.wins.push_back(w); }
+    append(b.win_cols, s.win_cols);
+    for (ExonPlan e : s.exons) { e.tx += tOff; b.exons.push_back(e); }
+    append(b.str_pool, s.str_pool);
+    b.mask_words = std::max(b.mask_words, s.mask_words);
+    b.max_rows_bound = std::max(b.max_rows_bound, s.max_rows_bound);
+    b.seq_cap = std::max(b.seq_cap, s.seq_cap);
+    b.n_main_windows += s.n_main_windows;
+    s = Batch();
+}
+}  // namespace
+
+// Genes are independent: plan gene ranges on worker threads, then concatenate the sub-batches in gene order.
+void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
+    size_t nthreads = std::min(host_threads(), std::max<size_t>(1, n_genes / 8));
+    if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, mapq_min, b); return; }
+    std::vector<uint64_t> cost(n_genes + 1, 0);
+    for (size_t g = 0; g < n_genes; g++) cost[g + 1] = cost[g] + genes[g].reads.size() + genes[g].refseq.size() / 8 + 1;
+    std::vector<size_t> cut(nthreads + 1, n_genes);
+    cut[0] = 0;
+    for (size_t t = 1; t < nthreads; t++) {
+        uint64_t target = cost[n_genes] * t / nthreads;
+        cut[t] = std::min<size_t>(n_genes, size_t(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin()));
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    std::vector<Batch> parts(nthreads);
+    std::vector<std::string> errors(nthreads);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; t++)
+        th.emplace_back([&, t] {
+            try { build_batch_range(genes + cut[t], cut[t + 1] - cut[t], rs, window_len, mapq_min, parts[t]); }
+            catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+        });
+    for (auto& x : th) x.join();
+    for (size_t t = 0; t < nthreads; t++)
+        if (!errors[t].empty()) throw Error(errors[t]);
+    b = Batch();
+    b.window_len = window_len;
+    for (size_t t = 0; t < nthreads; t++) merge_batch(b, parts[t]);
+    b.g_read_off.push_back(uint32_t(b.r_pos.size()));
+    b.g_var_off.push_back(uint32_t(b.v_pos.size()));
     b.tx_order.resize(b.tx.size());
     std::iota(b.tx_order.begin(), b.tx_order.end(), 0u);
     std::stable_sort(b.tx_order.begin(), b.tx_order.end(), [&](uint32_t a, uint32_t c) { return b.tx[a].n_steps > b.tx[c].n_steps; });
