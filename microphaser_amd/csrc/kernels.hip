@@ -143,6 +143,12 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 
     uint32_t ncols = 0, head = 0;
     uint32_t colver = 1;  // bumped whenever the column set changes
+    // Fast admission: while the live columns are a contiguous, monotone run of forward variant indices and none of them is
+    // a frameshift / start-loss variant, a new row's haplotype is one shift+mask (+ bit reversal on '+') of its K1 mask.
+    uint32_t n_special = 0;     // live columns with frameshift() > 0 or start-loss
+    bool contig = true;
+    uint32_t f_oldest = 0, f_newest = 0;
+    uint64_t special_mask = 0;  // bit c (hap bit order) set <=> column c is special
     uint64_t chunk_pos = 0, chunk_end = 0;   // group slots (per-wave chunk allocator: one atomic per GROUP_CHUNK groups)
     uint64_t rec_pos = 0, rec_end = 0;       // haplotype-record slots, same scheme (K3 then needs no atomics at all)
     uint64_t som_mask = 0;                   // bit c set <=> live column c is a somatic variant (same bit order as hap)
@@ -215,6 +221,10 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 head = (head + n_del) & 63;
                 uint64_t mask = (1ull << ncols) - 1ull;
                 som_mask &= mask;
+                special_mask &= mask;
+                n_special = uint32_t(__popcll(special_mask));
+                if (ncols == 0) contig = true;
+                else f_oldest = is_rev ? f_oldest - n_del : f_oldest + n_del;
 #pragma unroll
                 for (int r = 0; r < RPL; r++) hap[r] &= mask;
             }
@@ -264,17 +274,38 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 #pragma unroll
                 for (int r = 0; r < RPL; r++)
                     if (att[r]) { hap[r] = 0; fr0[r] = 0; fl[r] &= ST_MASK; }
-                __syncthreads();
-                for (uint32_t j = 0; j < ncols; j++) {
-                    uint32_t f = colf[(head + j) & 63], info = colinfo[(head + j) & 63];
+                const uint32_t lo_f = is_rev ? f_newest : f_oldest;  // smallest forward index among the live columns
+                bool fast = W == 1 && contig && n_special == 0;
+                if (fast) {
+                    bool cov_bad = false;
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) cov_bad |= att[r] && ncols && !(lo_f >= rvl[r] && lo_f + ncols - rvl[r] <= rcov[r]);
+                    fast = __ballot(cov_bad) == 0;
+                }
+                if (fast) {
+                    const uint64_t cmask = ncols ? (~0ull >> (64 - ncols)) : 0ull;
 #pragma unroll
                     for (int r = 0; r < RPL; r++)
-                        if (att[r]) {
-                            bool s, q;
-                            bits_of(r, f, info, s, q);
-                            hap[r] <<= 1;
-                            update_row(r, s, q, info);
+                        if (att[r] && ncols) {
+                            const uint32_t sh = lo_f - rvl[r];
+                            const uint64_t sb = (msup[r] >> sh) & cmask, qb = (mlq[r] >> sh) & cmask;
+                            // '+': column j (oldest = 0) is forward index lo_f + j and haplotype bit ncols-1-j -> reverse the run
+                            hap[r] = is_rev ? sb : (__brevll(sb) >> (64 - ncols));
+                            if (qb) { hap[r] = 0; fl[r] |= RF_BAD; }  // :192-195
                         }
+                } else {
+                    __syncthreads();
+                    for (uint32_t j = 0; j < ncols; j++) {
+                        uint32_t f = colf[(head + j) & 63], info = colinfo[(head + j) & 63];
+#pragma unroll
+                        for (int r = 0; r < RPL; r++)
+                            if (att[r]) {
+                                bool s, q;
+                                bits_of(r, f, info, s, q);
+                                hap[r] <<= 1;
+                                update_row(r, s, q, info);
+                            }
+                    }
                 }
                 // `contains` (:281-294) only ever matches on the reverse strand (rows keyed by start)
                 bool need_dup = false;
@@ -325,8 +356,13 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 if (pos >= T.sl_lo && pos < T.sl_hi) info |= 0x80000000u; else info &= 0x7FFFFFFFu;
                 __syncthreads();
                 if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
+                if (ncols == 0) { contig = true; f_oldest = f; }
+                else contig = contig && (f == (is_rev ? f_newest - 1 : f_newest + 1));
+                f_newest = f;
                 ncols++;
                 som_mask = (som_mask << 1) | ((info & VI_GERMLINE) ? 0ull : 1ull);
+                special_mask = (special_mask << 1) | (((info & VI_FS_MASK) || (info & 0x80000000u)) ? 1ull : 0ull);
+                n_special = uint32_t(__popcll(special_mask));
 #pragma unroll
                 for (int r = 0; r < RPL; r++)
                     if ((fl[r] & ST_MASK) == ST_ROW) {
