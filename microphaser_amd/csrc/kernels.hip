@@ -546,11 +546,10 @@ __device__ __forceinline__ uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <
 __device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
 constexpr int K3_THREADS = 64;                             // one wave per workgroup: LDS granularity 10.5 KB -> 15 waves/CU
-constexpr int K3_REFCAP = 64;                              // staged reference bytes (window + alignment slack);
-                                                           // re-used as the 16-word SHA-1 block buffer after the walk
+constexpr int K3_REFCAP = 36;                              // staged reference bytes (31-nt window + 3 alignment + 2)
 template <int CAP> struct K3Cfg {
-    static constexpr int SLOT_BYTES = K3_REFCAP + 2 * CAP;  // ref | seq | germ  (160 bytes at CAP = 48)
-    static constexpr int SLOT_DW = SLOT_BYTES / 4 + 1;      // odd dword stride (41 at CAP = 48)
+    static constexpr int SLOT_BYTES = K3_REFCAP + 2 * CAP;  // ref | seq | germ  (132 bytes at CAP = 48)
+    static constexpr int SLOT_DW = (SLOT_BYTES / 4) | 1;    // odd dword stride (33 at CAP = 48)
 };
 
 struct ShaStream {
@@ -658,17 +657,33 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         uint32_t i = ws.sso, j = 0, ns = 0, ngm = 0;
         bool indel = false, insertion = false, broke_flag = false;
         uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
+        // the first 8 columns (in walk order) are fetched up front so their loads overlap instead of forming a dependent chain
+        uint32_t cpos[8], cinfo[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            cpos[k] = 0xFFFFFFFFu; cinfo[k] = 0;
+            if (uint32_t(k) < ncols) {
+                const uint32_t dq = is_rev ? (ncols - 1 - k) : uint32_t(k);
+                const WinCol* wc = d.win_cols + ws.col_off + dq;
+                cpos[k] = wc->pos; cinfo[k] = wc->info;
+            }
+        }
         auto load_j = [&]() {
-            if (j < ncols) {
+            if (j < 8) {
+                pos_j = cpos[0]; info_j = cinfo[0];
+#pragma unroll
+                for (int k = 1; k < 8; k++) if (j == uint32_t(k)) { pos_j = cpos[k]; info_j = cinfo[k]; }
+                if (j >= ncols) pos_j = 0xFFFFFFFFu;
+            } else if (j < ncols) {
                 uint32_t dq = is_rev ? (ncols - 1 - j) : j;
                 const WinCol wc = d.win_cols[ws.col_off + dq];
-                f_j = wc.f;
                 pos_j = wc.pos;
                 info_j = wc.info;
             } else {
                 pos_j = 0xFFFFFFFFu;
             }
         };
+        auto col_f = [&]() { return d.win_cols[ws.col_off + (is_rev ? (ncols - 1 - j) : j)].f; };  // only indels need it
         auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) seq[ns] = c; ns++; };
         auto push_g = [&](uint8_t c) { if (ngm < SEQ_CAP) germ[ngm] = c; ngm++; };
         load_j();
@@ -691,6 +706,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                         push_s(sw);
                         i += 1;
                     } else if (kind == 1) {
+                        f_j = col_f();
                         uint32_t il = d.v_len[vbase + f_j] + 1;
                         const uint8_t* ins = d.ins_pool + d.v_insoff[vbase + f_j];
                         bool up = is_upper(r);
@@ -703,6 +719,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                         insertion = true;
                         i += 1;
                     } else {
+                        f_j = col_f();
                         uint32_t dl = d.v_len[vbase + f_j];
                         if (is_rev && pos_j + dl - 1 >= window_end) { brk = true; }
                         else {
