@@ -36,7 +36,7 @@ struct Batch {
     std::vector<uint32_t> g_read_off, g_var_off, g_start;  // per gene (+1 for the offsets)
     std::vector<uint64_t> g_ref_off;
     // ---- reads (gene-major, start-sorted, mapq-filtered)
-    std::vector<uint32_t> r_pos, r_end, r_lseq, r_ncig, r_dup;
+    std::vector<uint32_t> r_pos, r_end, r_lseq, r_ncig, r_dup, r_varlo;
     std::vector<uint64_t> r_cigoff, r_seqoff, r_qualoff;
     std::vector<uint32_t> cigar_pool;
     std::vector<uint8_t> seq_pool, qual_pool;

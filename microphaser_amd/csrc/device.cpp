@@ -71,6 +71,7 @@ void DeviceContext::upload(const Batch& b) {
     d_.r_lseq = up(b.r_lseq);
     d_.r_ncig = up(b.r_ncig);
     d_.r_dup = up(b.r_dup);
+    d_.r_varlo = up(b.r_varlo);
     d_.r_cigoff = up(b.r_cigoff);
     d_.r_seqoff = up(b.r_seqoff);
     d_.r_qualoff = up(b.r_qualoff);
@@ -97,7 +98,6 @@ void DeviceContext::upload(const Batch& b) {
     d_.seq_cap = b.seq_cap;
     d_.rec_stride = hap_rec_stride(b.seq_cap);
     // K1 outputs
-    d_.r_varlo = static_cast<uint32_t*>(dalloc(size_t(d_.n_reads) * 4)); allocs_.push_back(d_.r_varlo);
     d_.r_ncov = static_cast<uint32_t*>(dalloc(size_t(d_.n_reads) * 4)); allocs_.push_back(d_.r_ncov);
     d_.r_sup = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_sup);
     d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);

@@ -49,63 +49,92 @@ __device__ __forceinline__ int cigar_read_pos_dev(const uint32_t* cig, uint32_t 
     return -1;
 }
 
+// One thread per read. The first variant at or after the read start (r_varlo) comes from the planner, the variants the
+// read can see are then a short contiguous run of the gene's variant array; the run is walked twice - first only to find
+// its end (independent v_pos loads), then to evaluate the predicates with the loads of four variants in flight at once.
+__device__ __forceinline__ uint8_t decode_base4(uint32_t code) {  // BAM 4-bit code -> "=ACMGRSVTWYHKDBN"
+    const uint64_t lo = 0x565352474d43413dull, hi = 0x4e42444b48595754ull;
+    return uint8_t(((code & 8) ? hi : lo) >> (8 * (code & 7)));
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= d.n_reads) return;
-    uint32_t g = d.r_gene[i];
-    uint32_t vbase = d.g_var_off[g];
-    uint32_t nv = d.g_var_off[g + 1] - vbase;
-    uint32_t rpos = d.r_pos[i], rend = d.r_end[i], lseq = d.r_lseq[i], ncig = d.r_ncig[i];
+    const uint32_t g = d.r_gene[i];
+    const uint32_t vbase = d.g_var_off[g];
+    const uint32_t nv = d.g_var_off[g + 1] - vbase;
+    const uint32_t rpos = d.r_pos[i], rend = d.r_end[i], lseq = d.r_lseq[i], ncig = d.r_ncig[i];
+    const uint32_t lo = d.r_varlo[i];
     const uint32_t* cig = d.cigar_pool + d.r_cigoff[i];
     const uint8_t* seq4 = d.seq_pool + d.r_seqoff[i];
     const uint8_t* qual = d.qual_pool + d.r_qualoff[i];
-    // first variant with pos >= rpos
-    uint32_t lo = 0, hi = nv;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (d.v_pos[vbase + mid] < rpos) lo = mid + 1; else hi = mid;
+    // a variant can be a (stale) column of a window the read encloses without lying inside the read's aligned span;
+    // bad_quality still indexes the qualities by reference offset (:82-88): cover max(end, start + l_seq)
+    const uint32_t cover_end = max(rend, rpos + lseq);
+    uint32_t ncov = 0;
+    {
+        const uint32_t maxn = min(nv - lo, 64u * W);
+        const uint32_t* vp = d.v_pos + vbase + lo;
+        while (ncov + 4 <= maxn) {
+            uint32_t p0 = vp[ncov], p1 = vp[ncov + 1], p2 = vp[ncov + 2], p3 = vp[ncov + 3];
+            if (p3 < cover_end) { ncov += 4; continue; }
+            ncov += (p0 < cover_end) + (p1 < cover_end) + (p2 < cover_end);
+            goto counted;
+        }
+        while (ncov < maxn && vp[ncov] < cover_end) ncov++;
+    counted:;
     }
+    const uint32_t c0 = ncig > 0 ? cig[0] : 0;
+    const bool simple = ncig == 1 && (c0 & 0xF) == 0;  // a single M op: read_pos(p) = p - start
     uint64_t sup[W], lq[W];
 #pragma unroll
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
-    uint32_t ncov = 0;  // variants actually evaluated (K2 must not read mask bits beyond them)
-    for (uint32_t k = lo; k < nv && (k - lo) < 64u * W; k++) {
-        uint32_t vpos = d.v_pos[vbase + k];
-        // a variant can be a (stale) column of a window the read encloses without lying inside the read's
-        // aligned span; bad_quality still indexes the qualities by reference offset (:82-88)
-        if (vpos >= rend && vpos - rpos >= lseq) break;
-        uint32_t info = d.v_info[vbase + k];
-        uint32_t kind = info & VI_KIND_MASK;
-        bool s = false, q = false;
-        if (kind == 0) {  // SNV
-            uint32_t rel = vpos - rpos;
-            if (rel < lseq && qual[rel] < 10) q = true;
-            if (!q) {
-                int p = cigar_read_pos_dev(cig, ncig, rpos, vpos);
-                if (p >= 0 && uint32_t(p) < lseq) {
-                    uint8_t b4 = seq4[p >> 1];
-                    uint32_t code = (p & 1) ? (b4 & 0xF) : (b4 >> 4);
-                    const char dec[17] = "=ACMGRSVTWYHKDBN";
-                    s = uint8_t(dec[code]) == uint8_t(info >> VI_ALT_SHIFT);
-                }
-            }
-        } else {  // insertion / deletion: any I / D op of exactly that length
-            uint32_t want = kind == 1 ? 1u : 2u;
-            uint32_t vlen = d.v_len[vbase + k];
-            for (uint32_t c = 0; c < ncig; c++)
-                if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
-        }
-        uint32_t b = k - lo;
-        ncov = b + 1;
+    for (uint32_t b0 = 0; b0 < ncov; b0 += 4) {
+        uint32_t vpos[4], info[4];
+        uint8_t qb[4];
 #pragma unroll
-        for (int w = 0; w < W; w++)
-            if ((b >> 6) == uint32_t(w)) {
-                if (s) sup[w] |= 1ull << (b & 63);
-                if (q) lq[w] |= 1ull << (b & 63);
+        for (int u = 0; u < 4; u++) {
+            const uint32_t k = min(b0 + u, ncov - 1);
+            vpos[u] = d.v_pos[vbase + lo + k];
+            info[u] = d.v_info[vbase + lo + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t rel = vpos[u] - rpos;
+            qb[u] = rel < lseq ? qual[rel] : uint8_t(255);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = b0 + u;
+            if (b >= ncov) break;
+            const uint32_t kind = info[u] & VI_KIND_MASK;
+            bool s = false, q = false;
+            if (kind == 0) {  // SNV (:97-112, :80-92)
+                q = qb[u] < 10;
+                if (!q) {
+                    int p = simple ? int(vpos[u] - rpos) : cigar_read_pos_dev(cig, ncig, rpos, vpos[u]);
+                    if (simple && uint32_t(p) >= (c0 >> 4)) p = -1;
+                    if (p >= 0 && uint32_t(p) < lseq) {
+                        uint8_t b4 = seq4[p >> 1];
+                        uint32_t code = (p & 1) ? (b4 & 0xF) : (b4 >> 4);
+                        s = decode_base4(code) == uint8_t(info[u] >> VI_ALT_SHIFT);
+                    }
+                }
+            } else {  // insertion / deletion: any I / D op of exactly that length (:113-137)
+                uint32_t want = kind == 1 ? 1u : 2u;
+                uint32_t vlen = d.v_len[vbase + lo + b];
+                for (uint32_t c = 0; c < ncig; c++)
+                    if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
             }
+#pragma unroll
+            for (int w = 0; w < W; w++)
+                if ((b >> 6) == uint32_t(w)) {
+                    if (s) sup[w] |= 1ull << (b & 63);
+                    if (q) lq[w] |= 1ull << (b & 63);
+                }
+        }
     }
-    d.r_varlo[i] = lo;
     d.r_ncov[i] = ncov;
 #pragma unroll
     for (int w = 0; w < W; w++) {

@@ -27,8 +27,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint8_t* str_pool;
     const uint32_t* tx_order;
     uint32_t n_reads, n_tx, n_wins, mask_words;
+    const uint32_t* r_varlo;      // planner: gene-relative index of the first variant with pos >= r_pos
     // K1 output
-    uint32_t* r_varlo;
     uint32_t* r_ncov;             // number of variants (from r_varlo on) whose bits K1 evaluated
     uint64_t *r_sup, *r_lq;  // [read * mask_words + w]
     // K2 output

@@ -283,6 +283,7 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
                 uint64_t s = b.r_pos[gh.read_off + k];
                 uint64_t e = std::max<uint64_t>(b.r_end[gh.read_off + k], s + b.r_lseq[gh.read_off + k]);
                 while (vlo < vs.size() && vs[vlo].pos < s) vlo++;
+                b.r_varlo.push_back(uint32_t(vlo));
                 if (vhi < vlo) vhi = vlo;
                 while (vhi < vs.size() && vs[vhi].pos < e) vhi++;
                 size_t hi2 = vhi;
@@ -365,7 +366,7 @@ void merge_batch(Batch& b, Batch& s) {
     for (size_t i = 0; i + 1 < s.g_var_off.size(); i++) b.g_var_off.push_back(s.g_var_off[i] + vOff);
     append(b.g_start, s.g_start);
     for (uint64_t o : s.g_ref_off) b.g_ref_off.push_back(o + refOff);
-    append(b.r_pos, s.r_pos); append(b.r_end, s.r_end); append(b.r_lseq, s.r_lseq); append(b.r_ncig, s.r_ncig); append(b.r_dup, s.r_dup);
+    append(b.r_pos, s.r_pos); append(b.r_end, s.r_end); append(b.r_lseq, s.r_lseq); append(b.r_ncig, s.r_ncig); append(b.r_dup, s.r_dup); append(b.r_varlo, s.r_varlo);
     for (uint64_t o : s.r_cigoff) b.r_cigoff.push_back(o + cigOff);
     for (uint64_t o : s.r_seqoff) b.r_seqoff.push_back(o + seqOff);
     for (uint64_t o : s.r_qualoff) b.r_qualoff.push_back(o + qualOff);
