@@ -613,12 +613,12 @@ struct ShaStream {
         }
         h0 += a; h1 += b; h2 += c; h3 += d; h4 += e;
     }
-    // append n <= 4 bytes given as a big-endian integer
-    __device__ __forceinline__ void feed(uint32_t v, uint32_t n) {
+    // append n <= 5 bytes given as a big-endian integer (at most 3 bytes are queued, so the queue holds <= 8)
+    __device__ __forceinline__ void feed(uint64_t v, uint32_t n) {
         q = (q << (8 * n)) | v;
         nq += n;
         total += n;
-        if (nq >= 4) {
+        while (nq >= 4) {
             uint32_t wv = uint32_t(q >> (8 * (nq - 4)));
             nq -= 4;
             blk[widx++] = wv;
@@ -631,9 +631,10 @@ struct ShaStream {
         while (div) { feed('0' + (v / div) % 10, 1); div /= 10; }
     }
     __device__ void finish() {
-        uint32_t bits = total * 8;
+        const uint32_t bits = total * 8;
         feed(0x80, 1);
-        while (!(nq == 0 && widx == 14)) feed(0, 1);
+        if (nq) feed(0, 4 - nq);                 // complete the current word
+        while (widx != 14) feed(0, 4);           // zero words up to the 64-bit length field
         feed(0, 4);
         feed(bits, 4);
     }
@@ -859,11 +860,15 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
         for (int b = 0; b < 4; b++) {
             const uint32_t k = k0 + b;
             if (k < seq_len) {
-                uint32_t v = (dw >> (8 * b)) & 0xFF;
-                if (k) sh.feed((uint32_t(',') << 8) | ' ', 2);
-                if (v >= 100) sh.feed((uint32_t('0' + v / 100) << 16) | (uint32_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10), 3);
-                else if (v >= 10) sh.feed((uint32_t('0' + v / 10) << 8) | ('0' + v % 10), 2);
-                else sh.feed('0' + v, 1);
+                // "{:?}" of a Vec<u8>: decimal value, then ", " unless it is the last element - one feed of <= 5 bytes
+                const uint32_t v = (dw >> (8 * b)) & 0xFF;
+                uint64_t txt;
+                uint32_t n;
+                if (v >= 100) { txt = (uint64_t('0' + v / 100) << 16) | (uint64_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10); n = 3; }
+                else if (v >= 10) { txt = (uint64_t('0' + v / 10) << 8) | ('0' + v % 10); n = 2; }
+                else { txt = '0' + v; n = 1; }
+                if (k + 1 < seq_len) { txt = (txt << 16) | (uint64_t(',') << 8) | ' '; n += 2; }
+                sh.feed(txt, n);
             }
         }
     }
