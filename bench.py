@@ -159,7 +159,7 @@ def main():
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),
             "hbm_resident_bytes": int(st.hbm_bytes),
             "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "d2h_consume_s": None if args.no_consume else t_consume,
-                           "note": "host legs of rank 0, single thread; not part of `value`"},
+                           "note": "host legs of rank 0 (planner and consumer shard genes over host threads); not part of `value`"},
         }
         if world == 1 and args.cpu_sample > 0:
             cb = cpu_baseline(args.config, args.cpu_sample)
