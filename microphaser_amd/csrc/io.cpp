@@ -561,7 +561,7 @@ Interval make_interval(uint64_t start, uint64_t end, const std::string& frame) {
 }
 }  // namespace
 
-void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gene) {
+void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gene, bool use_three_prime_utr) {
     bool have_gene = false;
     Gene gene;
     bool start_codon_found = false, three_prime_found = false;
@@ -620,7 +620,7 @@ void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gen
             if (t.exons.empty()) throw Error("no exon record before start codon in GTF");
             if (rec.strand == "+") t.exons.back().start = rec.start - 1;
             else t.exons.back().end = rec.end;
-        } else if (rec.feature == "three_prime_utr") {  // :2083-2122
+        } else if (use_three_prime_utr && rec.feature == "three_prime_utr") {  // :2083-2122
             Transcript& t = last_tx("no transcript record before exon in GTF");
             if (three_prime_found) {
                 t.exons.push_back(make_interval(rec.start - 1, rec.end, rec.frame));
@@ -636,7 +636,7 @@ void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gen
 }
 
 void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const RefSource& fasta,
-                      bool warning_only, const std::function<void(GeneInput&)>& on_gene) {
+                      bool warning_only, const std::function<void(GeneInput&)>& on_gene, bool use_three_prime_utr) {
     ReadBuffer rb(bam);
     stream_gtf(gtf, [&](const Gene& g) {
         if (g.biotype != "protein_coding") return;  // microphasing.rs:1964
@@ -647,7 +647,7 @@ void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf,
         gi.reads.assign(rb.records().begin(), rb.records().end());
         gene_variants(vcf, g.chrom, g.start(), g.end(), warning_only, gi.variants);  // :932-942
         on_gene(gi);
-    });
+    }, use_three_prime_utr);
 }
 
 }  // namespace mp

@@ -121,12 +121,13 @@ class IndexedFasta : public RefSource {
 // Streams a GTF the way microphasing::phase does (reference: src/microphasing.rs:1982-2128) and calls
 // `on_gene` for every completed gene (all biotypes; the caller applies the protein_coding filter
 // exactly where the reference does, :1964). Throws mp::Error for an unsorted GTF (:1998-2000) and
-// for missing attributes.
-void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gene);
+// for missing attributes. `normal` mode ignores three_prime_utr records (src/normal_microphasing.rs:1319-1433).
+void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gene, bool use_three_prime_utr = true);
 
 // Convenience: run the per-gene loading of phase_gene (refseq, reads, variants) for every
 // protein-coding gene of a GTF stream.
 void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const RefSource& fasta,
-                      bool unsupported_allele_warning_only, const std::function<void(GeneInput&)>& on_gene);
+                      bool unsupported_allele_warning_only, const std::function<void(GeneInput&)>& on_gene,
+                      bool use_three_prime_utr = true);
 
 }  // namespace mp

@@ -189,4 +189,19 @@ struct SomaticOutput {
     uint64_t n_windows = 0;  // main-ORF print_haplotypes invocations (the benchmark unit)
 };
 
+// `microphaser normal`: its own record type with a single peptide_sequence column
+// (reference: src/normal_microphasing.rs:80-102) and two output streams (stdout FASTA, --tsv).
+struct NormalRecord {
+    std::string id, transcript, gene_id, gene_name, chrom;
+    uint64_t offset = 0, frame = 0;
+    double freq = 0;
+    uint32_t depth = 0, nvar = 0, nsomatic = 0, nvariant_sites = 0, nsomvariant_sites = 0;
+    std::string strand, variant_sites, somatic_positions, somatic_aa_change, germline_positions, germline_aa_change, peptide_sequence;
+};
+struct NormalOutput {
+    std::string fasta, tsv;
+    bool tsv_header_written = false;
+    uint64_t n_windows = 0;
+};
+
 }  // namespace mp

@@ -180,4 +180,25 @@ inline void write_tsv_record(SomaticOutput& o, const IDRecord& r) {
     t.push_back('\n');
 }
 
+// csv::Writer::serialize(normal_microphasing::IDRecord) (reference: src/normal_microphasing.rs:80-102)
+inline void write_normal_tsv_record(NormalOutput& o, const NormalRecord& r) {
+    std::string& t = o.tsv;
+    if (!o.tsv_header_written) {
+        t += "id\ttranscript\tgene_id\tgene_name\tchrom\toffset\tframe\tfreq\tdepth\tnvar\tnsomatic\tnvariant_sites\t"
+             "nsomvariant_sites\tstrand\tvariant_sites\tsomatic_positions\tsomatic_aa_change\tgermline_positions\t"
+             "germline_aa_change\tpeptide_sequence\n";
+        o.tsv_header_written = true;
+    }
+    auto S = [&](const std::string& f) { tsv_field(t, f); t.push_back('\t'); };
+    auto U = [&](uint64_t v) { t += std::to_string(v); t.push_back('\t'); };
+    S(r.id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom);
+    U(r.offset); U(r.frame);
+    t += fmt_f64(r.freq); t.push_back('\t');
+    U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
+    S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change);
+    S(r.germline_positions); S(r.germline_aa_change);
+    tsv_field(t, r.peptide_sequence);
+    t.push_back('\n');
+}
+
 }  // namespace mp

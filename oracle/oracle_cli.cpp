@@ -10,6 +10,7 @@
 
 #include "../microphaser_amd/csrc/io.hpp"
 #include "../microphaser_amd/csrc/synth.hpp"
+#include "normal_oracle.hpp"
 #include "peptides_oracle.hpp"
 #include "somatic_oracle.hpp"
 
@@ -109,7 +110,36 @@ int main(int argc, char** argv) {
             write_file(outp, mp_oracle::bincode_set(set));
             return 0;
         }
-        if (sub != "somatic") throw Error("oracle_cli: only `somatic`, `synth` and `build_reference` are available");
+        if (sub == "normal") {
+            // oracle_cli normal <normal.bam> --variants V --ref R --tsv T [-w 27] [-u] < gtf > fasta   (src/germline_cli.yaml)
+            std::string bam_path, vcf_path, ref_path, tsv_path = "info.tsv";
+            uint64_t wl = 27;
+            bool warn_only = false;
+            for (int i = 2; i < argc; i++) {
+                std::string a = argv[i];
+                auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + a); return argv[++i]; };
+                if (a == "--variants" || a == "-b") vcf_path = val();
+                else if (a == "--ref" || a == "-r") ref_path = val();
+                else if (a == "--tsv" || a == "-t") tsv_path = val();
+                else if (a == "--window-len" || a == "-w") wl = std::stoull(val());
+                else if (a == "--unsupported-allele-warning-only" || a == "-u") warn_only = true;
+                else if (a == "-v" || a == "--verbose") {}
+                else if (!a.empty() && a[0] != '-') bam_path = a;
+                else throw Error("unknown argument " + a);
+            }
+            BamData bam;
+            load_bam(bam_path, bam);
+            VcfData vcf;
+            load_vcf(vcf_path, vcf);
+            IndexedFasta fasta(ref_path);
+            NormalOutput nout;
+            load_gene_inputs(std::cin, bam, vcf, fasta, warn_only, [&](GeneInput& gi) { mp_oracle::normal_phase_gene(gi, bam.reads, wl, nout); },
+                             /*use_three_prime_utr=*/false);
+            std::fwrite(nout.fasta.data(), 1, nout.fasta.size(), stdout);
+            write_file(tsv_path, nout.tsv);
+            return 0;
+        }
+        if (sub != "somatic") throw Error("oracle_cli: only `somatic`, `normal`, `synth` and `build_reference` are available");
         std::string bam_path, vcf_path, ref_path, tsv_path = "info.tsv", normal_path = "normal.fasta", stats_path;
         uint64_t window_len = 27;
         bool warn_only = false;

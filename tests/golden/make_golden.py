@@ -321,6 +321,33 @@ def main():
                                     seq[a + k - lo] = ch
                             break
             print("  %s: %d/%d `normal` tiles placed by id" % (gfa, placed, len(tiles)))
+            # the remaining tiles are splice-merged windows (last bases of one CDS exon + first bases of the next,
+            # src/normal_microphasing.rs:1164-1233): use them to fill the few boundary bases no read covers
+            filled = 0
+            for tid, t in txs.items():
+                cds = sorted((a, b) for (a, b, _fr) in t["cds"])
+                for rid, tile in tiles:
+                    if len(tile) != 27:
+                        continue
+                    for (a0, a1), (b0, b1) in zip(cds, cds[1:]):
+                        for k in range(1, 27):
+                            pos = list(range(a1 - (27 - k), a1)) + list(range(b0, b0 + k))
+                            if pos[0] < a0 or pos[-1] >= b1:
+                                continue
+                            known = mism = 0
+                            for ch, q in zip(tile, pos):
+                                base = seq[q - lo]
+                                if base == "N":
+                                    continue
+                                known += 1
+                                if base.upper() != ch.upper():
+                                    mism += 1
+                            if known >= 20 and mism == 0 and known < 27:
+                                for ch, q in zip(tile, pos):
+                                    if seq[q - lo] == "N" and ch.isupper():
+                                        seq[q - lo] = ch
+                                        filled += 1
+            print("  %s: %d boundary bases filled from splice-merged tiles" % (gfa, filled))
         n_unknown = sum(1 for c in seq if c == "N")
         fa = os.path.join(d, chrom + ".mini.fa")
         with open(fa, "w") as f:

@@ -52,3 +52,22 @@ def test_oracle_build_reference_matches_reference_fixture(built, tmp_path):
     assert r.stdout == open(os.path.join(GOLDEN, "test_build", "expected_output", "reference_peptides.fasta"), "rb").read()
     want = m.decode_bincode_set(open(os.path.join(GOLDEN, "test_filter", "reference.binary"), "rb").read())
     assert m.decode_bincode_set(out.read_bytes()) == want == {b"MRRR", b"PEXD", b"LWHL", b"STDQ"}
+
+
+NORMAL_FIXTURES = {
+    # tests/lib.rs:237-249 (test_forward_germline) and :273-285 (splice_test_forward_germline): only the FASTA is diffed
+    "test_forward": ("forward_test.bam", "forward_test.germline.vcf", "forward_test.gtf", "chr14.mini.fa", "forward_test.germline.fa"),
+    "splice_forward_test": ("INSIG1.test.bam", "INSIG1.test.germline.vcf", "INSIG1.test.gtf", "chr7.mini.fa", "splice_forward_test.germline.fa"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(NORMAL_FIXTURES))
+def test_normal_oracle_matches_reference_expected_output(built, tmp_path, name):
+    bam, vcf, gtf, fa, exp = NORMAL_FIXTURES[name]
+    d = os.path.join(GOLDEN, name)
+    with open(os.path.join(d, gtf), "rb") as g:
+        r = subprocess.run([ORACLE_CLI, "normal", os.path.join(d, bam), "--variants", os.path.join(d, vcf), "--ref", os.path.join(d, fa),
+                            "--tsv", str(tmp_path / "n.tsv")], stdin=g, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == open(os.path.join(d, "expected_output", exp), "rb").read()
+    assert (tmp_path / "n.tsv").read_bytes().count(b"\n") == r.stdout.count(b">") + 1
