@@ -27,7 +27,10 @@ typedef struct mp_dataset mp_dataset;
 typedef struct mp_batch mp_batch;
 typedef struct mp_results mp_results;
 
-enum { MP_MODE_SOMATIC = 0 };
+enum {
+    MP_MODE_SOMATIC = 0, /* microphasing::phase   (src/microphasing.rs)        : stdout FASTA, normal FASTA, TSV */
+    MP_MODE_NORMAL = 1   /* normal_microphasing::phase (src/normal_microphasing.rs): stdout FASTA, TSV           */
+};
 
 /* Context. device >= 0: HIP device ordinal. device == -1: host-only context (data sets and
  * planning work, anything that needs the kernels fails loudly). */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libmicrophaser_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "microphaser")
 
 MODE_SOMATIC = 0
+MODE_NORMAL = 1  # `microphaser normal` (src/normal_microphasing.rs): fasta + tsv, no normal_fasta
 
 
 def build(verbose=False):

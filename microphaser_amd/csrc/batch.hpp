@@ -31,6 +31,7 @@ struct GeneHost {           // host-only per-gene bookkeeping
 
 struct Batch {
     uint64_t window_len = 27;
+    bool normal = false;                  // `microphaser normal` semantics (src/normal_microphasing.rs) instead of `somatic`
     // ---- genes
     std::vector<GeneHost> genes;
     std::vector<uint32_t> g_read_off, g_var_off, g_start;  // per gene (+1 for the offsets)
@@ -65,11 +66,10 @@ struct Batch {
     uint64_t bytes_k1_out() const;
 };
 
-// Build the batch + plan for a list of loaded genes. `mapq_min` = 5 for `somatic`
-// (reference: src/microphasing.rs:910), 0 for `normal`.
-void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& reads, uint64_t window_len, uint8_t mapq_min, Batch& out);
-inline void build_batch(const std::vector<GeneInput>& genes, const ReadStore& reads, uint64_t window_len, uint8_t mapq_min, Batch& out) {
-    build_batch(genes.data(), genes.size(), reads, window_len, mapq_min, out);
+// Build the batch + plan for a list of loaded genes, for `somatic` (normal = false) or `normal` mode.
+void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& reads, uint64_t window_len, bool normal, Batch& out);
+inline void build_batch(const std::vector<GeneInput>& genes, const ReadStore& reads, uint64_t window_len, bool normal, Batch& out) {
+    build_batch(genes.data(), genes.size(), reads, window_len, normal, out);
 }
 
 }  // namespace mp

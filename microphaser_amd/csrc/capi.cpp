@@ -29,7 +29,7 @@ struct mp_batch {
     uint64_t sum_wlen = 0, sum_cols = 0;  // cached for the byte accounting
 };
 struct mp_results {
-    SomaticOutput out;
+    SomaticOutput out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty
 };
 struct mp_peptides {
     PeptideResult res;
@@ -128,12 +128,13 @@ void mp_dataset_free(mp_dataset* ds) { delete ds; }
 
 int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, uint32_t gene_lo, uint32_t gene_hi, mp_batch** out) {
     return guarded(ctx, [&] {
-        if (mode != MP_MODE_SOMATIC) throw Error("only MP_MODE_SOMATIC is implemented");
-        if (gene_hi > ds->ds.genes.size()) gene_hi = uint32_t(ds->ds.genes.size());
+        if (mode != MP_MODE_SOMATIC && mode != MP_MODE_NORMAL) throw Error("unknown mode");
+        const std::vector<GeneInput>& genes = dataset_genes(const_cast<Dataset&>(ds->ds), mode == MP_MODE_NORMAL);
+        if (gene_hi > genes.size()) gene_hi = uint32_t(genes.size());
         if (gene_lo > gene_hi) gene_lo = gene_hi;
         std::unique_ptr<mp_batch> b(new mp_batch());
         b->reads = &ds->ds.bam.reads;
-        build_batch(ds->ds.genes.data() + gene_lo, size_t(gene_hi - gene_lo), *b->reads, window_len, /*mapq_min=*/5, b->batch);  // src/microphasing.rs:910
+        build_batch(genes.data() + gene_lo, size_t(gene_hi - gene_lo), *b->reads, window_len, mode == MP_MODE_NORMAL, b->batch);
         if (ctx->dev) {
             ctx->dev->upload(b->batch);
             b->uploaded = true;
@@ -180,7 +181,15 @@ int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
         HostResults hr;
         dev.download(hr);
         std::unique_ptr<mp_results> r(new mp_results());
-        consume_batch(batch->batch, hr, r->out);
+        if (batch->batch.normal) {
+            NormalOutput no;
+            consume_batch_normal(batch->batch, hr, no);
+            r->out.fasta = std::move(no.fasta);
+            r->out.tsv = std::move(no.tsv);
+            r->out.n_windows = no.n_windows;
+        } else {
+            consume_batch(batch->batch, hr, r->out);
+        }
         *out = r.release();
     });
 }

@@ -63,8 +63,10 @@ int main(int argc, char** argv) {
         mp_destroy(ctx);
         return 0;
     }
-    if (sub != "somatic") {
-        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic` and `build_reference` are available\n", sub.c_str());
+    // microphaser normal <normal.bam> --ref F --variants V [--tsv info.tsv] [-w 27] < gtf > fasta   (src/germline_cli.yaml, src/main.rs:104-143)
+    const bool normal_mode = sub == "normal";
+    if (sub != "somatic" && !normal_mode) {
+        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic`, `normal` and `build_reference` are available\n", sub.c_str());
         return 1;
     }
     std::string bam, vcf, ref, tsv = "info.tsv", normal = "normal.fasta";
@@ -79,7 +81,7 @@ int main(int argc, char** argv) {
         if (a == "--variants" || a == "-b") vcf = val();
         else if (a == "--ref" || a == "-r") ref = val();
         else if (a == "--tsv" || a == "-t") tsv = val();
-        else if (a == "--normal-output" || a == "-n") normal = val();
+        else if (!normal_mode && (a == "--normal-output" || a == "-n")) normal = val();
         else if (a == "--window-len" || a == "-w") window_len = std::strtoull(val(), nullptr, 10);
         else if (a == "--unsupported-allele-warning-only" || a == "-u") warn_only = 1;
         else if (a == "--device") device = std::atoi(val());
@@ -87,18 +89,18 @@ int main(int argc, char** argv) {
         else if (!a.empty() && a[0] != '-') bam = a;
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
     }
-    if (bam.empty() || vcf.empty() || ref.empty()) { std::fprintf(stderr, "tumor BAM, --variants and --ref are required\n"); return 1; }
+    if (bam.empty() || vcf.empty() || ref.empty()) { std::fprintf(stderr, "the sample BAM, --variants and --ref are required\n"); return 1; }
     mp_ctx* ctx = nullptr;
     if (mp_create(device, &ctx) != 0) { int rc = fail(ctx, "mp_create"); mp_destroy(ctx); return rc; }
     mp_dataset* ds = nullptr;
     if (mp_dataset_load(ctx, bam.c_str(), vcf.c_str(), ref.c_str(), nullptr, warn_only, &ds) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
     mp_results* res = nullptr;
-    if (mp_phase_dataset(ctx, ds, MP_MODE_SOMATIC, window_len, &res) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
+    if (mp_phase_dataset(ctx, ds, normal_mode ? MP_MODE_NORMAL : MP_MODE_SOMATIC, window_len, &res) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
     size_t n = 0;
     const char* p = mp_results_fasta(res, &n);
     std::fwrite(p, 1, n, stdout);
     p = mp_results_normal_fasta(res, &n);
-    if (!write_file(normal, p, n)) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
+    if (!normal_mode && !write_file(normal, p, n)) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
     p = mp_results_tsv(res, &n);
     if (!write_file(tsv, p, n)) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
     mp_results_free(res);

@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <limits>
 #include <thread>
@@ -123,6 +124,7 @@ IDRecord record_add_freq(const IDRecord& self, double freq) {
 }
 
 struct ConsumerHooks {
+    static constexpr bool kNormal = false;
     const Batch& b;
     const HostResults& res;
     const GeneHost& gh;
@@ -464,8 +466,209 @@ struct ConsumerHooks {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// `microphaser normal` (reference: src/normal_microphasing.rs). Same division of labour: the device supplies
+// haplotype keys, counts, depth (K2) and sequence / variant profile / first-or-last-codon stop / id (K3 normal + K3b);
+// the host keeps frameshifts, hap_vec / prev_hap_vec and the (sequence-concatenating) splice-side merge.
 namespace {
-void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1, SomaticOutput& out) {
+
+// IDRecord::update / add_freq of the normal mode (reference: src/normal_microphasing.rs:105-146, :148-179)
+NormalRecord nrecord_update(const NormalRecord& self, const NormalRecord& rec, uint64_t offset, const std::vector<uint8_t>& seq) {
+    NormalRecord r = self;
+    r.id = haplotype_id(seq.data(), seq.size(), self.transcript, offset, self.strand.empty() ? '?' : self.strand[0]);
+    r.somatic_positions = self.somatic_positions + rec.somatic_positions;
+    r.somatic_aa_change = self.somatic_aa_change + rec.somatic_aa_change;
+    r.germline_positions = self.germline_positions + rec.germline_positions;
+    r.germline_aa_change = self.germline_aa_change + rec.germline_aa_change;
+    r.offset = offset + self.offset;
+    r.freq = self.freq * rec.freq;
+    r.nvar = self.nvar + rec.nvar;
+    r.nsomatic = self.nsomatic + rec.nsomatic;
+    r.nvariant_sites = self.nvariant_sites + rec.nvariant_sites;
+    r.nsomvariant_sites = self.nsomvariant_sites + rec.nsomvariant_sites;
+    r.variant_sites = self.variant_sites + rec.variant_sites;
+    r.peptide_sequence.assign(reinterpret_cast<const char*>(seq.data()), seq.size());
+    return r;
+}
+NormalRecord nrecord_add_freq(const NormalRecord& self, double freq) {
+    NormalRecord r = self;
+    if (freq > 0.0) {
+        if (self.nvar == 0) throw Error("reference would panic: attempt to subtract with overflow (add_freq nvar)");
+        r.nvar = self.nvar - 1;
+    }
+    if (r.nvar < self.nsomatic) r.nsomatic = self.nsomatic - 1;
+    r.freq = self.freq + freq;
+    return r;
+}
+
+struct NormalConsumerHooks {
+    static constexpr bool kNormal = true;
+    const Batch& b;
+    const HostResults& res;
+    const GeneHost& gh;
+    const Gene& gene;
+    const Transcript& transcript;
+    const TxDev& T;
+    NormalOutput& out;
+    uint64_t window_len;
+    size_t next_step = 0, cur_step = 0;
+    bool is_fwd;
+
+    void on_exon(const ExonGeom&) {}
+    void routed(bool) {}
+
+    void on_step(const ExonGeom&, const StepGeom& sg, const std::vector<size_t>&) {
+        if (next_step >= T.n_steps) throw Error("internal error: consumer walked past the planned schedule");
+        cur_step = T.step_off + next_step++;
+        const Step& st = b.steps[cur_step];
+        if (st.sso != uint32_t(sg.sso) || uint64_t(st.wlen) != sg.splice_end - sg.sso)
+            throw Error("internal error: consumer and planner schedules diverged");
+    }
+
+    // print_haplotypes (reference: src/normal_microphasing.rs:341-647)
+    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
+        const Step& st = b.steps[cur_step];
+        if (!(st.flags & SF_PRINT)) throw Error("internal error: print_haplotypes at a step the planner did not schedule");
+        const WinStatic& ws = b.wins[st.win];
+        const WinDyn& wd = res.win_dyn[st.win];
+        if (!(wd.flags & WD_DONE)) throw Error("internal error: window was not computed on the device");
+        if (frame == 0) out.n_windows++;
+        const std::vector<Variant>& gvars = gh.input->variants;
+        const uint32_t ncols = ws.ncols;
+        std::vector<const Variant*> variants(ncols);
+        for (uint32_t j = 0; j < ncols; j++) variants[j] = &gvars[b.win_cols[ws.col_off + (is_fwd ? j : ncols - 1 - j)].f];
+        const char* strand = is_fwd ? "Forward" : "Reverse";
+        const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
+        const uint64_t wl = eg.ewl;
+        const bool boundary = (ws.need_recs & WS_CARRY) != 0;
+        const uint32_t nrows = wd.nrows;
+        std::vector<HapSeq> haplotypes_vec;
+        bool any_counted = false;
+        for (uint32_t k = 0; k < wd.ngroups; k++) any_counted |= res.groups[uint64_t(wd.group_off) + k].count != 0;
+        for (uint32_t k = 0; k < wd.ngroups; k++) {
+            const uint64_t slot = uint64_t(wd.group_off) + k;
+            const Group& G = res.groups[slot];
+            // the zero-count reference group only stands in when no read covers the window (:388-390)
+            if (G.count == 0 && (any_counted || G.hap != 0)) continue;
+            const GroupSum& gs = res.gsum[slot];
+            if (!(gs.flags & GS_VALID) || !(gs.flags & GS_HAS_REC))
+                throw Error("internal error: haplotype was not processed by the window-sequence kernel");
+            if (gs.flags & GS_BROKE) throw Error("internal error: haplotype sequence exceeds the record capacity");
+            const bool stop_gain = gs.flags & GS_STOP, insertion = gs.flags & GS_INSERTION;
+            if (stop_gain && splice_pos != 2) continue;  // :503-507
+            const HapRecHdr* rec = res.rec(gs.rec);
+            const uint8_t* rseq = res.rec_seq(gs.rec);
+            uint64_t prof_som;
+            std::memcpy(&prof_som, res.rec_germ(gs.rec), 8);
+            const uint64_t seq_len = rec->seq_len;
+            const double freq = double(G.count) / double(nrows);  // NaN when no read covers the window
+            HapSeq hs;
+            if (boundary || !eg.is_short) {
+                NormalRecord& r = hs.nrecord;
+                const uint64_t this_window_len = seq_len < wl ? seq_len : wl;
+                auto sl = [&](uint64_t a, uint64_t e) {
+                    if (a > e || e > seq_len) throw Error("reference would panic: slice index out of range");
+                    return std::string(reinterpret_cast<const char*>(rseq) + a, e - a);
+                };
+                std::string peptide = splice_pos == 1 ? sl(splice_gap, seq_len)
+                                      : splice_pos == 0 ? (insertion ? sl(0, seq_len) : sl(0, this_window_len)) : sl(0, seq_len);
+                if (!(gs.flags & GS_ID_VALID)) throw Error("internal error: haplotype id was not computed on the device");
+                char idb[20];
+                std::snprintf(idb, sizeof idb, "%015llx%c", (unsigned long long)rec->id60, strand[0]);
+                r.id = idb;
+                auto add = [](std::string& s, const std::string& x, bool& first) { if (!first) s += "|"; s += x; first = false; };
+                bool f1 = true, f2 = true, f3 = true, f4 = true, f5 = true;
+                uint32_t n_sites = 0, n_som_sites = 0;
+                for (uint32_t c = 0; c < ncols; c++) {  // :531-557 (0-based positions; profile index = visit order)
+                    if (c >= rec->prof_len) break;
+                    const Variant& v = *variants[c];
+                    if ((rec->prof_set >> c) & 1) {
+                        if ((prof_som >> c) & 1) { add(r.somatic_positions, std::to_string(v.pos), f1); add(r.somatic_aa_change, v.prot_change, f2); }
+                        else { add(r.germline_positions, std::to_string(v.pos), f3); add(r.germline_aa_change, v.prot_change, f4); }
+                    }
+                    if (c == 0 || v.pos != variants[c - 1]->pos) {
+                        n_sites++;
+                        add(r.variant_sites, std::to_string(v.pos), f5);
+                        if (!v.is_germline) n_som_sites++;
+                    }
+                }
+                r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
+                r.offset = offset; r.frame = frame; r.freq = freq; r.depth = nrows;
+                r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
+                r.strand = strand;
+                r.peptide_sequence = std::move(peptide);
+                if (!eg.is_short) {  // :629-644
+                    if (splice_pos == 1) {
+                        if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
+                        write_fasta(out.fasta, r.id, rseq + splice_gap, seq_len - splice_gap);
+                    } else if (splice_pos == 0) {
+                        if (wl > seq_len) throw Error("reference would panic: slice index out of range");
+                        write_fasta(out.fasta, r.id, rseq, size_t(wl));
+                    }
+                    write_normal_tsv_record(out, r);
+                }
+                hs.sequence.assign(rseq, rseq + seq_len);
+                r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);  // carried record: unsliced (:618-625)
+            }
+            haplotypes_vec.push_back(std::move(hs));
+        }
+        return {std::move(haplotypes_vec), std::move(fsf)};
+    }
+
+    // splice-side merge (reference: src/normal_microphasing.rs:1145-1250)
+    void splice_merge(const ExonGeom& eg, const StepGeom& sg, uint64_t exon_rest, std::map<uint64_t, uint64_t>&, FsFreq&,
+                      std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec) {
+        const std::vector<HapSeq>& first_hap_vec = is_fwd ? hap_vec : prev_hap_vec;
+        const std::vector<HapSeq>& sec_hap_vec = is_fwd ? prev_hap_vec : hap_vec;
+        using Bytes = std::vector<uint8_t>;
+        std::map<std::pair<uint64_t, Bytes>, NormalRecord> output_map;
+        std::vector<HapSeq> new_hap_vec;
+        for (const HapSeq& hapseq : first_hap_vec) {
+            for (const HapSeq& prev_hapseq : sec_hap_vec) {
+                Bytes prev_sequence = prev_hapseq.sequence;
+                const NormalRecord& prev_record = prev_hapseq.nrecord;
+                prev_sequence.insert(prev_sequence.end(), hapseq.sequence.begin(), hapseq.sequence.end());
+                if (eg.is_short) {
+                    HapSeq nh;
+                    nh.sequence = prev_sequence;
+                    nh.nrecord = nrecord_update(prev_record, hapseq.nrecord, 0, prev_sequence);
+                    new_hap_vec.push_back(std::move(nh));
+                }
+                uint64_t splice_offset = 3;
+                if (!is_fwd && exon_rest < 3) splice_offset += exon_rest;
+                size_t end_offset = 3;
+                if (sg.is_last_exon_window) end_offset = 0;
+                if (uint64_t(prev_sequence.size()) < 2 * window_len) {
+                    if (is_fwd) splice_offset = 0; else end_offset = 0;
+                }
+                for (;;) {
+                    if (end_offset > prev_sequence.size()) throw Error("reference would panic: attempt to subtract with overflow (merge)");
+                    if (!(splice_offset + window_len <= uint64_t(prev_sequence.size() - end_offset))) break;
+                    Bytes out_seq(prev_sequence.begin() + long(splice_offset), prev_sequence.begin() + long(splice_offset + window_len));
+                    NormalRecord out_record = nrecord_update(prev_record, hapseq.nrecord, splice_offset, out_seq);
+                    auto key = std::make_pair(splice_offset, out_seq);
+                    auto fit = output_map.find(key);
+                    const double old_freq = fit == output_map.end() ? 0.0 : fit->second.freq;
+                    output_map[key] = nrecord_add_freq(out_record, old_freq);
+                    splice_offset += 3;
+                }
+            }
+        }
+        if (eg.is_short && !eg.is_last) {
+            prev_hap_vec = std::move(new_hap_vec);
+        } else {
+            for (const auto& kv : output_map) {
+                const Bytes& out_seq = kv.first.second;
+                if (out_seq.size() < window_len) throw Error("reference would panic: slice index out of range");
+                write_fasta(out.fasta, kv.second.id, out_seq.data(), size_t(window_len));
+                write_normal_tsv_record(out, kv.second);
+            }
+        }
+    }
+};
+
+template <class Hooks, class Out>
+void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1, Out& out) {
     for (size_t g = g0; g < g1; g++) {
         const GeneHost& gh = b.genes[g];
         const GeneInput& gi = *gh.input;
@@ -473,20 +676,23 @@ void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1,
         for (uint32_t k = 0; k < gh.n_tx; k++) {
             const TxDev& T = b.tx[gh.tx_off + k];
             const Transcript& t = gi.gene.transcripts[gh.tx_src[k]];
-            ConsumerHooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
+            Hooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
             walk_transcript(gi.gene, t, vi, gh.max_read_len, b.window_len, hooks);
         }
     }
 }
-}  // namespace
+
+void append_part(SomaticOutput& out, SomaticOutput& p) { out.normal_fasta += p.normal_fasta; }
+void append_part(NormalOutput&, NormalOutput&) {}
 
 // Genes are independent (no state crosses phase_gene calls), so the host walk is sharded over threads by gene range and
 // the per-range streams are concatenated in gene order; the TSV header is kept from the first range that wrote a record.
-void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
+template <class Hooks, class Out>
+void consume_sharded(const Batch& b, const HostResults& res, Out& out) {
     size_t nthreads = host_threads();
     const size_t ng = b.genes.size();
     if (nthreads > ng) nthreads = ng ? ng : 1;
-    if (nthreads <= 1) { consume_range(b, res, 0, ng, out); return; }
+    if (nthreads <= 1) { consume_range<Hooks>(b, res, 0, ng, out); return; }
     // balance by planned steps
     std::vector<uint64_t> cost(ng + 1, 0);
     for (size_t g = 0; g < ng; g++) {
@@ -502,28 +708,40 @@ void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
         if (cut[t] > ng) cut[t] = ng;
         if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     }
-    std::vector<SomaticOutput> parts(nthreads);
+    std::vector<Out> parts(nthreads);
     std::vector<std::string> errors(nthreads);
     std::vector<std::thread> th;
     for (size_t t = 0; t < nthreads; t++)
         th.emplace_back([&, t] {
-            try { consume_range(b, res, cut[t], cut[t + 1], parts[t]); }
+            try { consume_range<Hooks>(b, res, cut[t], cut[t + 1], parts[t]); }
             catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
         });
     for (auto& x : th) x.join();
     for (size_t t = 0; t < nthreads; t++)
         if (!errors[t].empty()) throw Error(errors[t]);  // the first failing gene range in gene order, like a sequential run
     for (size_t t = 0; t < nthreads; t++) {
-        SomaticOutput& p = parts[t];
+        Out& p = parts[t];
         out.fasta += p.fasta;
-        out.normal_fasta += p.normal_fasta;
+        append_part(out, p);
         out.n_windows += p.n_windows;
         if (!p.tsv.empty()) {
             if (!out.tsv_header_written) { out.tsv += p.tsv; out.tsv_header_written = true; }
             else out.tsv.append(p.tsv, p.tsv.find('\n') + 1, std::string::npos);
         }
-        p = SomaticOutput();
+        p = Out();
     }
+}
+
+}  // namespace
+
+void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
+    if (b.normal) throw Error("internal error: somatic consumer on a normal-mode batch");
+    consume_sharded<ConsumerHooks>(b, res, out);
+}
+
+void consume_batch_normal(const Batch& b, const HostResults& res, NormalOutput& out) {
+    if (!b.normal) throw Error("internal error: normal consumer on a somatic-mode batch");
+    consume_sharded<NormalConsumerHooks>(b, res, out);
 }
 
 }  // namespace mp

@@ -10,4 +10,8 @@ namespace mp {
 // print_haplotypes call from the device results.
 void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out);
 
+// The same for `microphaser normal` (reference: src/normal_microphasing.rs:650-1279); the batch must have been planned
+// with normal = true.
+void consume_batch_normal(const Batch& b, const HostResults& res, NormalOutput& out);
+
 }  // namespace mp

@@ -95,6 +95,7 @@ void DeviceContext::upload(const Batch& b) {
     d_.n_tx = uint32_t(b.tx.size());
     d_.n_wins = uint32_t(b.wins.size());
     d_.mask_words = b.mask_words;
+    d_.normal = b.normal ? 1u : 0u;
     d_.seq_cap = b.seq_cap;
     d_.rec_stride = hap_rec_stride(b.seq_cap);
     // K1 outputs

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             const uint32_t kind = info[u] & VI_KIND_MASK;
             bool s = false, q = false;
             if (kind == 0) {  // SNV (:97-112, :80-92)
-                q = qb[u] < 10;
+                q = !d.normal && qb[u] < 10;  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
                 if (!q) {
                     int p = simple ? int(vpos[u] - rpos) : cigar_read_pos_dev(cig, ncig, rpos, vpos[u]);
                     if (simple && uint32_t(p) >= (c0 >> 4)) p = -1;
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     const uint32_t vbase = d.g_var_off[T.gene];
     const bool is_rev = T.strand != 0;
     const uint32_t W = d.mask_words;
+    const bool normal = d.normal != 0;  // `microphaser normal`: no qualities / frames / pending rows, other bit order at push_read
 
     __shared__ uint32_t colf[64];     // forward variant index (gene-relative) of each live column
     __shared__ uint32_t colinfo[64];  // v_info | start-loss bit 31
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
             for (int r = 0; r < RPL; r++) {
                 uint32_t st = fl[r] & ST_MASK;
                 if (st != ST_EMPTY) {
-                    bool keep = is_rev ? (rs[r] <= sso) : (re[r] >= splice_end);
+                    bool keep = is_rev ? (normal ? rs[r] < sso : rs[r] <= sso) : (re[r] >= splice_end);  // normal: cleanup_reads(sso) (:1001)
                     if (is_rev && (sflags & SF_FULL_RANGE) && st == ST_PENDING) keep = false;  // re-listed below if still in range
                     if (!keep) fl[r] = ST_EMPTY;
                 }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 #pragma unroll
             for (int r = 0; r < RPL; r++) {
                 // a read rejected for bad quality stays rejected until the column set changes (:192-195, :333-335)
-                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso && pver[r] != colver;
+                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso && (normal || pver[r] != colver);
                 any_att |= att[r];
             }
             if (__ballot(any_att)) {
@@ -319,8 +320,9 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                             const uint32_t sh = lo_f - rvl[r];
                             const uint64_t sb = (msup[r] >> sh) & cmask, qb = (mlq[r] >> sh) & cmask;
                             // '+': column j (oldest = 0) is forward index lo_f + j and haplotype bit ncols-1-j -> reverse the run
-                            hap[r] = is_rev ? sb : (__brevll(sb) >> (64 - ncols));
-                            if (qb) { hap[r] = 0; fl[r] |= RF_BAD; }  // :192-195
+                            // `normal` numbers the columns it finds at push time oldest = bit 0 (normal_microphasing.rs:317-319)
+                            hap[r] = (is_rev != normal) ? sb : (__brevll(sb) >> (64 - ncols));
+                            if (qb && !normal) { hap[r] = 0; fl[r] |= RF_BAD; }  // :192-195
                         }
                 } else {
                     __syncthreads();
@@ -331,14 +333,14 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                             if (att[r]) {
                                 bool s, q;
                                 bits_of(r, f, info, s, q);
-                                hap[r] <<= 1;
-                                update_row(r, s, q, info);
+                                if (normal) { if (s) hap[r] |= 1ull << j; }
+                                else { hap[r] <<= 1; update_row(r, s, q, info); }
                             }
                     }
                 }
                 // `contains` (:281-294) only ever matches on the reverse strand (rows keyed by start)
                 bool need_dup = false;
-                if (is_rev) {
+                if (is_rev && !normal) {
 #pragma unroll
                     for (int r = 0; r < RPL; r++) need_dup |= att[r] && !(fl[r] & RF_BAD) && ((rdup[r] >> 31) || any_rows_before);
                 }
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                         else fl[r] = (fl[r] & ~ST_MASK) | ST_ROW;
                     }
             }
-            if (!is_rev) {  // forward: every key is offered exactly once
+            if (!is_rev || normal) {  // forward (and every strand in `normal`): a listed candidate is offered exactly once
 #pragma unroll
                 for (int r = 0; r < RPL; r++)
                     if ((fl[r] & ST_MASK) == ST_PENDING) fl[r] = ST_EMPTY;
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 uint32_t info = d.v_info[vbase + f];
                 uint32_t pos = d.v_pos[vbase + f];
                 if (pos >= T.sl_lo && pos < T.sl_hi) info |= 0x80000000u; else info &= 0x7FFFFFFFu;
+                if (normal) info &= ~(uint32_t(VI_FS_MASK) | 0x80000000u);  // no frames, no start-loss in `normal`
                 __syncthreads();
                 if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
                 if (ncols == 0) { contig = true; f_oldest = f; }
@@ -839,6 +842,133 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     }
 }
 
+// K3 for `microphaser normal` (reference: src/normal_microphasing.rs:341-647): same slots and record layout, but the
+// sequence walk of the normal-sample tool - haplotype bit j is tested directly, a somatic variant is skipped on a
+// haplotype every row carries (:422-426), the second ALT at a position replaces the first (:429-431), a deletion moves
+// window_end (:451-456), one reference base is appended after every variant run (:476), and "stop" means the FIRST
+// ('+') / LAST ('-') codon of the peptide slice. germ_len is 0; the germ area's first 8 bytes hold the somatic subset of
+// the variant profile.
+template <int SEQ_CAP>
+__global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d, uint64_t n_slots) {
+    constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
+    __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t g = uint64_t(blockIdx.x) * K3_THREADS + tid;
+    uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
+    uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
+    uint8_t* seq = refb + K3_REFCAP;
+    uint32_t* germ_dw = slot + (K3_REFCAP + SEQ_CAP) / 4;
+    const uint32_t w = g < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
+    if (w == 0xFFFFFFFFu) return;
+    const WinStatic ws = d.wins[w];
+    const uint32_t vbase = ws.vbase;
+    const Group G = d.groups[g];
+    const uint64_t hap = G.hap;
+    const uint32_t nrows = d.win_dyn[w].nrows;
+    const bool freq_one = G.count != 0 && G.count == nrows;  // |count / nrows - 1| < EPSILON
+    const bool is_rev = (ws.flags & WSF_REVERSE) != 0;
+    const uint32_t ncols = ws.ncols;
+    uint32_t window_end = ws.sso + ws.wlen;
+    const uint8_t* wref = d.ref_pool + ws.ref_off;
+    const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(wref) & 3u);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(wref - mis);
+        const uint32_t ndw = (mis + ws.wlen + 3) >> 2;
+        for (uint32_t k = 0; k < ndw && k < K3_REFCAP / 4; k++) slot[k] = src[k];
+    }
+    const uint32_t staged = min(uint32_t(ws.wlen), uint32_t(K3_REFCAP) - mis);
+    auto ref_at = [&](uint32_t pos) -> uint8_t {
+        uint32_t k = pos - ws.sso;
+        return k < staged ? refb[mis + k] : wref[k];
+    };
+    auto col = [&](uint32_t j) { return d.win_cols[ws.col_off + (is_rev ? (ncols - 1 - j) : j)]; };
+    uint32_t i = ws.sso, j = 0, ns = 0, prof_len = 0, nvar = 0, nsom = 0;
+    uint64_t prof_set = 0, prof_som = 0;
+    bool insertion = false;
+    auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) seq[ns] = c; ns++; };
+    if (ncols == 0) {
+        for (; i < window_end; i++) push_s(ref_at(i));
+    } else {
+        WinCol cj = col(0);
+        while (i < window_end) {
+            while (j < ncols && i == cj.pos) {
+                if (freq_one && !(cj.info & VI_GERMLINE)) {
+                    j++; prof_len++;
+                    if (j < ncols) cj = col(j);
+                    continue;
+                }
+                if ((hap >> j) & 1) {
+                    if (j + 1 < ncols) {
+                        const WinCol nx = col(j + 1);
+                        if (nx.pos == i) { j++; cj = nx; }
+                    }
+                    const uint32_t kind = cj.info & VI_KIND_MASK;
+                    const uint8_t r = ref_at(i);
+                    if (kind == 0) {
+                        const uint8_t alt = uint8_t(cj.info >> VI_ALT_SHIFT);
+                        push_s(is_upper(r) ? to_lower(alt) : alt);
+                        i += 1;
+                    } else if (kind == 1) {
+                        const uint32_t il = d.v_len[vbase + cj.f] + 1;
+                        const uint8_t* ins = d.ins_pool + d.v_insoff[vbase + cj.f];
+                        const bool up = is_upper(r);
+                        for (uint32_t k = 0; k < il; k++) push_s(up ? to_lower(ins[k]) : to_upper(ins[k]));
+                        insertion = true;
+                        i += 1;
+                    } else {
+                        const uint32_t dl = d.v_len[vbase + cj.f];
+                        push_s(r);
+                        i += dl + 1;
+                        window_end += dl + 1;
+                    }
+                    if (prof_len < 64) {
+                        prof_set |= 1ull << prof_len;
+                        if (!(cj.info & VI_GERMLINE)) prof_som |= 1ull << prof_len;
+                    }
+                    if (!(cj.info & VI_GERMLINE)) nsom++;
+                    nvar++;
+                }
+                prof_len++;
+                j++;
+                if (j < ncols) cj = col(j);
+            }
+            push_s(ref_at(i));
+            i += 1;
+        }
+    }
+    const uint32_t seq_len = min(ns, uint32_t(SEQ_CAP));
+    uint32_t nlo = 0, nhi = seq_len;
+    if (ws.splice_pos == 1) nlo = min(uint32_t(ws.splice_gap), seq_len);
+    else if (ws.splice_pos == 0 && !insertion) nhi = min(seq_len, uint32_t(ws.ewl));
+    bool stop = false;
+    if (nhi - nlo >= 3) stop = is_rev ? stop_codon_at(seq, nhi - 3, false) : stop_codon_at(seq, nlo, true);
+    const bool skipped = stop && ws.splice_pos != 2;   // :503-507: such a haplotype produces nothing
+    uint32_t sumflags = GS_VALID | (stop ? GS_STOP : 0) | (insertion ? GS_INSERTION : 0) | (ns > uint32_t(SEQ_CAP) ? uint32_t(GS_BROKE) : 0u);
+    uint32_t recidx = 0;
+    const uint32_t slot_idx = d.g_rec[g];
+    if (slot_idx != 0xFFFFFFFFu) {
+        uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
+        germ_dw[0] = uint32_t(prof_som); germ_dw[1] = uint32_t(prof_som >> 32);
+        out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
+        out[2] = 0; out[3] = 0;
+        out[4] = seq_len | (0u << 8) | (min(prof_len, 255u) << 16) | (min(nvar, 255u) << 24);
+        out[5] = min(nsom, 255u);
+        out[6] = w;
+        out[7] = skipped ? 0u : 1u;
+        const uint32_t* sq = slot + K3_REFCAP / 4;
+#pragma unroll
+        for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
+        sumflags |= GS_HAS_REC | (skipped ? 0u : uint32_t(GS_ID_VALID));
+        recidx = slot_idx;
+    } else {
+        atomicOr(d.err, WD_REC_OVERFLOW);
+    }
+    GroupSum gs;
+    gs.flags = sumflags;
+    gs.rec = recidx;
+    d.gsum[g] = gs;
+}
+
 // K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
 // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
 template <int SEQ_CAP>
@@ -916,6 +1046,16 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {
     if (n_group_slots == 0) return;
     dim3 grid(uint32_t((n_group_slots + K3_THREADS - 1) / K3_THREADS)), block(K3_THREADS);
+    if (d.normal) {
+        switch (d.seq_cap) {
+            case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d, n_group_slots); break;
+            case 112: hipLaunchKernelGGL(k3_window_seq_normal<112>, grid, block, 0, stream, d, n_group_slots); break;
+            case 240: hipLaunchKernelGGL(k3_window_seq_normal<240>, grid, block, 0, stream, d, n_group_slots); break;
+            default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+        }
+        HIP_CHECK_LAUNCH();
+        return;
+    }
     switch (d.seq_cap) {
         case 48: hipLaunchKernelGGL(k3_window_seq<48>, grid, block, 0, stream, d, n_group_slots); break;
         case 112: hipLaunchKernelGGL(k3_window_seq<112>, grid, block, 0, stream, d, n_group_slots); break;

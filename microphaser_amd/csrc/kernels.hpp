@@ -27,6 +27,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint8_t* str_pool;
     const uint32_t* tx_order;
     uint32_t n_reads, n_tx, n_wins, mask_words;
+    uint32_t normal;              // 1: `microphaser normal` semantics (src/normal_microphasing.rs)
     const uint32_t* r_varlo;      // planner: gene-relative index of the first variant with pos >= r_pos
     // K1 output
     uint32_t* r_ncov;             // number of variants (from r_varlo on) whose bits K1 evaluated

@@ -14,7 +14,9 @@ namespace mp {
 
 namespace {
 
-struct PlannerHooks {
+template <bool NORMAL>
+struct PlannerHooksT {
+    static constexpr bool kNormal = NORMAL;
     Batch& b;
     const GeneHost& gh;
     const std::vector<Variant>& vars;
@@ -86,7 +88,8 @@ struct PlannerHooks {
             if (v.kind == VK_DEL) max_len += v.len;
             if (v.kind != VK_SNV) non_snv = true;
         }
-        b.wins.back().need_recs = (non_snv || fs_seen) ? WS_ALL_IDS : 0;
+        b.wins.back().need_recs = (NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0;  // `normal` emits every haplotype
+        if (NORMAL) max_len += 1;  // the unconditional trailing base (src/normal_microphasing.rs:476)
         if (b.wins.back().need_recs) b.steps[cur_step].flags |= SF_NEED_RECS;
         if (max_len > SEQ_CAPS[2])
             throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
@@ -138,6 +141,9 @@ struct PlannerHooks {
         uint64_t lo = sg.cand_lo, hi = sg.cand_hi;
         if (sg.is_first_exon_window) {
             fl |= SF_FULL_RANGE;
+        } else if (NORMAL) {
+            // `normal` has no `contains`: on the '-' strand every in-range read is pushed again at every step
+            // (src/normal_microphasing.rs:942-967, 1010-1017), so the whole range is listed each time
         } else if (!is_fwd && have_prev_cand) {
             hi = std::min(hi, prev_cand_lo);
             if (hi < lo) hi = lo;
@@ -185,9 +191,11 @@ struct PlannerHooks {
 
 }  // namespace
 
-static void build_batch_range(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
+static void build_batch_range(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
+    const uint8_t mapq_min = normal ? 0 : 5;  // src/microphasing.rs:910 vs src/normal_microphasing.rs:676-684
     b = Batch();
     b.window_len = window_len;
+    b.normal = normal;
     b.genes.resize(n_genes);
     uint32_t max_span_vars = 0;
     {   // reserve the big pools once
@@ -315,16 +323,25 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
             // start-loss interval (:1305-1319): the first scheduled exon's first codon
             td.sl_lo = 1; td.sl_hi = 0;
             for (const Interval& ex : t.exons) {
+                if (normal) break;  // `normal` has no start-loss bookkeeping
                 if (ex.start > ex.end) continue;
                 if (t.strand == FORWARD) { td.sl_lo = uint32_t(ex.start); td.sl_hi = uint32_t(ex.start + 3); }
                 else { td.sl_lo = uint32_t(ex.end >= 3 ? ex.end - 3 : 0); td.sl_hi = uint32_t(ex.end); }
                 break;
             }
-            PlannerHooks hooks{b, gh, gi.variants, fwd2rev, t.strand == FORWARD, uint32_t(b.tx.size())};
-            walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks);
-            td.n_steps = uint32_t(b.steps.size()) - td.step_off;
-            b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
-            while (b.seq_cap < hooks.max_seq_len) b.seq_cap = b.seq_cap == SEQ_CAPS[0] ? SEQ_CAPS[1] : SEQ_CAPS[2];
+            auto run = [&](auto& hooks) {
+                walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks);
+                td.n_steps = uint32_t(b.steps.size()) - td.step_off;
+                b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
+                while (b.seq_cap < hooks.max_seq_len) b.seq_cap = b.seq_cap == SEQ_CAPS[0] ? SEQ_CAPS[1] : SEQ_CAPS[2];
+            };
+            if (normal) {
+                PlannerHooksT<true> hooks{b, gh, gi.variants, fwd2rev, t.strand == FORWARD, uint32_t(b.tx.size())};
+                run(hooks);
+            } else {
+                PlannerHooksT<false> hooks{b, gh, gi.variants, fwd2rev, t.strand == FORWARD, uint32_t(b.tx.size())};
+                run(hooks);
+            }
             b.tx.push_back(td);
             gh.tx_src.push_back(uint32_t(ti));
         }
@@ -389,9 +406,9 @@ void merge_batch(Batch& b, Batch& s) {
 }  // namespace
 
 // Genes are independent: plan gene ranges on worker threads, then concatenate the sub-batches in gene order.
-void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, uint8_t mapq_min, Batch& b) {
+void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
     size_t nthreads = std::min(host_threads(), std::max<size_t>(1, n_genes / 8));
-    if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, mapq_min, b); return; }
+    if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, normal, b); return; }
     std::vector<uint64_t> cost(n_genes + 1, 0);
     for (size_t g = 0; g < n_genes; g++) cost[g + 1] = cost[g] + genes[g].reads.size() + genes[g].refseq.size() / 8 + 1;
     std::vector<size_t> cut(nthreads + 1, n_genes);
@@ -406,7 +423,7 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
     std::vector<std::thread> th;
     for (size_t t = 0; t < nthreads; t++)
         th.emplace_back([&, t] {
-            try { build_batch_range(genes + cut[t], cut[t + 1] - cut[t], rs, window_len, mapq_min, parts[t]); }
+            try { build_batch_range(genes + cut[t], cut[t + 1] - cut[t], rs, window_len, normal, parts[t]); }
             catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
         });
     for (auto& x : th) x.join();
@@ -414,6 +431,7 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
         if (!errors[t].empty()) throw Error(errors[t]);
     b = Batch();
     b.window_len = window_len;
+    b.normal = normal;
     for (size_t t = 0; t < nthreads; t++) merge_batch(b, parts[t]);
     b.g_read_off.push_back(uint32_t(b.r_pos.size()));
     b.g_var_off.push_back(uint32_t(b.v_pos.size()));

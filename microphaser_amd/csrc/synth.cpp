@@ -307,13 +307,29 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
     dataset_load_genes(ds, false);
 }
 
-void dataset_load_genes(Dataset& ds, bool warn_only) {
+static void load_genes_into(Dataset& ds, bool warn_only, bool use_utr, std::vector<GeneInput>& out) {
     MemFasta mf;
     for (size_t c = 0; c < ds.contig_names.size(); c++) mf.contigs[ds.contig_names[c]] = &ds.contig_seq[c];
     std::istringstream in(ds.gtf);
-    ds.genes.clear();
+    out.clear();
     load_gene_inputs(in, ds.bam, ds.vcf, ds.fasta ? static_cast<const RefSource&>(*ds.fasta) : static_cast<const RefSource&>(mf),
-                     warn_only, [&](GeneInput& gi) { ds.genes.push_back(std::move(gi)); });
+                     warn_only, [&](GeneInput& gi) { out.push_back(std::move(gi)); }, use_utr);
+}
+
+void dataset_load_genes(Dataset& ds, bool warn_only) {
+    ds.warn_only = warn_only;
+    load_genes_into(ds, warn_only, true, ds.genes);
+    ds.genes_normal.clear();
+    ds.genes_normal_ready = false;
+}
+
+const std::vector<GeneInput>& dataset_genes(Dataset& ds, bool normal) {
+    if (!normal) return ds.genes;
+    if (!ds.genes_normal_ready) {
+        load_genes_into(ds, ds.warn_only, false, ds.genes_normal);
+        ds.genes_normal_ready = true;
+    }
+    return ds.genes_normal;
 }
 
 void dataset_load_files(const std::string& bam, const std::string& vcf, const std::string& fasta, std::istream& gtf,

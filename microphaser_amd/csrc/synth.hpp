@@ -28,10 +28,14 @@ struct Dataset {
     VcfData vcf;
     std::string gtf;
     std::vector<GeneInput> genes;              // protein-coding genes in GTF order, loaded as phase_gene would
+    std::vector<GeneInput> genes_normal;       // the same for `normal` (three_prime_utr records ignored); built on demand
+    bool genes_normal_ready = false;
+    bool warn_only = false;
 };
 
 void synth_generate(const SynthConfig& cfg, Dataset& ds);
 void dataset_load_genes(Dataset& ds, bool unsupported_allele_warning_only);
+const std::vector<GeneInput>& dataset_genes(Dataset& ds, bool normal);  // genes as the given mode's phase() builds them
 void dataset_load_files(const std::string& bam, const std::string& vcf, const std::string& fasta, std::istream& gtf,
                         bool unsupported_allele_warning_only, Dataset& ds);
 void dataset_write_files(const Dataset& ds, const std::string& prefix);  // prefix.{bam,vcf,gtf,fa,fa.fai}

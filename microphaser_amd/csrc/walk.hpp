@@ -25,6 +25,9 @@ using FsFreq = std::map<uint64_t, std::pair<double, bool>>;  // frameshift_frequ
 
 struct HapSeq {  // reference: HaplotypeSeq (microphasing.rs:141-145); record carries the unsliced sequences
     IDRecord record;
+    // `normal` mode (normal_microphasing.rs:182-186): the sequence bytes + its own record type
+    std::vector<uint8_t> sequence;
+    NormalRecord nrecord;
 };
 
 struct ExonGeom {
@@ -69,7 +72,7 @@ struct VarIndex {
 //   void routed(bool to_prev_hap_vec);   // which carry-over vector the last print's haplotypes went to
 //   void splice_merge(const ExonGeom&, const StepGeom&, uint64_t exon_rest, std::map<uint64_t,uint64_t>& frameshifts,
 //                     FsFreq&, std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec);
-//   static constexpr bool kDynamic;   // false: planner (never terminates)
+//   static constexpr bool kNormal;    // true: the control flow of `microphaser normal` (src/normal_microphasing.rs:700-1277)
 template <class Hooks>
 void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIndex& vi, uint64_t max_read_len,
                      uint64_t window_len, Hooks& hooks) {
@@ -96,9 +99,15 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
         eg.start = exon.start;
         eg.end = exon.end;
         uint64_t exon_len = exon.end - exon.start;
-        eg.ceo = exon_count == 1 ? exon.frame : (exon_rest == 0 ? 0 : 3 - exon_rest);
-        eg.is_last = exon_count == exon_number;
-        eg.is_first = exon_count == 1;
+        if constexpr (Hooks::kNormal) {  // src/normal_microphasing.rs:733-742 (enumerate index, exon.frame ignored)
+            eg.ceo = exon_rest == 0 ? 0 : 3 - exon_rest;
+            eg.is_last = ei == exon_number - 1;
+            eg.is_first = ei == 0;
+        } else {
+            eg.ceo = exon_count == 1 ? exon.frame : (exon_rest == 0 ? 0 : 3 - exon_rest);
+            eg.is_last = exon_count == exon_number;
+            eg.is_first = exon_count == 1;
+        }
         eg.is_short = exon_len < 3 ? true : window_len >= exon_len - eg.ceo - (3 - eg.ceo) % 3;
         eg.ewl = !eg.is_short ? window_len : (exon_len - eg.ceo) - ((exon_len - eg.ceo) % 3);
         if (eg.ewl == 0) eg.ewl = exon_len;
@@ -188,7 +197,13 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
             for (size_t k : new_cols) {  // frameshift bookkeeping (:1299-1342); start_loss handled by position interval
                 const Variant& variant = vars[k];
                 uint64_t s = variant.frameshift();
-                if ((s % 3) > 0) {
+                if constexpr (Hooks::kNormal) {  // src/normal_microphasing.rs:1042-1048: no % 3, keyed by end_pos on both strands
+                    if (s > 0) {
+                        std::vector<uint64_t> previous;
+                        for (const auto& kv : frameshifts) previous.push_back(kv.second + s);
+                        for (uint64_t s_ : previous) frameshifts[variant.end_pos()] = s_;
+                    }
+                } else if ((s % 3) > 0) {
                     std::vector<uint64_t> previous;
                     for (const auto& kv : frameshifts) previous.push_back(kv.second + s);
                     for (uint64_t s_ : previous) frameshifts[is_fwd ? variant.end_pos() : variant.pos] = s_ % 3;
@@ -217,28 +232,42 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
                     }
                     auto res = hooks.print(eg, sg, frameshift, std::move(frameshift_frequencies), is_first_exon_window);
                     frameshift_frequencies = std::move(res.second);
-                    if (res.first.empty() || !frameshift_frequencies.count(frameshift)) stopped_frameshift = key;
-                    const bool to_prev = exon_rest < 3 && (!eg.is_short || eg.is_first) && !has_frameshift;  // :1445-1454
+                    bool to_prev;
+                    if constexpr (Hooks::kNormal) {  // src/normal_microphasing.rs:1113-1122
+                        if (res.first.empty()) stopped_frameshift = key;
+                        to_prev = exon_rest < 3 && (!eg.is_short || eg.is_first);
+                    } else {
+                        if (res.first.empty() || !frameshift_frequencies.count(frameshift)) stopped_frameshift = key;
+                        to_prev = exon_rest < 3 && (!eg.is_short || eg.is_first) && !has_frameshift;  // :1445-1454
+                    }
                     if (to_prev) prev_hap_vec = std::move(res.first);
                     else hap_vec = std::move(res.first);
                     hooks.routed(to_prev);
-                    if (frameshift != 0 && frameshift_frequencies.count(frameshift) && frameshift_frequencies.at(frameshift).first == 0.0)
-                        stopped_frameshift = key;
+                    if constexpr (!Hooks::kNormal) {
+                        if (frameshift != 0 && frameshift_frequencies.count(frameshift) && frameshift_frequencies.at(frameshift).first == 0.0)
+                            stopped_frameshift = key;
+                    }
                 }
             }
-            if (frameshift_count == 0 || !main_orf || !frameshift_frequencies.count(0)) {  // :1465-1473
-                frameshifts.clear();
-                break;
-            }
-            if (stopped_frameshift != 3) {  // :1477-1481
-                auto it = frameshifts.find(stopped_frameshift);
-                if (it == frameshifts.end()) throw Error("reference would panic: unwrap on None (stopped_frameshift)");
-                if (it->second != 0) frameshifts.erase(it);
-            }
-            if (frameshifts.empty()) break;
-            if (frameshift_frequencies.at(0).first == 0.0 && frameshifts.size() == 1) {  // :1485-1488
-                frameshifts.clear();
-                break;
+            if constexpr (Hooks::kNormal) {  // src/normal_microphasing.rs:1125-1135
+                if (frameshift_count == 0 || !main_orf) { frameshifts.clear(); break; }
+                frameshifts.erase(stopped_frameshift);
+                if (frameshifts.empty()) break;
+            } else {
+                if (frameshift_count == 0 || !main_orf || !frameshift_frequencies.count(0)) {  // :1465-1473
+                    frameshifts.clear();
+                    break;
+                }
+                if (stopped_frameshift != 3) {  // :1477-1481
+                    auto it = frameshifts.find(stopped_frameshift);
+                    if (it == frameshifts.end()) throw Error("reference would panic: unwrap on None (stopped_frameshift)");
+                    if (it->second != 0) frameshifts.erase(it);
+                }
+                if (frameshifts.empty()) break;
+                if (frameshift_frequencies.at(0).first == 0.0 && frameshifts.size() == 1) {  // :1485-1488
+                    frameshifts.clear();
+                    break;
+                }
             }
             bool at_splice_side = is_fwd ? offset - eg.ceo == exon.start : offset + eg.ewl + eg.ceo == exon.end;  // :1497-1502
             is_first_exon_window = false;

@@ -36,11 +36,12 @@ int main(int argc, char** argv) {
             SynthConfig cfg;
             uint64_t lo = 0, hi = ~0ull, wl = 27;
             std::string stats, prefix;
-            bool skip_panics = false;
+            bool skip_panics = false, normal_mode = false;
             for (int i = 2; i < argc; i++) {
                 std::string a = argv[i];
                 auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + a); return argv[++i]; };
                 if (a == "--seed") cfg.seed = std::stoull(val());
+                else if (a == "--mode") normal_mode = val() == "normal";
                 else if (a == "--transcripts") cfg.n_transcripts = uint32_t(std::stoul(val()));
                 else if (a == "--depth") cfg.depth = std::stod(val());
                 else if (a == "--spacing") cfg.var_spacing = std::stod(val());
@@ -56,22 +57,31 @@ int main(int argc, char** argv) {
             }
             Dataset ds;
             synth_generate(cfg, ds);
-            if (hi > ds.genes.size()) hi = ds.genes.size();
+            const std::vector<GeneInput>& genes = dataset_genes(ds, normal_mode);  // `normal` loads genes without the 3' UTR rule
+            if (hi > genes.size()) hi = genes.size();
             SomaticOutput out;
+            NormalOutput nout;
             auto t0 = std::chrono::steady_clock::now();
             std::string skipped;
             for (uint64_t g = lo; g < hi; g++) {
-                if (!skip_panics) { mp_oracle::phase_gene(ds.genes[g], ds.bam.reads, wl, out); continue; }
+                auto run = [&] {
+                    if (normal_mode) mp_oracle::normal_phase_gene(genes[g], ds.bam.reads, wl, nout);
+                    else mp_oracle::phase_gene(genes[g], ds.bam.reads, wl, out);
+                };
+                if (!skip_panics) { run(); continue; }
                 // test harness mode: a gene on which the reference itself would panic is dropped as a whole
                 SomaticOutput before = out;
+                NormalOutput nbefore = nout;
                 try {
-                    mp_oracle::phase_gene(ds.genes[g], ds.bam.reads, wl, out);
+                    run();
                 } catch (const Error& e) {
                     if (std::string(e.what()).rfind("reference would panic", 0) != 0) throw;
                     out = before;
+                    nout = nbefore;
                     skipped += (skipped.empty() ? "" : ", ") + std::to_string(g);
                 }
             }
+            if (normal_mode) { out.fasta = nout.fasta; out.tsv = nout.tsv; out.n_windows = nout.n_windows; }
             double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (!prefix.empty()) {
                 write_file(prefix + ".fa", out.fasta);

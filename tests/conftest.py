@@ -55,3 +55,10 @@ def run_oracle_files(paths, tmp, window_len=27, extra=()):
     if r.returncode != 0:
         raise RuntimeError("oracle failed: " + r.stderr.decode())
     return {"fa": r.stdout, "normal.fa": open(nfa, "rb").read(), "tsv": open(tsv, "rb").read()}
+
+
+# `microphaser normal` fixtures (reference tests/lib.rs:237-249, :273-285): bam, vcf, gtf, fasta, expected FASTA
+NORMAL_FIXTURES = {
+    "test_forward": ("forward_test.bam", "forward_test.germline.vcf", "forward_test.gtf", "chr14.mini.fa", "forward_test.germline.fa"),
+    "splice_forward_test": ("INSIG1.test.bam", "INSIG1.test.germline.vcf", "INSIG1.test.gtf", "chr7.mini.fa", "splice_forward_test.germline.fa"),
+}

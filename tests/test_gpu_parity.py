@@ -5,7 +5,7 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ORACLE_CLI, SOMATIC_FIXTURES, fixture_paths, read_expected
+from conftest import GOLDEN, NORMAL_FIXTURES, ORACLE_CLI, SOMATIC_FIXTURES, fixture_paths, read_expected
 
 pytestmark = pytest.mark.gpu
 
@@ -140,3 +140,55 @@ def test_gpu_build_reference_rejects_non_acgt_codons(ctx, tmp_path):
     fa.write_text(">x_F\nACGTNACGTACG\n")
     with pytest.raises(m.MicrophaserError, match="reference would panic"):
         ctx.build_reference(str(fa), 4)
+
+
+# ------------------------------------------------------------------ `microphaser normal` (src/normal_microphasing.rs)
+@pytest.mark.parametrize("name", sorted(NORMAL_FIXTURES))
+def test_gpu_normal_mode_matches_reference_expected_output(ctx, tmp_path, name):
+    """The reference's own germline expectations (tests/lib.rs:237-249, :273-285 diff the FASTA only); the TSV, which the
+    reference does not check, is compared with the oracle's."""
+    import microphaser_amd as m
+    bam, vcf, gtf, fa, exp = NORMAL_FIXTURES[name]
+    d = os.path.join(GOLDEN, name)
+    res = ctx.load(os.path.join(d, bam), os.path.join(d, vcf), os.path.join(d, fa), os.path.join(d, gtf)).phase(mode=m.MODE_NORMAL)
+    assert res.fasta == open(os.path.join(d, "expected_output", exp), "rb").read()
+    assert res.normal_fasta == b""
+    with open(os.path.join(d, gtf), "rb") as g:
+        r = subprocess.run([ORACLE_CLI, "normal", os.path.join(d, bam), "--variants", os.path.join(d, vcf), "--ref", os.path.join(d, fa),
+                            "--tsv", str(tmp_path / "n.tsv")], stdin=g, capture_output=True, check=True)
+    assert res.tsv == (tmp_path / "n.tsv").read_bytes()
+
+
+@pytest.mark.parametrize("seed,n,depth,spacing,indel,multi,soft", [(7, 20, 30.0, 5.4, 0.0, 0.0, 0.0), (41, 24, 12.0, 3.0, 0.0, 0.0, 0.0),
+                                                                     (17, 20, 20.0, 5.4, 0.06, 0.1, 0.3)])
+def test_gpu_normal_mode_matches_oracle_on_synthetic_exome(ctx, tmp_path, seed, n, depth, spacing, indel, multi, soft):
+    """Every haplotype of every window is emitted in this mode; '-' strand transcripts re-push their reads at every step
+    (no `contains`), so row counts far exceed the depth. Genes the reference would panic on are dropped on both sides."""
+    import microphaser_amd as m
+    from microphaser_amd.shard import merge_streams
+    prefix = os.path.join(str(tmp_path), "on")
+    r = subprocess.run([ORACLE_CLI, "synth", "--mode", "normal", "--seed", str(seed), "--transcripts", str(n), "--depth", str(depth),
+                        "--spacing", str(spacing), "--indel-rate", str(indel), "--multiallelic-rate", str(multi), "--softmask-rate", str(soft),
+                        "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    st = json.loads(r.stdout)
+    exp = {e: open(prefix + "." + e, "rb").read() for e in ("fa", "tsv")}
+    ds = ctx.synth(seed, n, depth, spacing, indel_rate=indel, multiallelic_rate=multi, softmask_rate=soft)
+    parts, windows, lo = [], 0, 0
+    for g in st["skipped"] + [ds.num_genes]:
+        if g > lo:
+            b = ds.batch(gene_lo=lo, gene_hi=g, mode=m.MODE_NORMAL)
+            b.run()
+            res = b.results()
+            parts.append(dict(fasta=res.fasta, normal_fasta=res.normal_fasta, tsv=res.tsv))
+            windows += res.windows
+        if g < ds.num_genes:
+            with pytest.raises(m.MicrophaserError):
+                b = ds.batch(gene_lo=g, gene_hi=g + 1, mode=m.MODE_NORMAL)
+                b.run()
+                b.results()
+        lo = g + 1
+    got = merge_streams(parts)
+    assert windows == st["windows"]
+    assert got["fasta"] == exp["fa"]
+    assert got["tsv"] == exp["tsv"]
+    assert exp["tsv"].count(b"\n") > 1000

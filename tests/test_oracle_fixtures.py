@@ -9,7 +9,7 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ORACLE_CLI, SOMATIC_FIXTURES, fixture_paths, read_expected, run_oracle_files
+from conftest import NORMAL_FIXTURES, GOLDEN, ORACLE_CLI, SOMATIC_FIXTURES, fixture_paths, read_expected, run_oracle_files
 
 
 @pytest.mark.parametrize("name", sorted(SOMATIC_FIXTURES))
@@ -54,11 +54,6 @@ def test_oracle_build_reference_matches_reference_fixture(built, tmp_path):
     assert m.decode_bincode_set(out.read_bytes()) == want == {b"MRRR", b"PEXD", b"LWHL", b"STDQ"}
 
 
-NORMAL_FIXTURES = {
-    # tests/lib.rs:237-249 (test_forward_germline) and :273-285 (splice_test_forward_germline): only the FASTA is diffed
-    "test_forward": ("forward_test.bam", "forward_test.germline.vcf", "forward_test.gtf", "chr14.mini.fa", "forward_test.germline.fa"),
-    "splice_forward_test": ("INSIG1.test.bam", "INSIG1.test.germline.vcf", "INSIG1.test.gtf", "chr7.mini.fa", "splice_forward_test.germline.fa"),
-}
 
 
 @pytest.mark.parametrize("name", sorted(NORMAL_FIXTURES))
