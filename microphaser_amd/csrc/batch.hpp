@@ -50,6 +50,7 @@ struct Batch {
     // ---- plan
     std::vector<TxDev> tx;
     std::vector<Step> steps;
+    std::vector<uint16_t> step_aux;       // normal mode only, one per Step: candidate key range R | 0x8000 = a new column epoch starts
     std::vector<WinStatic> wins;
     std::vector<WinCol> win_cols;         // column lists of the printing windows
     std::vector<ExonPlan> exons;

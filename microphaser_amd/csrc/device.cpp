@@ -87,6 +87,7 @@ void DeviceContext::upload(const Batch& b) {
     d_.ref_pool = up(b.ref_pool);
     d_.tx = up(b.tx);
     d_.steps = up(b.steps);
+    d_.step_aux = up(b.step_aux);
     d_.wins = up(b.wins);
     d_.win_cols = up(b.win_cols);
     d_.str_pool = up(b.str_pool);
@@ -112,6 +113,7 @@ void DeviceContext::upload(const Batch& b) {
     // first guess: 6 distinct haplotypes per window + chunk slack per transcript
     group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 1024 + 4096;  // slack: one partly used chunk per transcript
     rec_cap_ = group_cap_ / 3 + uint64_t(d_.n_tx + 1) * 128 + 4096;
+    if (b.normal) rec_cap_ = group_cap_;   // every haplotype of every window has a record in this mode
     alloc_outputs();
     HIP_OK(hipStreamSynchronize(stream_));
 }
@@ -154,6 +156,8 @@ void DeviceContext::run(RunTiming& t) {
             rpl_ *= 2;
             continue;
         }
+        if (err & WD_EPOCH_OVERFLOW) throw Error("normal mode: more than 128 live column epochs in one transcript (variant density too high for this build)");
+        if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 1024 distinct haplotypes in one window");
         if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || cur[0] > group_cap_ || cur[1] > rec_cap_) {
             if ((err & WD_GROUP_OVERFLOW) || cur[0] > group_cap_) group_cap_ = std::max<uint64_t>(group_cap_ * 2, cur[0] + 4096);
             if ((err & WD_REC_OVERFLOW) || cur[1] > rec_cap_) rec_cap_ = std::max<uint64_t>(rec_cap_ * 2, cur[1] + 4096);

@@ -161,7 +161,6 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     const uint32_t vbase = d.g_var_off[T.gene];
     const bool is_rev = T.strand != 0;
     const uint32_t W = d.mask_words;
-    const bool normal = d.normal != 0;  // `microphaser normal`: no qualities / frames / pending rows, other bit order at push_read
 
     __shared__ uint32_t colf[64];     // forward variant index (gene-relative) of each live column
     __shared__ uint32_t colinfo[64];  // v_info | start-loss bit 31
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
             for (int r = 0; r < RPL; r++) {
                 uint32_t st = fl[r] & ST_MASK;
                 if (st != ST_EMPTY) {
-                    bool keep = is_rev ? (normal ? rs[r] < sso : rs[r] <= sso) : (re[r] >= splice_end);  // normal: cleanup_reads(sso) (:1001)
+                    bool keep = is_rev ? (rs[r] <= sso) : (re[r] >= splice_end);
                     if (is_rev && (sflags & SF_FULL_RANGE) && st == ST_PENDING) keep = false;  // re-listed below if still in range
                     if (!keep) fl[r] = ST_EMPTY;
                 }
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
 #pragma unroll
             for (int r = 0; r < RPL; r++) {
                 // a read rejected for bad quality stays rejected until the column set changes (:192-195, :333-335)
-                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso && (normal || pver[r] != colver);
+                att[r] = (fl[r] & ST_MASK) == ST_PENDING && re[r] >= splice_end && rs[r] <= sso && pver[r] != colver;
                 any_att |= att[r];
             }
             if (__ballot(any_att)) {
@@ -320,9 +319,8 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                             const uint32_t sh = lo_f - rvl[r];
                             const uint64_t sb = (msup[r] >> sh) & cmask, qb = (mlq[r] >> sh) & cmask;
                             // '+': column j (oldest = 0) is forward index lo_f + j and haplotype bit ncols-1-j -> reverse the run
-                            // `normal` numbers the columns it finds at push time oldest = bit 0 (normal_microphasing.rs:317-319)
-                            hap[r] = (is_rev != normal) ? sb : (__brevll(sb) >> (64 - ncols));
-                            if (qb && !normal) { hap[r] = 0; fl[r] |= RF_BAD; }  // :192-195
+                            hap[r] = is_rev ? sb : (__brevll(sb) >> (64 - ncols));
+                            if (qb) { hap[r] = 0; fl[r] |= RF_BAD; }  // :192-195
                         }
                 } else {
                     __syncthreads();
@@ -333,14 +331,14 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                             if (att[r]) {
                                 bool s, q;
                                 bits_of(r, f, info, s, q);
-                                if (normal) { if (s) hap[r] |= 1ull << j; }
-                                else { hap[r] <<= 1; update_row(r, s, q, info); }
+                                hap[r] <<= 1;
+                                update_row(r, s, q, info);
                             }
                     }
                 }
                 // `contains` (:281-294) only ever matches on the reverse strand (rows keyed by start)
                 bool need_dup = false;
-                if (is_rev && !normal) {
+                if (is_rev) {
 #pragma unroll
                     for (int r = 0; r < RPL; r++) need_dup |= att[r] && !(fl[r] & RF_BAD) && ((rdup[r] >> 31) || any_rows_before);
                 }
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                         else fl[r] = (fl[r] & ~ST_MASK) | ST_ROW;
                     }
             }
-            if (!is_rev || normal) {  // forward (and every strand in `normal`): a listed candidate is offered exactly once
+            if (!is_rev) {  // forward: every key is offered exactly once
 #pragma unroll
                 for (int r = 0; r < RPL; r++)
                     if ((fl[r] & ST_MASK) == ST_PENDING) fl[r] = ST_EMPTY;
@@ -385,7 +383,6 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 uint32_t info = d.v_info[vbase + f];
                 uint32_t pos = d.v_pos[vbase + f];
                 if (pos >= T.sl_lo && pos < T.sl_hi) info |= 0x80000000u; else info &= 0x7FFFFFFFu;
-                if (normal) info &= ~(uint32_t(VI_FS_MASK) | 0x80000000u);  // no frames, no start-loss in `normal`
                 __syncthreads();
                 if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
                 if (ncols == 0) { contig = true; f_oldest = f; }
@@ -564,6 +561,291 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
         if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
     if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
+}
+
+// ====================================================================== K2 (normal)
+// `microphaser normal` replays the same schedule on a different matrix (reference: src/normal_microphasing.rs:218-339):
+// no qualities, frames or `contains`, and push_read numbers the columns it finds OLDEST = bit 0 while extend_right
+// shifts NEWEST into bit 0. Without `contains` a read is pushed again at every step whose candidate key range and window
+// it satisfies, so on the '-' strand (whole range re-scanned every step) the matrix holds ~(read length - window) copies
+// of each read. Copies pushed while the column set did not change ("a column epoch") are identical and stay identical;
+// copies from different epochs differ by a bit permutation. The kernel therefore keeps
+//   * ONE lane slot per live read (listed once per transcript by the planner),
+//   * per live epoch its "recipe" (which variant each haplotype bit holds - a ring that shares head / length with the
+//     column deque: extend_right appends, shrink_left drops the high bits) and its run of windows (sso range, window
+//     length, candidate key range),
+// and at a printing step derives, per (read, epoch), the number of live copies in closed form and the haplotype word
+// from the K1 support mask; haplotypes are counted in an LDS hash table and written in ascending key order.
+constexpr uint32_t K2N_EPOCHS = 128;       // live column epochs of one transcript (ring)
+constexpr uint32_t K2N_TABLE = 1024;       // haplotype hash slots per window
+constexpr uint32_t K2N_GROUP_CHUNK = 1024; // group slots per allocation (>= K2N_TABLE)
+struct EpochMeta { int32_t xmin, xmax; int32_t w, range; };
+
+template <int RPL>
+__global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = d.tx_order[blockIdx.x];
+    const TxDev T = d.tx[t];
+    const uint32_t rbase = d.g_read_off[T.gene];
+    const uint32_t vbase = d.g_var_off[T.gene];
+    const bool is_rev = T.strand != 0;
+    const uint32_t W = d.mask_words;
+
+    __shared__ uint16_t colf[64];                     // column deque: gene-relative forward variant index
+    __shared__ uint16_t recipe[K2N_EPOCHS][64];
+    __shared__ EpochMeta emeta[K2N_EPOCHS];
+    __shared__ unsigned long long tkey[K2N_TABLE];    // haplotype + 1 (0 = free)
+    __shared__ uint32_t tcnt[K2N_TABLE];
+    __shared__ unsigned long long skey[K2N_TABLE];    // compacted (haplotype, count) of the current window
+    __shared__ uint32_t scnt[K2N_TABLE];
+    __shared__ uint32_t ng_lds;
+    for (uint32_t k = lane; k < K2N_TABLE; k += 64) { tkey[k] = 0; tcnt[k] = 0; }
+    if (lane == 0) ng_lds = 0;
+    __syncthreads();
+
+    bool occ[RPL];
+    int32_t rs[RPL], re[RPL];
+    uint32_t rvl[RPL], rcov[RPL], ridx[RPL];
+    uint64_t msup[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; r++) { occ[r] = false; rs[r] = re[r] = 0; rvl[r] = rcov[r] = ridx[r] = 0; msup[r] = 0; }
+
+    uint32_t ncols = 0, head = 0, ep_head = 0, n_ep = 0;
+    uint64_t chunk_pos = 0, chunk_end = 0, rec_pos = 0, rec_end = 0, n_groups_tx = 0;
+    uint32_t sticky_err = 0;
+
+    // supports_variant(read of slot r, variant f) from the K1 mask (reference: normal_microphasing.rs:43-78)
+    auto support = [&](int r, uint32_t f) -> bool {
+        const uint32_t b = f - rvl[r];
+        if (f >= rvl[r] && b < rcov[r]) {
+            if (W == 1) return (msup[r] >> b) & 1;
+            return (d.r_sup[uint64_t(ridx[r]) * W + (b >> 6)] >> (b & 63)) & 1;
+        }
+        const uint32_t kind = d.v_info[vbase + f] & VI_KIND_MASK;   // outside the read: only an indel can match (any op of that length)
+        if (kind != 0) {
+            const uint32_t want = kind == 1 ? 1u : 2u, vlen = d.v_len[vbase + f];
+            const uint32_t* cig = d.cigar_pool + d.r_cigoff[ridx[r]];
+            const uint32_t ncig = d.r_ncig[ridx[r]];
+            for (uint32_t c = 0; c < ncig; c++)
+                if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) return true;
+        }
+        return false;
+    };
+    // live copies of the read in slot r that were pushed during epoch m, at the step with splice_side_offset `sso`:
+    // pushed at window x <=> start in [x - range, x] and end >= x + w (push_read :301-331 + the candidate range :942-967);
+    // '-': cleanup_reads(sso) drops every copy of a read with start >= sso before the pushes of the step (:1001)
+    auto copies = [&](int r, const EpochMeta& m, bool is_current, int32_t sso) -> uint32_t {
+        int32_t lo = max(m.xmin, rs[r]);
+        int32_t hi = min(m.xmax, min(rs[r] + m.range, re[r] - m.w));
+        if (is_rev && rs[r] >= sso) {
+            if (!is_current) return 0;
+            return (lo <= sso && sso <= hi) ? 1u : 0u;
+        }
+        return hi >= lo ? uint32_t(hi - lo + 1) : 0u;
+    };
+
+    for (uint32_t s0 = 0; s0 < T.n_steps; s0 += 64) {
+        const uint32_t nb = min(64u, T.n_steps - s0);
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
+        if (lane < nb) {
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + (T.step_off + s0 + lane));
+            w0 = sp[0]; w1 = sp[1]; w2 = sp[2]; w3 = sp[3]; w4 = sp[4]; w5 = sp[5];
+            w6 = d.step_aux[T.step_off + s0 + lane];
+        }
+        for (uint32_t i = 0; i < nb; i++) {
+            const int32_t sso = int32_t(rdlane(w0, i));
+            const uint32_t cand_lo = rdlane(w1, i), col_hi = rdlane(w2, i), win = rdlane(w3, i);
+            const uint32_t p4 = rdlane(w4, i), p5 = rdlane(w5, i), ax = rdlane(w6, i);
+            const uint32_t cand_n = p4 & 0xFFFF, wlen = (p4 >> 16) & 0xFF, n_del = p4 >> 24;
+            const uint32_t n_add = p5 & 0xFF, sflags = (p5 >> 8) & 0xFF;
+            const int32_t splice_end = sso + int32_t(wlen);
+            const int32_t range = int32_t(ax & 0x7FFF);
+            const bool new_epoch = (ax & 0x8000u) != 0;
+
+            // ---- cleanup_reads (:286-299): a slot is released once no copy of its read can exist or be pushed any more
+#pragma unroll
+            for (int r = 0; r < RPL; r++)
+                if (occ[r] && (is_rev ? rs[r] > sso : re[r] < splice_end)) occ[r] = false;
+            // ---- shrink_left (:239-252): every haplotype keeps its low ncols bits
+            if (n_del) { ncols -= n_del; head = (head + n_del) & 63; }
+            // ---- newly listed reads
+            if (cand_n) {
+                uint32_t left = cand_n, c = cand_lo;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) {
+                    if (left) {
+                        const bool empty = !occ[r];
+                        const uint64_t freem = __ballot(empty);
+                        const uint32_t rank = lanes_below(freem, lane);
+                        if (empty && rank < left) {
+                            const uint32_t gi = rbase + c + rank;
+                            ridx[r] = gi;
+                            rs[r] = int32_t(d.r_pos[gi]);
+                            re[r] = int32_t(d.r_end[gi]);
+                            rvl[r] = d.r_varlo[gi];
+                            rcov[r] = d.r_ncov[gi];
+                            if (W == 1) msup[r] = d.r_sup[gi];
+                            occ[r] = true;
+                        }
+                        const uint32_t took = min(uint32_t(__popcll(freem)), left);
+                        c += took;
+                        left -= took;
+                    }
+                }
+                if (left) sticky_err |= WD_ROW_OVERFLOW;
+            }
+            // ---- the epoch this step's pushes belong to
+            __syncthreads();
+            if (new_epoch || n_ep == 0) {
+                if (n_ep == K2N_EPOCHS) { sticky_err |= WD_EPOCH_OVERFLOW; ep_head = (ep_head + 1) & (K2N_EPOCHS - 1); n_ep--; }
+                const uint32_t e = (ep_head + n_ep) & (K2N_EPOCHS - 1);
+                if (lane < ncols) recipe[e][(head + lane) & 63] = colf[(head + ncols - 1 - lane) & 63];  // oldest column = bit 0 (:317-319)
+                if (lane == 0) { EpochMeta m; m.xmin = sso; m.xmax = sso; m.w = int32_t(wlen); m.range = range; emeta[e] = m; }
+                n_ep++;
+            } else if (lane == 0) {
+                const uint32_t e = (ep_head + n_ep - 1) & (K2N_EPOCHS - 1);
+                if (is_rev) emeta[e].xmin = sso; else emeta[e].xmax = sso;
+            }
+            // ---- extend_right (:254-284): every copy shifts left, the new columns enter at bit 0
+            for (uint32_t a = 0; a < n_add; a++) {
+                const uint32_t tr = col_hi - n_add + a;
+                const uint32_t f = is_rev ? d.v_rev2fwd[vbase + tr] : tr;
+                const uint32_t slot = (head + ncols) & 63;
+                if (lane == 0) colf[slot] = uint16_t(f);
+                for (uint32_t k = lane; k < n_ep; k += 64) recipe[(ep_head + k) & (K2N_EPOCHS - 1)][slot] = uint16_t(f);
+                ncols++;
+            }
+            __syncthreads();
+            // ---- retire the oldest epochs nothing alive was pushed in
+            while (n_ep > 1) {
+                const EpochMeta m = emeta[ep_head];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) any |= occ[r] && copies(r, m, false, sso) != 0;
+                if (__ballot(any)) break;
+                ep_head = (ep_head + 1) & (K2N_EPOCHS - 1);
+                n_ep--;
+            }
+            if (!(sflags & SF_PRINT)) continue;
+
+            // ---- count phase of print_haplotypes (:352-390)
+            uint32_t nrows_l = 0;
+            for (uint32_t k = 0; k < n_ep; k++) {
+                const uint32_t e = (ep_head + k) & (K2N_EPOCHS - 1);
+                const EpochMeta m = emeta[e];
+                uint32_t n[RPL];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) { n[r] = occ[r] ? copies(r, m, k + 1 == n_ep, sso) : 0u; any |= n[r] != 0; }
+                if (!__ballot(any)) continue;
+                uint64_t hv[RPL];
+#pragma unroll
+                for (int r = 0; r < RPL; r++) hv[r] = 0;
+                for (uint32_t p = 0; p < ncols; p++) {
+                    const uint32_t f = recipe[e][(head + p) & 63];
+                    const uint32_t bit = ncols - 1 - p;
+#pragma unroll
+                    for (int r = 0; r < RPL; r++)
+                        if (n[r] && support(r, f)) hv[r] |= 1ull << bit;
+                }
+#pragma unroll
+                for (int r = 0; r < RPL; r++)
+                    if (n[r]) {
+                        nrows_l += n[r];
+                        const unsigned long long key1 = hv[r] + 1ull;
+                        uint32_t slot = uint32_t((hv[r] * 0x9E3779B97F4A7C15ull) >> 54) & (K2N_TABLE - 1);
+                        bool done = false;
+                        for (uint32_t probe = 0; probe < K2N_TABLE && !done; probe++) {
+                            const unsigned long long old = atomicCAS(&tkey[slot], 0ull, key1);
+                            if (old == 0ull) atomicAdd(&ng_lds, 1u);
+                            if (old == 0ull || old == key1) { atomicAdd(&tcnt[slot], n[r]); done = true; }
+                            slot = (slot + 1) & (K2N_TABLE - 1);
+                        }
+                        if (!done) sticky_err |= WD_HAP_OVERFLOW;
+                    }
+            }
+            __syncthreads();
+            uint32_t nrows = nrows_l;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) nrows += __shfl_xor(nrows, off, 64);
+            // compact the table (and leave it clean for the next window)
+            uint32_t ng = 0;
+            for (uint32_t s = 0; s < K2N_TABLE / 64; s++) {
+                const uint32_t idx = s * 64 + lane;
+                const unsigned long long kk = tkey[idx];
+                const bool o = kk != 0ull;
+                const uint64_t m = __ballot(o);
+                if (o) {
+                    const uint32_t pos = ng + lanes_below(m, lane);
+                    skey[pos] = kk - 1ull;
+                    scnt[pos] = tcnt[idx];
+                    tkey[idx] = 0ull;
+                    tcnt[idx] = 0;
+                }
+                ng += uint32_t(__popcll(m));
+            }
+            if (ng == 0) {  // no read covers the window: the reference haplotype stands in with count 0 (:388-390)
+                if (lane == 0) { skey[0] = 0ull; scnt[0] = 0; }
+                ng = 1;
+            }
+            if (lane == 0) ng_lds = 0;
+            __syncthreads();
+            uint32_t werr = sticky_err;
+            // group slots + one HapRec slot per haplotype (every haplotype of every window can be emitted in this mode)
+            if (chunk_pos + ng > chunk_end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(d.cursors, (unsigned long long)K2N_GROUP_CHUNK);
+                const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                chunk_pos = (uint64_t(bhi) << 32) | blo;
+                chunk_end = chunk_pos + K2N_GROUP_CHUNK;
+            }
+            const bool can_write = chunk_end <= d.group_cap;
+            if (!can_write) werr |= WD_GROUP_OVERFLOW;
+            if (can_write && rec_pos + ng > rec_end) {
+                for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the chunk's unused tail
+                    if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
+                const uint32_t want = max(uint32_t(REC_CHUNK), ng);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)want);
+                const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                rec_pos = (uint64_t(bhi) << 32) | blo;
+                rec_end = rec_pos + want;
+            }
+            if (can_write && rec_pos + ng > d.rec_cap) sticky_err |= WD_REC_OVERFLOW;
+            const uint64_t gbase = chunk_pos;
+            if (can_write) {
+                for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+                    const uint32_t g = g0 + lane;
+                    if (g < ng) {
+                        const unsigned long long key = skey[g];
+                        uint32_t rank = 0;   // ascending key order = the reference's VecMap iteration order (:394)
+                        for (uint32_t j = 0; j < ng; j++) rank += skey[j] < key ? 1u : 0u;
+                        Group G; G.hap = key; G.count = scnt[g]; G.aux = 0;
+                        d.groups[gbase + rank] = G;
+                        d.g_win[gbase + rank] = win;
+                        const uint64_t rec = rec_pos + rank;
+                        d.g_rec[gbase + rank] = rec < d.rec_cap ? uint32_t(rec) : 0xFFFFFFFFu;
+                    }
+                }
+                rec_pos += ng;
+                chunk_pos += ng;
+                n_groups_tx += ng;
+            }
+            if (lane == 0) {
+                WinDyn wd;
+                wd.group_off = uint32_t(gbase);
+                wd.ngroups = ng;
+                wd.nrows = nrows;
+                wd.flags = WD_DONE | werr;
+                d.win_dyn[win] = wd;
+            }
+            __syncthreads();
+        }
+    }
+    for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the last record chunk's unused tail
+        if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
+    if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
+    if (sticky_err) atomicOr(d.err, sticky_err);
 }
 
 // ====================================================================== K3
@@ -1032,6 +1314,18 @@ void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream) {
     if (d.n_tx == 0) return;
     dim3 grid(d.n_tx), block(64);
+    if (d.normal) {
+        switch (rows_per_lane) {
+            case 1: hipLaunchKernelGGL(k2n_window_replay<1>, grid, block, 0, stream, d); break;
+            case 2: hipLaunchKernelGGL(k2n_window_replay<2>, grid, block, 0, stream, d); break;
+            case 4: hipLaunchKernelGGL(k2n_window_replay<4>, grid, block, 0, stream, d); break;
+            case 8: hipLaunchKernelGGL(k2n_window_replay<8>, grid, block, 0, stream, d); break;
+            case 16: hipLaunchKernelGGL(k2n_window_replay<16>, grid, block, 0, stream, d); break;
+            default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+        }
+        HIP_CHECK_LAUNCH();
+        return;
+    }
     switch (rows_per_lane) {
         case 1: hipLaunchKernelGGL(k2_window_replay<1>, grid, block, 0, stream, d); break;
         case 2: hipLaunchKernelGGL(k2_window_replay<2>, grid, block, 0, stream, d); break;

@@ -22,6 +22,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     // plan
     const TxDev* tx;
     const Step* steps;
+    const uint16_t* step_aux;     // normal mode: per Step, candidate key range | 0x8000 = new column epoch
     const WinStatic* wins;
     const WinCol* win_cols;
     const uint8_t* str_pool;

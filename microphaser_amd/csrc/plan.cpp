@@ -36,6 +36,10 @@ struct PlannerHooksT {
     uint64_t max_seq_len = 0;
     // windows whose haplotypes currently sit in prev_hap_vec / hap_vec (they feed the next splice-side merge)
     uint32_t last_print_win = 0xFFFFFFFFu, held_prev = 0xFFFFFFFFu, held_hap = 0xFFFFFFFFu;
+    // normal mode: list-once bookkeeping and the geometry of the previous step (epoch breaks)
+    bool have_listed = false;
+    uint32_t listed_lo = 0, listed_hi = 0;
+    uint64_t n_steps_tx = 0, last_sso = 0, last_end = 0, last_wlen = 0, last_range = 0, last_added = 0;
 
     uint32_t tr_index(size_t fwd_idx) const { return is_fwd ? uint32_t(fwd_idx) : fwd2rev[fwd_idx]; }
 
@@ -141,16 +145,34 @@ struct PlannerHooksT {
         uint64_t lo = sg.cand_lo, hi = sg.cand_hi;
         if (sg.is_first_exon_window) {
             fl |= SF_FULL_RANGE;
-        } else if (NORMAL) {
-            // `normal` has no `contains`: on the '-' strand every in-range read is pushed again at every step
-            // (src/normal_microphasing.rs:942-967, 1010-1017), so the whole range is listed each time
-        } else if (!is_fwd && have_prev_cand) {
+        } else if (!NORMAL && !is_fwd && have_prev_cand) {
             hi = std::min(hi, prev_cand_lo);
             if (hi < lo) hi = lo;
         }
         prev_cand_lo = sg.cand_lo;
         have_prev_cand = true;
         uint32_t c0 = read_lower(lo), c1 = read_lower(hi);
+        if (NORMAL) {
+            // `normal` has no `contains`: a read is pushed again at EVERY step whose key range and window it satisfies
+            // (src/normal_microphasing.rs:942-967, 1010-1017). The kernel keeps ONE slot per read and derives the number
+            // of copies per column epoch in closed form (k2n_window_replay), so a read is listed exactly once per
+            // transcript: when its key first enters a candidate range. That needs sso / splice_end to move one way only.
+            if (n_steps_tx) {
+                bool ok = is_fwd ? (sg.sso >= last_sso && sg.splice_end >= last_end) : (sg.sso <= last_sso);
+                if (!ok) throw Error("normal mode: exons of a transcript overlap or are not in transcription order (not supported by this build)");
+            }
+            if (!have_listed) { listed_lo = c1; listed_hi = c0; have_listed = true; }  // nothing listed yet on either side
+            if (is_fwd) { c0 = std::max(c0, listed_hi); c1 = std::max(c1, c0); listed_hi = std::max(listed_hi, c1); }
+            else { c1 = std::min(c1, listed_lo); c0 = std::min(c0, c1); listed_lo = std::min(listed_lo, c0); }
+            const uint64_t range = sg.sso - sg.cand_lo;   // key range extent R: candidates have start in [sso - R, sso]
+            if (range > 0x7FFF) throw Error("normal mode: candidate key range wider than 32767 nt");
+            const uint64_t wl_now = sg.splice_end - sg.sso;
+            const bool new_epoch = n_steps_tx == 0 || sg.deleted > 0 || last_added > 0 || wl_now != last_wlen || range != last_range ||
+                                   (is_fwd ? sg.sso != last_sso + 1 : sg.sso + 1 != last_sso);
+            b.step_aux.push_back(uint16_t(range | (new_epoch ? 0x8000u : 0u)));
+            last_sso = sg.sso; last_end = sg.splice_end; last_wlen = wl_now; last_range = range; last_added = new_cols.size();
+            n_steps_tx++;
+        }
         if (c1 - c0 > 65535) throw Error("more than 65535 candidate reads in one step");
         st.cand_lo = c0;
         st.cand_n = uint16_t(c1 - c0);
@@ -393,6 +415,7 @@ void merge_batch(Batch& b, Batch& s) {
     append(b.ins_pool, s.ins_pool); append(b.ref_pool, s.ref_pool);
     for (TxDev t : s.tx) { t.gene += gOff; t.step_off += sOff; t.id_off += strOff; b.tx.push_back(t); }
     for (Step st : s.steps) { if (st.win != 0xFFFFFFFFu) st.win += wOff; st.exon += eOff; b.steps.push_back(st); }
+    b.step_aux.insert(b.step_aux.end(), s.step_aux.begin(), s.step_aux.end());
     for (WinStatic w : s.wins) { w.tx += tOff; w.col_off += wcOff; w.ref_off += uint32_t(refOff); w.vbase += vOff; w.step += sOff; b.wins.push_back(w); }
     append(b.win_cols, s.win_cols);
     for (ExonPlan e : s.exons) { e.tx += tOff; b.exons.push_back(e); }

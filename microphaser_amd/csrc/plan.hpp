@@ -97,7 +97,8 @@ struct WinDyn {          // K2 output per printing step
     uint32_t nrows;      // ObservationMatrix::nrows() (depth column)
     uint32_t flags;      // WD_*
 };
-enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4, WD_REC_OVERFLOW = 8 };
+enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4, WD_REC_OVERFLOW = 8,
+                  WD_EPOCH_OVERFLOW = 16, WD_HAP_OVERFLOW = 32 };  // normal mode: column-epoch ring / haplotype table full
 
 struct Group {           // K2 output: one distinct (haplotype, frame.0, frame.1 != 0) key of one window, ascending
     uint64_t hap;
