@@ -492,10 +492,7 @@ NormalRecord nrecord_update(const NormalRecord& self, const NormalRecord& rec, u
 }
 NormalRecord nrecord_add_freq(const NormalRecord& self, double freq) {
     NormalRecord r = self;
-    if (freq > 0.0) {
-        if (self.nvar == 0) throw Error("reference would panic: attempt to subtract with overflow (add_freq nvar)");
-        r.nvar = self.nvar - 1;
-    }
+    if (freq > 0.0) r.nvar = self.nvar - 1u;  // u32 wrap-around at nvar == 0, as the reference's release build does (:150)
     if (r.nvar < self.nsomatic) r.nsomatic = self.nsomatic - 1;
     r.freq = self.freq + freq;
     return r;

@@ -91,10 +91,10 @@ NormalRecord record_update(const NormalRecord& self, const NormalRecord& rec, ui
 }
 NormalRecord record_add_freq(const NormalRecord& self, double freq) {
     NormalRecord r = self;
-    if (freq > 0.0) {
-        if (self.nvar == 0) ref_panic("attempt to subtract with overflow (add_freq nvar)");
-        r.nvar = self.nvar - 1;
-    }
+    // `self.nvar - 1` on a u32 (:150): with nvar == 0 a debug build panics, the release build (Cargo.toml has no
+    // overflow-checks profile; the published binary) wraps to 4294967295 and prints that. Release behaviour is restated:
+    // it is what a user of `microphaser normal` observes, and about one synthetic gene in seven reaches this line.
+    if (freq > 0.0) r.nvar = self.nvar - 1u;
     if (r.nvar < self.nsomatic) r.nsomatic = self.nsomatic - 1;
     r.freq = self.freq + freq;
     return r;

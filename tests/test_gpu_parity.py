@@ -192,3 +192,30 @@ def test_gpu_normal_mode_matches_oracle_on_synthetic_exome(ctx, tmp_path, seed, 
     assert got["fasta"] == exp["fa"]
     assert got["tsv"] == exp["tsv"]
     assert exp["tsv"].count(b"\n") > 1000
+
+
+# ------------------------------------------------------------------ the product CLI (src/cli.yaml surface): GTF on stdin, FASTA on stdout
+PRODUCT_CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microphaser_amd", "_lib", "microphaser")
+
+
+def test_gpu_cli_somatic_matches_reference_expected_output(built, tmp_path):
+    p = fixture_paths("test_reverse")
+    with open(p["gtf"], "rb") as g:
+        r = subprocess.run([PRODUCT_CLI, "somatic", p["bam"], "--variants", p["vcf"], "--ref", p["fasta"], "--tsv", str(tmp_path / "o.tsv"),
+                            "--normal-output", str(tmp_path / "o.normal.fa")], stdin=g, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    exp = read_expected(p["expected"])
+    assert r.stdout == exp["fa"]
+    assert (tmp_path / "o.normal.fa").read_bytes() == exp["normal.fa"]
+    assert (tmp_path / "o.tsv").read_bytes() == exp["tsv"]
+
+
+def test_gpu_cli_normal_matches_reference_expected_output(built, tmp_path):
+    bam, vcf, gtf, fa, exp = NORMAL_FIXTURES["splice_forward_test"]
+    d = os.path.join(GOLDEN, "splice_forward_test")
+    with open(os.path.join(d, gtf), "rb") as g:
+        r = subprocess.run([PRODUCT_CLI, "normal", os.path.join(d, bam), "-b", os.path.join(d, vcf), "-r", os.path.join(d, fa),
+                            "-t", str(tmp_path / "n.tsv"), "-w", "27"], stdin=g, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == open(os.path.join(d, "expected_output", exp), "rb").read()
+    assert (tmp_path / "n.tsv").read_bytes().count(b"\n") == r.stdout.count(b">") + 1
