@@ -109,6 +109,24 @@ const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n);    /* sorted 
 uint64_t mp_peptides_count(const mp_peptides* p);                     /* translated windows                   */
 void mp_peptides_free(mp_peptides* p);
 
+/* `microphaser filter` (reference: peptides::filter, src/peptides.rs:221-709 <- run_filtering, src/main.rs:170-214,
+ * src/filter_cli.yaml): translate the mutant / normal windows of a `somatic` info.tsv, drop self-similar, repeated and
+ * post-stop peptides, remove those present in the reference peptidome (bincode HashSet<Vec<u8>> from build_reference)
+ * and annotate the rest with the maximum-likelihood frequency and the 95 % credible interval of their variant region.
+ * Translation, peptidome membership and the per-region statistics run on the GPU. peptide_len <= 12.
+ * mp_filter reads the two files; mp_filter_buffers takes their bytes. */
+typedef struct mp_filtered mp_filtered;
+int mp_filter(mp_ctx* ctx, const char* tsv_path, const char* reference_binary_path, uint32_t peptide_len, mp_filtered** out);
+int mp_filter_buffers(mp_ctx* ctx, const char* tsv, size_t tsv_len, const char* reference_binary, size_t reference_len,
+                      uint32_t peptide_len, mp_filtered** out);
+const char* mp_filtered_fasta(const mp_filtered* f, size_t* len);          /* stdout: kept tumor peptides           */
+const char* mp_filtered_normal_fasta(const mp_filtered* f, size_t* len);   /* --normal-output                       */
+const char* mp_filtered_tsv(const mp_filtered* f, size_t* len);            /* --tsv-output (header always present)  */
+const char* mp_filtered_removed_tsv(const mp_filtered* f, size_t* len);    /* --similar-removed                     */
+const char* mp_filtered_removed_fasta(const mp_filtered* f, size_t* len);  /* --removed-peptides                    */
+uint64_t mp_filtered_count(const mp_filtered* f, int which);               /* 0 rows, 1 peptides scored, 2 groups, 3 kept, 4 removed */
+void mp_filtered_free(mp_filtered* f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,15 @@ def lib():
         "mp_peptides_keys": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_peptides_count": (u64, [vp]),
         "mp_peptides_free": (None, [vp]),
+        "mp_filter": (i32, [vp, cp, cp, u32, pp]),
+        "mp_filter_buffers": (i32, [vp, cp, ctypes.c_size_t, cp, ctypes.c_size_t, u32, pp]),
+        "mp_filtered_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_filtered_normal_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_filtered_tsv": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_filtered_removed_tsv": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_filtered_removed_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_filtered_count": (u64, [vp, i32]),
+        "mp_filtered_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -105,6 +114,8 @@ C_ABI_SYMBOLS = [
     "mp_batch_results", "mp_batch_free", "mp_phase_dataset", "mp_results_fasta", "mp_results_normal_fasta",
     "mp_results_tsv", "mp_results_windows", "mp_results_free",
     "mp_build_reference", "mp_peptides_fasta", "mp_peptides_binary", "mp_peptides_keys", "mp_peptides_count", "mp_peptides_free",
+    "mp_filter", "mp_filter_buffers", "mp_filtered_fasta", "mp_filtered_normal_fasta", "mp_filtered_tsv", "mp_filtered_removed_tsv",
+    "mp_filtered_removed_fasta", "mp_filtered_count", "mp_filtered_free",
 ]
 
 
@@ -151,6 +162,15 @@ class Context:
         self._check(lib().mp_build_reference(self._h, fasta_path.encode(), peptide_len, ctypes.byref(h)))
         return Peptides(h)
 
+    def filter(self, tsv, reference_binary, peptide_len=9):
+        """`microphaser filter`: `tsv` / `reference_binary` are file paths (str) or the files' bytes."""
+        h = ctypes.c_void_p()
+        if isinstance(tsv, bytes) and isinstance(reference_binary, bytes):
+            self._check(lib().mp_filter_buffers(self._h, tsv, len(tsv), reference_binary, len(reference_binary), peptide_len, ctypes.byref(h)))
+        else:
+            self._check(lib().mp_filter(self._h, tsv.encode(), reference_binary.encode(), peptide_len, ctypes.byref(h)))
+        return Filtered(h)
+
     def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0):
         h = ctypes.c_void_p()
         if indel_rate or multiallelic_rate or softmask_rate:
@@ -179,6 +199,19 @@ class Peptides:
         self.keys = list((ctypes.c_uint64 * n.value).from_address(p)) if n.value else []
         self.count = L.mp_peptides_count(h)
         L.mp_peptides_free(h)
+
+
+class Filtered:
+    """Result of `filter`: the five output streams of the reference's sub-command."""
+
+    def __init__(self, h):
+        L = lib()
+        n = ctypes.c_size_t()
+        for name in ("fasta", "normal_fasta", "tsv", "removed_tsv", "removed_fasta"):
+            p = getattr(L, "mp_filtered_" + name)(h, ctypes.byref(n))
+            setattr(self, name, _bytes_at(p, n.value))
+        self.rows, self.peptides, self.groups, self.kept, self.removed = (L.mp_filtered_count(h, k) for k in range(5))
+        L.mp_filtered_free(h)
 
 
 def key_to_peptide(key, length):

@@ -9,6 +9,7 @@
 #include "batch.hpp"
 #include "consume.hpp"
 #include "device.hpp"
+#include "filter.hpp"
 #include "pep.hpp"
 #include "synth.hpp"
 
@@ -30,6 +31,9 @@ struct mp_batch {
 };
 struct mp_results {
     SomaticOutput out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty
+};
+struct mp_filtered {
+    FilterResult res;
 };
 struct mp_peptides {
     PeptideResult res;
@@ -229,5 +233,43 @@ const char* mp_peptides_binary(const mp_peptides* p, size_t* len) { if (len) *le
 const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n) { if (n) *n = p->res.keys.size(); return p->res.keys.data(); }
 uint64_t mp_peptides_count(const mp_peptides* p) { return p->res.n_peptides; }
 void mp_peptides_free(mp_peptides* p) { delete p; }
+
+int mp_filter_buffers(mp_ctx* ctx, const char* tsv, size_t tsv_len, const char* reference_binary, size_t reference_len, uint32_t peptide_len,
+                      mp_filtered** out) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        std::unique_ptr<mp_filtered> f(new mp_filtered());
+        filter_device(dev.device(), std::string(reference_binary, reference_len), std::string(tsv, tsv_len), peptide_len, f->res);
+        *out = f.release();
+    });
+}
+int mp_filter(mp_ctx* ctx, const char* tsv_path, const char* reference_binary_path, uint32_t peptide_len, mp_filtered** out) {
+    std::string tsv, ref;
+    int rc = guarded(ctx, [&] {
+        auto slurp = [](const char* path) {
+            std::ifstream in(path, std::ios::binary);
+            if (!in) throw Error(std::string("cannot open ") + path);
+            std::stringstream ss;
+            ss << in.rdbuf();
+            return ss.str();
+        };
+        ref = slurp(reference_binary_path);
+        tsv = slurp(tsv_path);
+    });
+    if (rc != 0) return rc;
+    return mp_filter_buffers(ctx, tsv.data(), tsv.size(), ref.data(), ref.size(), peptide_len, out);
+}
+const char* mp_filtered_fasta(const mp_filtered* f, size_t* len) { if (len) *len = f->res.fasta.size(); return f->res.fasta.data(); }
+const char* mp_filtered_normal_fasta(const mp_filtered* f, size_t* len) { if (len) *len = f->res.normal_fasta.size(); return f->res.normal_fasta.data(); }
+const char* mp_filtered_tsv(const mp_filtered* f, size_t* len) { if (len) *len = f->res.tsv.size(); return f->res.tsv.data(); }
+const char* mp_filtered_removed_tsv(const mp_filtered* f, size_t* len) { if (len) *len = f->res.removed_tsv.size(); return f->res.removed_tsv.data(); }
+const char* mp_filtered_removed_fasta(const mp_filtered* f, size_t* len) { if (len) *len = f->res.removed_fasta.size(); return f->res.removed_fasta.data(); }
+uint64_t mp_filtered_count(const mp_filtered* f, int which) {
+    switch (which) {
+        case 0: return f->res.n_rows; case 1: return f->res.n_peptides; case 2: return f->res.n_groups; case 3: return f->res.n_kept;
+        case 4: return f->res.n_removed; default: return 0;
+    }
+}
+void mp_filtered_free(mp_filtered* f) { delete f; }
 
 }  // extern "C"

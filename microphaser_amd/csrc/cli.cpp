@@ -63,10 +63,53 @@ int main(int argc, char** argv) {
         mp_destroy(ctx);
         return 0;
     }
+    if (sub == "filter") {
+        // microphaser filter -t info.tsv -r reference.binary [-o info.filtered.tsv] [-s info.removed.tsv] [-p peptides.removed.fasta]
+        //                    [-n normal.filtered.fa] [-l 9] > tumor.filtered.fa          (src/filter_cli.yaml, src/main.rs:170-214)
+        std::string tsv, ref, tsvo = "info.filtered.tsv", simo = "info.removed.tsv", remp = "peptides.removed.fasta", normo = "normal.filtered.fa";
+        unsigned peptide_len = 9;
+        int device = 0;
+        for (int i = 2; i < argc; i++) {
+            std::string a = argv[i];
+            auto val = [&]() -> const char* {
+                if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(1); }
+                return argv[++i];
+            };
+            if (a == "--tsv" || a == "-t") tsv = val();
+            else if (a == "--reference" || a == "-r") ref = val();
+            else if (a == "--tsv-output" || a == "-o") tsvo = val();
+            else if (a == "--similar-removed" || a == "-s") simo = val();
+            else if (a == "--removed-peptides" || a == "-p") remp = val();
+            else if (a == "--normal-output" || a == "-n") normo = val();
+            else if (a == "--peptide-length" || a == "-l") peptide_len = unsigned(std::strtoul(val(), nullptr, 10));
+            else if (a == "--device") device = std::atoi(val());
+            else if (a == "-v" || a == "--verbose") {}
+            else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
+        }
+        if (tsv.empty() || ref.empty()) { std::fprintf(stderr, "--tsv and --reference are required\n"); return 1; }
+        mp_ctx* ctx = nullptr;
+        if (mp_create(device, &ctx) != 0) { int rc = fail(ctx, "mp_create"); mp_destroy(ctx); return rc; }
+        mp_filtered* f = nullptr;
+        if (mp_filter(ctx, tsv.c_str(), ref.c_str(), peptide_len, &f) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
+        size_t n = 0;
+        const char* p = mp_filtered_fasta(f, &n);
+        std::fwrite(p, 1, n, stdout);
+        p = mp_filtered_normal_fasta(f, &n);
+        if (!write_file(normo, p, n)) { std::fprintf(stderr, "cannot write %s\n", normo.c_str()); return 1; }
+        p = mp_filtered_tsv(f, &n);
+        if (!write_file(tsvo, p, n)) { std::fprintf(stderr, "cannot write %s\n", tsvo.c_str()); return 1; }
+        p = mp_filtered_removed_tsv(f, &n);
+        if (!write_file(simo, p, n)) { std::fprintf(stderr, "cannot write %s\n", simo.c_str()); return 1; }
+        p = mp_filtered_removed_fasta(f, &n);
+        if (!write_file(remp, p, n)) { std::fprintf(stderr, "cannot write %s\n", remp.c_str()); return 1; }
+        mp_filtered_free(f);
+        mp_destroy(ctx);
+        return 0;
+    }
     // microphaser normal <normal.bam> --ref F --variants V [--tsv info.tsv] [-w 27] < gtf > fasta   (src/germline_cli.yaml, src/main.rs:104-143)
     const bool normal_mode = sub == "normal";
     if (sub != "somatic" && !normal_mode) {
-        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic`, `normal` and `build_reference` are available\n", sub.c_str());
+        std::fprintf(stderr, "microphaser (MI355X build): sub-command `%s` is not accelerated in this build; only `somatic`, `normal`, `build_reference` and `filter` are available\n", sub.c_str());
         return 1;
     }
     std::string bam, vcf, ref, tsv = "info.tsv", normal = "normal.fasta";

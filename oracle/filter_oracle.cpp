@@ -1,0 +1,362 @@
+// TEST INFRASTRUCTURE - NOT PRODUCT CODE. See filter_oracle.hpp.
+#include "filter_oracle.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <map>
+#include <set>
+#include <tuple>
+#include <vector>
+
+#include "../microphaser_amd/csrc/model.hpp"
+#include "../microphaser_amd/csrc/util.hpp"
+#include "peptides_oracle.hpp"
+
+namespace mp_oracle {
+
+namespace {
+
+using mp::Error;
+using mp::IDRecord;
+
+// ---- statrs 0.15 -------------------------------------------------------------------------------------------------
+// factorial::ln_factorial: ln of a cached f64 factorial up to 170, ln_gamma(x + 1) above
+double ln_gamma(double x) {  // gamma::ln_gamma (Lanczos, g = 10.900511, 11 coefficients)
+    static const double R = 10.900511;
+    static const double DK[11] = {2.48574089138753565546e-5, 1.05142378581721974210,   -3.45687097222016235469, 4.51227709466894823700,
+                                  -2.98285225323576655721,   1.05639711577126713077,   -1.95428773191645869583e-1, 1.70970543404441224307e-2,
+                                  -5.71926117404305781283e-4, 4.63399473359905636708e-6, -2.71994908488607703910e-9};
+    static const double LN_2_SQRT_E_OVER_PI = 0.6207822376352452223455184457816472122518527279025978;
+    static const double LN_PI = 1.1447298858494001741434273513530587116472948129153;
+    if (x < 0.5) {
+        double s = DK[0];
+        for (int i = 1; i < 11; i++) s += DK[i] / (double(i) - x);
+        return LN_PI - std::log(std::sin(M_PI * x)) - std::log(s) - LN_2_SQRT_E_OVER_PI - (0.5 - x) * std::log((0.5 - x + R) / M_E);
+    }
+    double s = DK[0];
+    for (int i = 1; i < 11; i++) s += DK[i] / (x + double(i) - 1.0);
+    return std::log(s) + LN_2_SQRT_E_OVER_PI + (x - 0.5) * std::log((x - 0.5 + R) / M_E);
+}
+double ln_factorial(uint64_t x) {
+    static const std::vector<double> fcache = [] {
+        std::vector<double> f(171);
+        f[0] = 1.0;
+        for (int i = 1; i < 171; i++) f[i] = f[i - 1] * double(i);
+        return f;
+    }();
+    return x <= 170 ? std::log(fcache[x]) : ln_gamma(double(x) + 1.0);
+}
+double ln_binomial(uint64_t n, uint64_t k) {
+    if (k > n) return -std::numeric_limits<double>::infinity();
+    return ln_factorial(n) - ln_factorial(k) - ln_factorial(n - k);
+}
+double binomial_pmf(double p, uint64_t n, uint64_t x) {  // Binomial::new(p, n).unwrap().pmf(x)
+    if (!(p >= 0.0 && p <= 1.0)) throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (Binomial::new)");
+    if (x > n) return 0.0;
+    if (p == 0.0) return x == 0 ? 1.0 : 0.0;
+    if (p == 1.0) return x == n ? 1.0 : 0.0;
+    return std::exp(ln_binomial(n, x) + double(x) * std::log(p) + double(n - x) * std::log(1.0 - p));
+}
+uint64_t round_to_u64(double v) {  // `alt[i].round() as u64` (saturating cast, NaN -> 0)
+    double r = std::round(v);
+    if (!(r > 0.0)) return 0;
+    if (r >= 18446744073709551615.0) return ~0ull;
+    return uint64_t(r);
+}
+
+// density (src/peptides.rs:188-201)
+double density(const std::vector<double>& alt, const std::vector<uint32_t>& depth, double theta) {
+    double prob = 1.0;
+    for (size_t i = 0; i < alt.size(); i++) prob *= binomial_pmf(theta, depth[i], round_to_u64(alt[i]));
+    return prob;
+}
+
+// ---- bio 0.34 LogProb ---------------------------------------------------------------------------------------------
+const double LN_ZERO = -std::numeric_limits<double>::infinity();
+double ln_sum_exp(const std::vector<double>& probs) {
+    if (probs.empty()) return LN_ZERO;
+    double pmax = probs[0];
+    size_t imax = 0;
+    for (size_t i = 1; i < probs.size(); i++)
+        if (probs[i] > pmax) { pmax = probs[i]; imax = i; }
+    if (pmax == LN_ZERO) return LN_ZERO;
+    if (pmax == std::numeric_limits<double>::infinity()) return pmax;
+    double s = 0.0;
+    for (size_t i = 0; i < probs.size(); i++)
+        if (i != imax && probs[i] != LN_ZERO) s += std::exp(probs[i] - pmax);
+    return pmax + std::log1p(s);
+}
+template <class D>
+double ln_simpsons_integrate_exp(D dens, double a, double b, size_t n) {
+    // itertools_num::linspace(a, b, n): a + step * i with step = (b - a) / (n - 1)
+    const double step = (b - a) / double(n - 1);
+    std::vector<double> probs;
+    for (size_t i = 1; i + 1 < n; i++) {
+        const double v = a + step * double(i);
+        const double weight = double(2 + (i % 2) * 2);
+        probs.push_back(dens(v) + std::log(weight));
+    }
+    probs.push_back(dens(a));
+    probs.push_back(dens(b));
+    const double width = b - a;
+    return ln_sum_exp(probs) + std::log(width) - std::log(double(n - 1)) - std::log(3.0);
+}
+
+struct Interval { uint64_t ml; double a, b; };
+
+// the statistics of one record group; `final_pass` selects the loop after the last row (:596-660) instead of the one
+// used when the region changes (:415-481)
+Interval credible_interval(const std::vector<double>& freqs, const std::vector<uint32_t>& depths, bool final_pass) {
+    // prob_func (:203-219) + max_by(partial_cmp): the LAST maximum wins
+    uint64_t ml = 0;
+    double best = 0;
+    for (uint64_t t = 0; t < 101; t++) {
+        const double p = density(freqs, depths, double(t) * 0.01);
+        if (p != p) throw Error("reference would panic: called `Option::unwrap()` on a `None` value (partial_cmp)");
+        if (t == 0 || p >= best) { best = p; ml = t; }
+    }
+    auto ln_dens = [&](double v) { return std::log(density(freqs, depths, v)); };
+    const double r = ln_simpsons_integrate_exp(ln_dens, 0.0, 1.0, 99);
+    auto ln_norm = [&](double v) { return std::log(density(freqs, depths, v)) - r; };
+    const double L95 = std::log(0.95), L96 = std::log(0.96);
+    double a = ml < 10 ? 0.0 : double(ml - 10) * 0.01;
+    double b = ml > 90 ? 1.0 : double(ml + 10) * 0.01;
+    double p = LN_ZERO;
+    if (!final_pass) {
+        double a_old = double(ml) * 0.01, b_old = double(ml) * 0.01;
+        for (int counter = 0; counter != 50; counter++) {
+            if (p < L95) {
+                a_old = a;
+                a = a < 0.1 ? 0.0 : a - 0.1;
+                b_old = b;
+                b = b > 0.9 ? 1.0 : b + 0.1;
+            }
+            if (p > L96) {
+                a += (a_old - a) / 2.0;
+                b -= (b - b_old) / 2.0;
+            }
+            p = ln_simpsons_integrate_exp(ln_norm, a, b, 11);
+            if (p >= L95 && p < L96) break;
+        }
+    } else {
+        double a_r = double(ml) * 0.01, a_l = 0.0, b_r = 1.0, b_l = double(ml) * 0.01;
+        for (int counter = 0; counter != 10; counter++) {
+            if (p < L95) {
+                a_r = a;
+                a = a < 0.1 ? 0.0 : a - ((a - a_l) / 2.0);
+                b_l = b;
+                b = b > 0.9 ? 1.0 : b + ((b_r - b) / 2.0);
+            }
+            if (p > L96) {
+                a_l = a;
+                a += (a_r - a) / 2.0;
+                b_r = b;
+                b -= (b - b_l) / 2.0;
+            }
+            p = ln_simpsons_integrate_exp(ln_norm, a, b, 11);
+            if (p >= L95 && p < L96) break;
+        }
+    }
+    return {ml, a, b};
+}
+
+// ---- csv -----------------------------------------------------------------------------------------------------------
+std::vector<std::vector<std::string>> read_tsv(const std::string& text) {  // csv::ReaderBuilder::delimiter(b'\t'), default quoting
+    std::vector<std::vector<std::string>> rows;
+    std::vector<std::string> row;
+    std::string field;
+    bool in_quotes = false, any = false;
+    for (size_t i = 0; i < text.size(); i++) {
+        char c = text[i];
+        if (in_quotes) {
+            if (c == '"') {
+                if (i + 1 < text.size() && text[i + 1] == '"') { field.push_back('"'); i++; }
+                else in_quotes = false;
+            } else field.push_back(c);
+            continue;
+        }
+        if (c == '"' && field.empty()) { in_quotes = true; any = true; }
+        else if (c == '\t') { row.push_back(field); field.clear(); any = true; }
+        else if (c == '\n' || c == '\r') {
+            if (c == '\r' && i + 1 < text.size() && text[i + 1] == '\n') i++;
+            if (any || !field.empty()) { row.push_back(field); rows.push_back(row); }
+            row.clear(); field.clear(); any = false;
+        } else { field.push_back(c); any = true; }
+    }
+    if (any || !field.empty()) { row.push_back(field); rows.push_back(row); }
+    return rows;
+}
+uint64_t parse_u64(const std::string& s, const char* what) {
+    if (s.empty() || s.find_first_not_of("0123456789") != std::string::npos) throw Error(std::string("CSV deserialize error: field ") + what + ": invalid digit found in string");
+    return std::strtoull(s.c_str(), nullptr, 10);
+}
+double parse_f64(const std::string& s) {
+    char* e = nullptr;
+    double v = std::strtod(s.c_str(), &e);
+    if (s.empty() || *e) throw Error("CSV deserialize error: field freq: invalid float literal");
+    return v;
+}
+IDRecord parse_row(const std::vector<std::string>& f) {  // serde positional deserialize of common::IDRecord (src/common.rs:350-373)
+    if (f.size() != 21) throw Error("CSV deserialize error: found record with " + std::to_string(f.size()) + " fields, but expected 21");
+    IDRecord r;
+    r.id = f[0]; r.transcript = f[1]; r.gene_id = f[2]; r.gene_name = f[3]; r.chrom = f[4];
+    r.offset = parse_u64(f[5], "offset"); r.frame = parse_u64(f[6], "frame"); r.freq = parse_f64(f[7]);
+    r.depth = uint32_t(parse_u64(f[8], "depth")); r.nvar = uint32_t(parse_u64(f[9], "nvar")); r.nsomatic = uint32_t(parse_u64(f[10], "nsomatic"));
+    r.nvariant_sites = uint32_t(parse_u64(f[11], "nvariant_sites")); r.nsomvariant_sites = uint32_t(parse_u64(f[12], "nsomvariant_sites"));
+    r.strand = f[13]; r.variant_sites = f[14]; r.somatic_positions = f[15]; r.somatic_aa_change = f[16];
+    r.germline_positions = f[17]; r.germline_aa_change = f[18]; r.normal_sequence = f[19]; r.mutant_sequence = f[20];
+    return r;
+}
+
+const char* FILTERED_HEADER =
+    "id\ttranscript\tgene_id\tgene_name\tchrom\toffset\tframe\tfreq\tcredible_interval\tdepth\tnvar\tnsomatic\tnvariant_sites\tnsomvariant_sites\t"
+    "strand\tvariant_sites\tsomatic_positions\tsomatic_aa_change\tgermline_positions\tgermline_aa_change\tnormal_sequence\tmutant_sequence\t"
+    "normal_peptide\ttumor_peptide\n";
+
+void write_filtered(std::string& t, const IDRecord& r, const std::string& ci, const std::string& normal_pep, const std::string& tumor_pep) {
+    auto S = [&](const std::string& f) { mp::tsv_field(t, f); t.push_back('\t'); };
+    auto U = [&](uint64_t v) { t += std::to_string(v); t.push_back('\t'); };
+    S(r.id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom); U(r.offset); U(r.frame);
+    t += mp::fmt_f64(r.freq); t.push_back('\t');
+    S(ci); U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
+    S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change); S(r.germline_positions); S(r.germline_aa_change);
+    S(r.normal_sequence); S(r.mutant_sequence); S(normal_pep);
+    mp::tsv_field(t, tumor_pep);
+    t.push_back('\n');
+}
+
+std::set<std::string> read_bincode_set(const std::string& b) {  // bincode v1 HashSet<Vec<u8>>
+    size_t p = 0;
+    auto u64 = [&]() {
+        if (p + 8 > b.size()) throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (bincode: unexpected end of file)");
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= uint64_t(uint8_t(b[p + i])) << (8 * i);
+        p += 8;
+        return v;
+    };
+    std::set<std::string> s;
+    uint64_t n = u64();
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t l = u64();
+        if (p + l > b.size()) throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (bincode: unexpected end of file)");
+        s.insert(b.substr(p, l));
+        p += l;
+    }
+    return s;
+}
+
+}  // namespace
+
+void filter(const std::string& reference_binary, const std::string& tsv_text, size_t peptide_length, FilterOutput& out) {
+    const std::set<std::string> ref_set = read_bincode_set(reference_binary);
+    using Key = std::tuple<uint64_t, std::string, std::string>;
+    struct Entry { IDRecord row; std::string tumor_pep, normal_pep; };
+    std::tuple<std::string, std::string, std::string> current{"", "", ""}, current_variant{"", "", ""};
+    std::pair<std::string, std::string> region_sites{"", ""};
+    std::map<Key, std::vector<double>> frequencies;
+    std::map<Key, std::vector<uint32_t>> depth;
+    std::map<Key, std::vector<Entry>> records;
+    std::set<std::string> seen_peptides;
+    std::map<std::pair<std::string, uint64_t>, size_t> stop_gained;
+    bool removed_header = false;
+    out.tsv += FILTERED_HEADER;  // :258-261
+
+    auto flush = [&](bool final_pass) {
+        for (const auto& kv : records) {
+            const Interval ci = credible_interval(frequencies.at(kv.first), depth.at(kv.first), final_pass);
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "%.2f-%.2f", ci.a, ci.b);
+            for (const Entry& e : kv.second) {
+                IDRecord out_row = e.row;
+                out_row.freq = out_row.depth == 0 ? 0.0 : double(ci.ml) * 0.01;
+                if (ref_set.count(e.tumor_pep)) {
+                    mp::write_fasta(out.removed_fasta, out_row.id, reinterpret_cast<const uint8_t*>(e.tumor_pep.data()), e.tumor_pep.size());
+                    if (!removed_header) { out.removed_tsv += FILTERED_HEADER; removed_header = true; }
+                    write_filtered(out.removed_tsv, out_row, buf, e.normal_pep, e.tumor_pep);
+                } else {
+                    mp::write_fasta(out.fasta, out_row.id, reinterpret_cast<const uint8_t*>(e.tumor_pep.data()), e.tumor_pep.size());
+                    if (!e.normal_pep.empty())
+                        mp::write_fasta(out.normal_fasta, out_row.id, reinterpret_cast<const uint8_t*>(e.normal_pep.data()), e.normal_pep.size());
+                    write_filtered(out.tsv, out_row, buf, e.normal_pep, e.tumor_pep);
+                }
+            }
+        }
+    };
+
+    auto rows = read_tsv(tsv_text);
+    for (size_t ri = 1; ri < rows.size(); ri++) {  // first record = header
+        const IDRecord row = parse_row(rows[ri]);
+        size_t som_pos = 0;
+        if (!row.somatic_positions.empty() && row.somatic_positions.find('|') == std::string::npos) {
+            if (row.somatic_positions.find_first_not_of("0123456789") != std::string::npos)
+                throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (somatic_positions)");
+            som_pos = size_t(std::strtoull(row.somatic_positions.c_str(), nullptr, 10));
+        }
+        const std::string& orientation = row.strand;
+        const size_t offset = size_t(row.offset);
+        const int frame = (!row.id.empty() && row.id.back() == 'F') ? 1 : -1;
+        const std::string tumor_peptide = to_protein(row.mutant_sequence, frame);
+        const std::string normal_peptide = row.normal_sequence.empty() ? std::string() : to_protein(row.normal_sequence, frame);
+        size_t i = 0;
+        const std::pair<std::string, uint64_t> check{row.transcript, row.frame};
+        auto sg = stop_gained.find(check);
+        if (sg != stop_gained.end()) {
+            bool downstream = orientation == "Forward" ? offset > sg->second : orientation == "Reverse" ? offset < sg->second : false;
+            if (downstream) continue;
+        }
+        if (tumor_peptide.find('X') != std::string::npos && (std::fabs(row.freq - 1.0) < std::numeric_limits<double>::epsilon() || row.frame > 0))
+            stop_gained[check] = offset;
+        while (i + peptide_length <= tumor_peptide.size()) {
+            const std::string tumor_pep = tumor_peptide.substr(i, peptide_length);
+            if (tumor_pep.find('X') != std::string::npos) break;
+            const std::string normal_pep = normal_peptide.size() >= i + peptide_length ? normal_peptide.substr(i, peptide_length) : normal_peptide;
+            if (normal_pep.empty() && som_pos > 0) {
+                if (orientation == "Forward") {
+                    if ((i + peptide_length) * 3 + offset <= som_pos) { i += 1; continue; }
+                } else if (orientation == "Reverse") {
+                    if ((tumor_peptide.size() - (i + peptide_length)) * 3 + offset > som_pos) { i += 1; continue; }
+                }
+            }
+            i += 1;
+            if (tumor_pep == normal_pep) continue;
+            const std::pair<std::string, std::string> current_sites{row.transcript, row.variant_sites};
+            const std::tuple<std::string, std::string, std::string> cur{row.transcript, row.somatic_positions, row.germline_positions};
+            if (cur == current) {
+                if (seen_peptides.count(tumor_pep)) continue;
+            } else {
+                current = cur;
+                seen_peptides.clear();
+            }
+            if (current_variant == std::make_tuple(std::string(), std::string(), std::string())) current_variant = cur;
+            seen_peptides.insert(tumor_pep);
+            Entry e;
+            e.row = row;
+            e.row.id = std::to_string(i) + "_" + row.id;
+            e.tumor_pep = tumor_pep;
+            e.normal_pep = normal_pep;
+            const Key key{row.frame, row.somatic_positions, row.germline_positions};
+            const double alt = row.freq * double(row.depth);
+            if (current_sites != region_sites) {
+                flush(false);
+                frequencies.clear(); depth.clear(); records.clear();
+                frequencies[key] = {alt};
+                depth[key] = {row.depth};
+                records[key] = {e};
+                region_sites = current_sites;
+            } else {
+                // entry().or_insert_with(|| vec![x]).push(x): a key that first appears here gets the value TWICE
+                if (!depth.count(key)) depth[key] = {row.depth};
+                depth[key].push_back(row.depth);
+                if (!frequencies.count(key)) frequencies[key] = {alt};
+                frequencies[key].push_back(alt);
+                if (!records.count(key)) records[key] = {e};
+                records[key].push_back(e);
+            }
+        }
+    }
+    flush(true);
+}
+
+}  // namespace mp_oracle

@@ -219,3 +219,64 @@ def test_gpu_cli_normal_matches_reference_expected_output(built, tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == open(os.path.join(d, "expected_output", exp), "rb").read()
     assert (tmp_path / "n.tsv").read_bytes().count(b"\n") == r.stdout.count(b">") + 1
+
+
+# ------------------------------------------------------------------ `microphaser filter` (src/peptides.rs:188-709)
+FILTER_FIXTURES = {"test_filter": "filtered", "test_filter_long": "filtered_long", "test_filter_fs": "filtered_fs"}
+
+
+@pytest.mark.parametrize("name", sorted(FILTER_FIXTURES))
+def test_gpu_filter_matches_reference_expected_output(ctx, name):
+    d, stem = os.path.join(GOLDEN, name), FILTER_FIXTURES[name]
+    f = ctx.filter(os.path.join(d, "info.tsv"), os.path.join(d, "reference.binary"), 9)
+    exp = os.path.join(d, "expected_output")
+    assert f.fasta == open(os.path.join(exp, "tumor.%s.fa" % stem), "rb").read()
+    assert f.normal_fasta == open(os.path.join(exp, "normal.%s.fa" % stem), "rb").read()
+    assert f.tsv == open(os.path.join(exp, "info.%s.tsv" % stem), "rb").read()
+
+
+def test_gpu_config_e_pipeline_matches_oracle(ctx, tmp_path):
+    """Config E end to end on one synthetic exome: `normal` -> `build_reference -l 9` (normal peptidome) -> `somatic` ->
+    `filter`; every stage on the GPU, every stage's output compared with the CPU oracle run on the same bytes."""
+    import microphaser_amd as m
+    ds = ctx.synth(303, 30, indel_rate=0.03)
+    normal_fa = tmp_path / "normal_peptides.fa"
+    parts = []
+    for g in range(ds.num_genes):  # genes the reference would panic on are dropped from the peptidome input
+        try:
+            b = ds.batch(gene_lo=g, gene_hi=g + 1, mode=m.MODE_NORMAL)
+            b.run()
+            parts.append(b.results().fasta)
+        except m.MicrophaserError:
+            pass
+    normal_fa.write_bytes(b"".join(parts))
+    pep = ctx.build_reference(str(normal_fa), 9)
+    ref_bin = tmp_path / "reference.binary"
+    ref_bin.write_bytes(pep.binary)
+    som_parts = []
+    for g in range(ds.num_genes):
+        try:
+            b = ds.batch(gene_lo=g, gene_hi=g + 1)
+            b.run()
+            r = b.results()
+            som_parts.append(dict(fasta=r.fasta, normal_fasta=r.normal_fasta, tsv=r.tsv))
+        except m.MicrophaserError:
+            pass
+    from microphaser_amd.shard import merge_streams
+    info = tmp_path / "info.tsv"
+    info.write_bytes(merge_streams(som_parts)["tsv"])
+    assert info.read_bytes().count(b"\n") > 500
+    f = ctx.filter(str(info), str(ref_bin), 9)
+    r = subprocess.run([ORACLE_CLI, "filter", "-r", str(ref_bin), "-l", "9", "-t", str(info), "-o", str(tmp_path / "o.tsv"),
+                        "-n", str(tmp_path / "o.normal.fa"), "-s", str(tmp_path / "o.removed.tsv"), "-p", str(tmp_path / "o.removed.fa")],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert f.fasta == r.stdout
+    assert f.normal_fasta == (tmp_path / "o.normal.fa").read_bytes()
+    assert f.tsv == (tmp_path / "o.tsv").read_bytes()
+    assert f.removed_tsv == (tmp_path / "o.removed.tsv").read_bytes()
+    assert f.removed_fasta == (tmp_path / "o.removed.fa").read_bytes()
+    assert f.kept > 100 and f.removed > 0 and f.groups > 20
+    # the buffer entry point gives the same result
+    f2 = ctx.filter(info.read_bytes(), ref_bin.read_bytes(), 9)
+    assert (f2.fasta, f2.tsv, f2.removed_tsv) == (f.fasta, f.tsv, f.removed_tsv)

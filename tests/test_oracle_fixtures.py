@@ -66,3 +66,21 @@ def test_normal_oracle_matches_reference_expected_output(built, tmp_path, name):
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == open(os.path.join(d, "expected_output", exp), "rb").read()
     assert (tmp_path / "n.tsv").read_bytes().count(b"\n") == r.stdout.count(b">") + 1
+
+
+FILTER_FIXTURES = {"test_filter": "filtered", "test_filter_long": "filtered_long", "test_filter_fs": "filtered_fs"}
+
+
+@pytest.mark.parametrize("name", sorted(FILTER_FIXTURES))
+def test_filter_oracle_matches_reference_expected_output(built, tmp_path, name):
+    """tests/lib.rs:146-211: tumor FASTA, normal FASTA and filtered TSV (incl. the credible-interval strings) byte for byte."""
+    d, stem = os.path.join(GOLDEN, name), FILTER_FIXTURES[name]
+    r = subprocess.run([ORACLE_CLI, "filter", "--reference", os.path.join(d, "reference.binary"), "-l", "9", "--tsv", os.path.join(d, "info.tsv"),
+                        "--tsv-output", str(tmp_path / "o.tsv"), "--normal-output", str(tmp_path / "o.normal.fa"),
+                        "--similar-removed", str(tmp_path / "o.removed.tsv"), "--removed-peptides", str(tmp_path / "o.removed.fa")],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    exp = os.path.join(d, "expected_output")
+    assert r.stdout == open(os.path.join(exp, "tumor.%s.fa" % stem), "rb").read()
+    assert (tmp_path / "o.normal.fa").read_bytes() == open(os.path.join(exp, "normal.%s.fa" % stem), "rb").read()
+    assert (tmp_path / "o.tsv").read_bytes() == open(os.path.join(exp, "info.%s.tsv" % stem), "rb").read()
