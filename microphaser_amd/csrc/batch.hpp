@@ -55,7 +55,9 @@ struct Batch {
     std::vector<WinCol> win_cols;         // column lists of the printing windows
     std::vector<ExonPlan> exons;
     std::vector<uint8_t> str_pool;        // transcript ids
-    std::vector<uint32_t> tx_order;       // launch order (longest first)
+    std::vector<SegDev> segs;             // independent replay units (whole exons of one transcript), see plan.hpp
+    std::vector<uint32_t> seg_order;      // launch order (longest first)
+    std::vector<uint8_t> seg_break_del;   // planner scratch: the n_del each segment's first step had before the break
     // ---- sizing
     uint32_t seq_cap = 48;                // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks

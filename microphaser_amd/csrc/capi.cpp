@@ -1,6 +1,8 @@
 // C ABI (include/microphaser_hip.h) over the planner / device context / consumer.
 #include "../../include/microphaser_hip.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -139,6 +141,12 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
         std::unique_ptr<mp_batch> b(new mp_batch());
         b->reads = &ds->ds.bam.reads;
         build_batch(genes.data() + gene_lo, size_t(gene_hi - gene_lo), *b->reads, window_len, mode == MP_MODE_NORMAL, b->batch);
+        if (std::getenv("MP_DEBUG")) {
+            uint32_t mx = 0;
+            for (const SegDev& g : b->batch.segs) mx = std::max(mx, g.n_steps);
+            std::fprintf(stderr, "[mp] plan: %zu transcripts, %zu segments (longest %u steps), %zu steps, %zu windows\n", b->batch.tx.size(),
+                         b->batch.segs.size(), mx, b->batch.steps.size(), b->batch.wins.size());
+        }
         if (ctx->dev) {
             ctx->dev->upload(b->batch);
             b->uploaded = true;

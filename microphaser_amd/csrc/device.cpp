@@ -91,7 +91,9 @@ void DeviceContext::upload(const Batch& b) {
     d_.wins = up(b.wins);
     d_.win_cols = up(b.win_cols);
     d_.str_pool = up(b.str_pool);
-    d_.tx_order = up(b.tx_order);
+    d_.segs = up(b.segs);
+    d_.seg_order = up(b.seg_order);
+    d_.n_segs = uint32_t(b.segs.size());
     d_.n_reads = uint32_t(b.r_pos.size());
     d_.n_tx = uint32_t(b.tx.size());
     d_.n_wins = uint32_t(b.wins.size());
@@ -126,6 +128,11 @@ void DeviceContext::alloc_outputs() {
     d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
     d_.recs = static_cast<uint8_t*>(oalloc(rec_cap_ * d_.rec_stride));
+    d_.live_groups = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
+    d_.rec_want = static_cast<uint8_t*>(oalloc(rec_cap_));
+    d_.want_recs = static_cast<uint32_t*>(oalloc(rec_cap_ * 4));
+    sel_temp_bytes_ = compaction_temp_bytes(std::max(group_cap_, rec_cap_));
+    sel_temp_ = oalloc(sel_temp_bytes_);
     d_.group_cap = group_cap_;
     d_.rec_cap = rec_cap_;
 }
@@ -165,9 +172,22 @@ void DeviceContext::run(RunTiming& t) {
             continue;
         }
         const uint64_t slots = cur[0], rec_slots = cur[1];
-        launch_k3_window_seq(d_, slots, stream_);
+        // dense lists: K3 over the used group slots, K3b over the records that need an id (cursors[3] = list length)
+        uint64_t n_live = 0, n_want = 0;
+        if (slots) {
+            launch_compact_live_groups(d_, slots, sel_temp_, sel_temp_bytes_, reinterpret_cast<uint64_t*>(d_.cursors + 3), stream_);
+            HIP_OK(hipMemcpyAsync(&n_live, d_.cursors + 3, 8, hipMemcpyDeviceToHost, stream_));
+            HIP_OK(hipStreamSynchronize(stream_));
+        }
+        HIP_OK(hipMemsetAsync(d_.rec_want, 0, rec_cap_, stream_));
+        launch_k3_window_seq(d_, n_live, stream_);
+        if (rec_slots) {
+            launch_compact_wanted_recs(d_, rec_slots, sel_temp_, sel_temp_bytes_, reinterpret_cast<uint64_t*>(d_.cursors + 3), stream_);
+            HIP_OK(hipMemcpyAsync(&n_want, d_.cursors + 3, 8, hipMemcpyDeviceToHost, stream_));
+        }
         HIP_OK(hipEventRecord(ev_[3], stream_));
-        launch_k3b_haplotype_ids(d_, rec_slots, stream_);
+        HIP_OK(hipStreamSynchronize(stream_));
+        launch_k3b_haplotype_ids(d_, n_want, stream_);
         HIP_OK(hipEventRecord(ev_[4], stream_));
         HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
@@ -177,8 +197,10 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
-        t.n_group_slots = last_slots_ = slots;
-        t.n_recs = last_recs_ = rec_slots;
+        last_slots_ = slots;
+        last_recs_ = rec_slots;
+        t.n_group_slots = n_live;   // what K3 / K3b actually processed
+        t.n_recs = n_want;
         t.n_groups = cur[2];
         return;
     }

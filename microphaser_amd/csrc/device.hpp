@@ -59,6 +59,8 @@ class DeviceContext {
     int rpl_ = 1;
     uint32_t max_rows_bound_ = 0;
     uint64_t last_slots_ = 0, last_recs_ = 0;
+    void* sel_temp_ = nullptr;      // rocPRIM select workspace for the dense K3 / K3b index lists
+    size_t sel_temp_bytes_ = 0;
 };
 
 }  // namespace mp

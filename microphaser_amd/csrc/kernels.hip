@@ -10,6 +10,7 @@
 //                         profile, stop scan, SHA-1 id (reference: src/microphasing.rs:434-603,
 //                         :42-76, :667-675)
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include "kernels.hpp"
 
@@ -155,8 +156,8 @@ template <int RPL>
 __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     constexpr uint32_t GROUP_CHUNK = RPL <= 4 ? 256u : 64u * RPL;  // group slots per allocation (>= rows of one window)
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = d.tx_order[blockIdx.x];
-    const TxDev T = d.tx[t];
+    const SegDev S = d.segs[d.seg_order[blockIdx.x]];
+    const TxDev T = d.tx[S.tx];
     const uint32_t rbase = d.g_read_off[T.gene];
     const uint32_t vbase = d.g_var_off[T.gene];
     const bool is_rev = T.strand != 0;
@@ -219,11 +220,11 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
         if (q || (fl[r] & (RF_BAD | RF_SL))) { hap[r] = 0; fl[r] |= RF_BAD; }
     };
 
-    for (uint32_t s0 = 0; s0 < T.n_steps; s0 += 64) {
-        const uint32_t nb = min(64u, T.n_steps - s0);
+    for (uint32_t s0 = 0; s0 < S.n_steps; s0 += 64) {
+        const uint32_t nb = min(64u, S.n_steps - s0);
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0;
         if (lane < nb) {
-            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + (T.step_off + s0 + lane));
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + (S.step_off + s0 + lane));
             w0 = sp[0]; w1 = sp[1]; w2 = sp[2]; w3 = sp[3]; w4 = sp[4]; w5 = sp[5];
         }
         for (uint32_t i = 0; i < nb; i++) {
@@ -440,8 +441,6 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     const uint64_t nm = __ballot(need);
                     const uint32_t nneed = __popcll(nm);
                     if (nneed && rec_pos + nneed > rec_end) {
-                        for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the chunk's unused tail
-                            if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
                         unsigned long long base = 0;
                         if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)REC_CHUNK);
                         uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
@@ -557,8 +556,6 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
             }
         }
     }
-    for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the last record chunk's unused tail
-        if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
     if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
@@ -584,8 +581,8 @@ struct EpochMeta { int32_t xmin, xmax; int32_t w, range; };
 template <int RPL>
 __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = d.tx_order[blockIdx.x];
-    const TxDev T = d.tx[t];
+    const SegDev S = d.segs[d.seg_order[blockIdx.x]];
+    const TxDev T = d.tx[S.tx];
     const uint32_t rbase = d.g_read_off[T.gene];
     const uint32_t vbase = d.g_var_off[T.gene];
     const bool is_rev = T.strand != 0;
@@ -644,13 +641,13 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
         return hi >= lo ? uint32_t(hi - lo + 1) : 0u;
     };
 
-    for (uint32_t s0 = 0; s0 < T.n_steps; s0 += 64) {
-        const uint32_t nb = min(64u, T.n_steps - s0);
+    for (uint32_t s0 = 0; s0 < S.n_steps; s0 += 64) {
+        const uint32_t nb = min(64u, S.n_steps - s0);
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
         if (lane < nb) {
-            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + (T.step_off + s0 + lane));
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + (S.step_off + s0 + lane));
             w0 = sp[0]; w1 = sp[1]; w2 = sp[2]; w3 = sp[3]; w4 = sp[4]; w5 = sp[5];
-            w6 = d.step_aux[T.step_off + s0 + lane];
+            w6 = d.step_aux[S.step_off + s0 + lane];
         }
         for (uint32_t i = 0; i < nb; i++) {
             const int32_t sso = int32_t(rdlane(w0, i));
@@ -802,8 +799,6 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
             const bool can_write = chunk_end <= d.group_cap;
             if (!can_write) werr |= WD_GROUP_OVERFLOW;
             if (can_write && rec_pos + ng > rec_end) {
-                for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the chunk's unused tail
-                    if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
                 const uint32_t want = max(uint32_t(REC_CHUNK), ng);
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)want);
@@ -842,8 +837,6 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
             __syncthreads();
         }
     }
-    for (uint64_t q = rec_pos + lane; q < rec_end; q += 64)   // retire the last record chunk's unused tail
-        if (q < d.rec_cap) reinterpret_cast<uint32_t*>(d.recs + q * d.rec_stride)[7] = 0;
     if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
     if (sticky_err) atomicOr(d.err, sticky_err);
 }
@@ -936,13 +929,13 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
-    const uint64_t g = uint64_t(blockIdx.x) * K3_THREADS + tid;
-    const uint32_t lane = tid & 63;
+    const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;   // index into the dense list of live group slots
+    const uint64_t g = li < n_slots ? d.live_groups[li] : 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
     uint8_t* germ = seq + SEQ_CAP;
-    const uint32_t w = g < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
+    const uint32_t w = li < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
     const bool live = w != 0xFFFFFFFFu;
     uint32_t sumflags = 0;
     bool need_rec = false;
@@ -971,95 +964,124 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         };
         uint32_t i = ws.sso, j = 0, ns = 0, ngm = 0;
         bool indel = false, insertion = false, broke_flag = false;
-        uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
-        // the first 8 columns (in walk order) are fetched up front so their loads overlap instead of forming a dependent chain
-        uint32_t cpos[8], cinfo[8];
+        if (ws.flags & WSF_SIMPLE) {
+            // SNV-only window whose columns lie at strictly increasing positions inside the window (planner-checked): the
+            // walk of :473-601 visits every column exactly once, so the two sequences are the reference window with one
+            // byte replaced per set column - no per-base loop. 32 bytes are copied as dwords (wlen <= 32).
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            cpos[k] = 0xFFFFFFFFu; cinfo[k] = 0;
-            if (uint32_t(k) < ncols) {
-                const uint32_t dq = is_rev ? (ncols - 1 - k) : uint32_t(k);
-                const WinCol* wc = d.win_cols + ws.col_off + dq;
-                cpos[k] = wc->pos; cinfo[k] = wc->info;
+            for (int k = 0; k < 8; k++) {
+                const uint32_t v = __builtin_amdgcn_alignbyte(slot[k + 1], slot[k], mis);
+                slot[K3_REFCAP / 4 + k] = v;
+                slot[(K3_REFCAP + SEQ_CAP) / 4 + k] = v;
             }
-        }
-        auto load_j = [&]() {
-            if (j < 8) {
-                pos_j = cpos[0]; info_j = cinfo[0];
-#pragma unroll
-                for (int k = 1; k < 8; k++) if (j == uint32_t(k)) { pos_j = cpos[k]; info_j = cinfo[k]; }
-                if (j >= ncols) pos_j = 0xFFFFFFFFu;
-            } else if (j < ncols) {
-                uint32_t dq = is_rev ? (ncols - 1 - j) : j;
+            uint64_t rem = hap & (ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull));
+            while (rem) {
+                const uint32_t bit = uint32_t(__builtin_ctzll(rem));
+                rem &= rem - 1;
+                const uint32_t dq = ncols - 1 - bit;
                 const WinCol wc = d.win_cols[ws.col_off + dq];
-                pos_j = wc.pos;
-                info_j = wc.info;
-            } else {
-                pos_j = 0xFFFFFFFFu;
+                const uint32_t off = wc.pos - ws.sso;
+                const uint8_t r = refb[mis + off];
+                const uint8_t alt = uint8_t(wc.info >> VI_ALT_SHIFT);
+                const uint8_t sw = is_upper(r) ? to_lower(alt) : alt;
+                seq[off] = sw;
+                if (wc.info & VI_GERMLINE) germ[off] = sw; else nsom++;
+                nvar++;
+                prof_set |= 1ull << (is_rev ? bit : dq);
             }
-        };
-        auto col_f = [&]() { return d.win_cols[ws.col_off + (is_rev ? (ncols - 1 - j) : j)].f; };  // only indels need it
-        auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) seq[ns] = c; ns++; };
-        auto push_g = [&](uint8_t c) { if (ngm < SEQ_CAP) germ[ngm] = c; ngm++; };
-        load_j();
-        // sequence walk of print_haplotypes (:473-601); runs of plain reference bases are copied in bulk
-        while (i < window_end) {
-            while (j < ncols && i == pos_j) {
-                uint32_t fs = (info_j & VI_FS_MASK) >> VI_FS_SHIFT;
-                if (first_fs == 0 && fs) { first_fs = fs; first_fs_j = j; }
-                uint32_t dq = is_rev ? (ncols - 1 - j) : j;
-                uint32_t bit = ncols - 1 - dq;
-                if ((hap >> bit) & 1) {
-                    uint32_t kind = info_j & VI_KIND_MASK;
-                    bool germline = info_j & VI_GERMLINE;
-                    uint8_t r = ref_at(i);
-                    bool brk = false;
-                    if (kind == 0) {
-                        uint8_t alt = uint8_t(info_j >> VI_ALT_SHIFT);
-                        uint8_t sw = is_upper(r) ? to_lower(alt) : alt;
-                        push_g(germline ? sw : r);
-                        push_s(sw);
-                        i += 1;
-                    } else if (kind == 1) {
-                        f_j = col_f();
-                        uint32_t il = d.v_len[vbase + f_j] + 1;
-                        const uint8_t* ins = d.ins_pool + d.v_insoff[vbase + f_j];
-                        bool up = is_upper(r);
-                        for (uint32_t k = 0; k < il; k++) {
-                            uint8_t c = up ? to_lower(ins[k]) : to_upper(ins[k]);
-                            if (germline) push_g(c);
-                            push_s(c);
-                        }
-                        if (!germline) indel = true;
-                        insertion = true;
-                        i += 1;
-                    } else {
-                        f_j = col_f();
-                        uint32_t dl = d.v_len[vbase + f_j];
-                        if (is_rev && pos_j + dl - 1 >= window_end) { brk = true; }
-                        else {
-                            if (germline || i == window_end - 1) push_g(r);
-                            else {
-                                for (uint32_t k = 0; k < dl + 1; k++) push_g(ref_at(i + k));
-                                indel = true;
-                            }
-                            push_s(r);
-                            i += dl + 1;
-                        }
-                    }
-                    if (brk) { broke_flag = true; break; }
-                    if (!germline) nsom++;
-                    nvar++;
-                    prof_set |= 1ull << j;
+            ns = ngm = ws.wlen;
+            j = ncols;
+        } else {
+            uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
+            // the first 8 columns (in walk order) are fetched up front so their loads overlap instead of forming a dependent chain
+            uint32_t cpos[8], cinfo[8];
+    #pragma unroll
+            for (int k = 0; k < 8; k++) {
+                cpos[k] = 0xFFFFFFFFu; cinfo[k] = 0;
+                if (uint32_t(k) < ncols) {
+                    const uint32_t dq = is_rev ? (ncols - 1 - k) : uint32_t(k);
+                    const WinCol* wc = d.win_cols + ws.col_off + dq;
+                    cpos[k] = wc->pos; cinfo[k] = wc->info;
                 }
-                j++;
-                load_j();
             }
-            if (i < window_end) {
-                // the next position at which anything other than a reference copy can happen
-                // (a stuck cursor - pos_j <= i, e.g. after the incomplete-deletion break - never matches again)
-                uint32_t stop_at = (j < ncols && pos_j > i) ? min(pos_j, window_end) : window_end;
-                for (; i < stop_at; i++) { uint8_t r = ref_at(i); push_s(r); push_g(r); }
+            auto load_j = [&]() {
+                if (j < 8) {
+                    pos_j = cpos[0]; info_j = cinfo[0];
+    #pragma unroll
+                    for (int k = 1; k < 8; k++) if (j == uint32_t(k)) { pos_j = cpos[k]; info_j = cinfo[k]; }
+                    if (j >= ncols) pos_j = 0xFFFFFFFFu;
+                } else if (j < ncols) {
+                    uint32_t dq = is_rev ? (ncols - 1 - j) : j;
+                    const WinCol wc = d.win_cols[ws.col_off + dq];
+                    pos_j = wc.pos;
+                    info_j = wc.info;
+                } else {
+                    pos_j = 0xFFFFFFFFu;
+                }
+            };
+            auto col_f = [&]() { return d.win_cols[ws.col_off + (is_rev ? (ncols - 1 - j) : j)].f; };  // only indels need it
+            auto push_s = [&](uint8_t c) { if (ns < SEQ_CAP) seq[ns] = c; ns++; };
+            auto push_g = [&](uint8_t c) { if (ngm < SEQ_CAP) germ[ngm] = c; ngm++; };
+            load_j();
+            // sequence walk of print_haplotypes (:473-601); runs of plain reference bases are copied in bulk
+            while (i < window_end) {
+                while (j < ncols && i == pos_j) {
+                    uint32_t fs = (info_j & VI_FS_MASK) >> VI_FS_SHIFT;
+                    if (first_fs == 0 && fs) { first_fs = fs; first_fs_j = j; }
+                    uint32_t dq = is_rev ? (ncols - 1 - j) : j;
+                    uint32_t bit = ncols - 1 - dq;
+                    if ((hap >> bit) & 1) {
+                        uint32_t kind = info_j & VI_KIND_MASK;
+                        bool germline = info_j & VI_GERMLINE;
+                        uint8_t r = ref_at(i);
+                        bool brk = false;
+                        if (kind == 0) {
+                            uint8_t alt = uint8_t(info_j >> VI_ALT_SHIFT);
+                            uint8_t sw = is_upper(r) ? to_lower(alt) : alt;
+                            push_g(germline ? sw : r);
+                            push_s(sw);
+                            i += 1;
+                        } else if (kind == 1) {
+                            f_j = col_f();
+                            uint32_t il = d.v_len[vbase + f_j] + 1;
+                            const uint8_t* ins = d.ins_pool + d.v_insoff[vbase + f_j];
+                            bool up = is_upper(r);
+                            for (uint32_t k = 0; k < il; k++) {
+                                uint8_t c = up ? to_lower(ins[k]) : to_upper(ins[k]);
+                                if (germline) push_g(c);
+                                push_s(c);
+                            }
+                            if (!germline) indel = true;
+                            insertion = true;
+                            i += 1;
+                        } else {
+                            f_j = col_f();
+                            uint32_t dl = d.v_len[vbase + f_j];
+                            if (is_rev && pos_j + dl - 1 >= window_end) { brk = true; }
+                            else {
+                                if (germline || i == window_end - 1) push_g(r);
+                                else {
+                                    for (uint32_t k = 0; k < dl + 1; k++) push_g(ref_at(i + k));
+                                    indel = true;
+                                }
+                                push_s(r);
+                                i += dl + 1;
+                            }
+                        }
+                        if (brk) { broke_flag = true; break; }
+                        if (!germline) nsom++;
+                        nvar++;
+                        prof_set |= 1ull << j;
+                    }
+                    j++;
+                    load_j();
+                }
+                if (i < window_end) {
+                    // the next position at which anything other than a reference copy can happen
+                    // (a stuck cursor - pos_j <= i, e.g. after the incomplete-deletion break - never matches again)
+                    uint32_t stop_at = (j < ncols && pos_j > i) ? min(pos_j, window_end) : window_end;
+                    for (; i < stop_at; i++) { uint8_t r = ref_at(i); push_s(r); push_g(r); }
+                }
             }
         }
         seq_len = min(ns, uint32_t(SEQ_CAP));
@@ -1104,6 +1126,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                 out[5] = nsom | (first_fs << 8) | (first_fs_j << 16);
                 out[6] = w;
                 out[7] = want_id ? 1u : 0u;
+                if (want_id) d.rec_want[slot_idx] = 1;
                 const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
                 for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
@@ -1135,12 +1158,13 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
-    const uint64_t g = uint64_t(blockIdx.x) * K3_THREADS + tid;
+    const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;
+    const uint64_t g = li < n_slots ? d.live_groups[li] : 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
     uint32_t* germ_dw = slot + (K3_REFCAP + SEQ_CAP) / 4;
-    const uint32_t w = g < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
+    const uint32_t w = li < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
     if (w == 0xFFFFFFFFu) return;
     const WinStatic ws = d.wins[w];
     const uint32_t vbase = ws.vbase;
@@ -1237,6 +1261,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
         out[5] = min(nsom, 255u);
         out[6] = w;
         out[7] = skipped ? 0u : 1u;
+        if (!skipped) d.rec_want[slot_idx] = 1;
         const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
         for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
@@ -1256,10 +1281,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
 template <int SEQ_CAP>
 __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t n_recs) {
     __shared__ uint32_t lds_blk[64 * 17];
-    const uint64_t r = uint64_t(blockIdx.x) * 64 + threadIdx.x;
-    if (r >= n_recs) return;
+    const uint64_t li = uint64_t(blockIdx.x) * 64 + threadIdx.x;   // index into the dense list of records that need an id
+    if (li >= n_recs) return;
+    const uint64_t r = d.want_recs[li];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
-    if (rec[7] == 0) return;
     const uint32_t seq_len = rec[4] & 0xFF;
     const WinStatic ws = d.wins[rec[6]];
     const TxDev T = d.tx[ws.tx];
@@ -1293,6 +1318,39 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
     rec[3] = uint32_t(id60 >> 32);
 }
 
+// ====================================================================== compaction
+// K2's chunk allocators leave unused slots behind (one partly used chunk per wave); K3 / K3b therefore run over dense
+// index lists built here (rocPRIM select through hipCUB) instead of over the raw slot ranges.
+struct LiveGroupPred {
+    const uint32_t* g_win;
+    __device__ bool operator()(uint32_t i) const { return g_win[i] != 0xFFFFFFFFu; }
+};
+struct WantRecPred {
+    const uint8_t* want;
+    __device__ bool operator()(uint32_t i) const { return want[i] != 0; }
+};
+size_t compaction_temp_bytes(uint64_t n_max) {
+    size_t a = 0, b = 0;
+    uint32_t* out = nullptr;
+    uint64_t* cnt = nullptr;
+    hipcub::CountingInputIterator<uint32_t> it(0u);
+    if (hipcub::DeviceSelect::If(nullptr, a, it, out, cnt, int(n_max), LiveGroupPred{nullptr}, nullptr) != hipSuccess) throw_hip(hipErrorUnknown, __FILE__, __LINE__);
+    if (hipcub::DeviceSelect::If(nullptr, b, it, out, cnt, int(n_max), WantRecPred{nullptr}, nullptr) != hipSuccess) throw_hip(hipErrorUnknown, __FILE__, __LINE__);
+    return std::max(a, b) + 256;
+}
+void launch_compact_live_groups(const DeviceBatch& d, uint64_t n_slots, void* temp, size_t temp_bytes, uint64_t* d_count, hipStream_t stream) {
+    if (n_slots > 0x7FFFFFFFull) throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    hipcub::CountingInputIterator<uint32_t> it(0u);
+    hipError_t e = hipcub::DeviceSelect::If(temp, temp_bytes, it, d.live_groups, d_count, int(n_slots), LiveGroupPred{d.g_win}, stream);
+    if (e != hipSuccess) throw_hip(e, __FILE__, __LINE__);
+}
+void launch_compact_wanted_recs(const DeviceBatch& d, uint64_t n_recs, void* temp, size_t temp_bytes, uint64_t* d_count, hipStream_t stream) {
+    if (n_recs > 0x7FFFFFFFull) throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    hipcub::CountingInputIterator<uint32_t> it(0u);
+    hipError_t e = hipcub::DeviceSelect::If(temp, temp_bytes, it, d.want_recs, d_count, int(n_recs), WantRecPred{d.rec_want}, stream);
+    if (e != hipSuccess) throw_hip(e, __FILE__, __LINE__);
+}
+
 // ====================================================================== launchers
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
     if (d.n_reads == 0) return;
@@ -1312,8 +1370,8 @@ void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
 }
 
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream) {
-    if (d.n_tx == 0) return;
-    dim3 grid(d.n_tx), block(64);
+    if (d.n_segs == 0) return;
+    dim3 grid(d.n_segs), block(64);
     if (d.normal) {
         switch (rows_per_lane) {
             case 1: hipLaunchKernelGGL(k2n_window_replay<1>, grid, block, 0, stream, d); break;

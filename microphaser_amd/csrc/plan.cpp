@@ -36,6 +36,11 @@ struct PlannerHooksT {
     uint64_t max_seq_len = 0;
     // windows whose haplotypes currently sit in prev_hap_vec / hap_vec (they feed the next splice-side merge)
     uint32_t last_print_win = 0xFFFFFFFFu, held_prev = 0xFFFFFFFFu, held_hap = 0xFFFFFFFFu;
+    // segments: where the current one starts, the extreme candidate keys seen so far, prefix maximum of the read ends
+    const std::vector<uint32_t>* pmax_end = nullptr;
+    uint32_t seg_start = 0xFFFFFFFFu;
+    uint64_t seg_last_sso = 0, seg_low_key = ~0ull;
+    bool seg_any = false;
     // normal mode: list-once bookkeeping and the geometry of the previous step (epoch breaks)
     bool have_listed = false;
     uint32_t listed_lo = 0, listed_hi = 0;
@@ -80,7 +85,19 @@ struct PlannerHooksT {
         w.ewl = uint8_t(eg.ewl);
         w.splice_pos = uint8_t(sg.splice_pos);
         w.splice_gap = uint8_t(sg.splice_gap);
-        w.flags = uint8_t((st.flags & 0x7F) | (is_fwd ? 0 : WSF_REVERSE));
+        w.flags = uint8_t((st.flags & 0x7E) | (is_fwd ? 0 : WSF_REVERSE));
+        {   // WSF_SIMPLE: every column an SNV, positions strictly increasing in walk order (ascending) and inside the window
+            bool simple = !NORMAL && st.wlen <= 32;
+            uint64_t prev = 0;
+            bool first = true;
+            for (size_t k = 0; k < cols.size() && simple; k++) {
+                const Variant& v = vars[is_fwd ? cols[k] : cols[cols.size() - 1 - k]];
+                if (v.kind != VK_SNV || v.pos < st.sso || v.pos >= uint64_t(st.sso) + st.wlen || (!first && v.pos <= prev)) simple = false;
+                prev = v.pos;
+                first = false;
+            }
+            if (simple) w.flags |= WSF_SIMPLE;
+        }
         b.wins.push_back(w);
         // upper bound of the sequence lengths print_haplotypes can build for this window: the window itself, plus the
         // inserted bases, plus the reference bases a somatic deletion restores in the germline sequence (:547-577)
@@ -117,6 +134,31 @@ struct PlannerHooksT {
         if (sg.deleted > 255 || new_cols.size() > 255) throw Error("more than 255 column changes in one step");
         st.n_del = uint8_t(sg.deleted);
         st.n_add = uint8_t(new_cols.size());
+        // ---- segment break: nothing of the matrix may survive into this step (rows, pending candidates, columns)
+        {
+            const uint32_t here = uint32_t(b.steps.size());
+            if (seg_start == 0xFFFFFFFFu) { seg_start = here; b.seg_break_del.push_back(0); }   // one entry per segment (first of a transcript: no break)
+            else if (sg.is_first_exon_window && seg_any && cols.size() == sg.deleted) {
+                bool rows_may_survive;
+                if (is_fwd) {   // a read listed so far (start <= last sso) that still encloses: end >= splice_end
+                    const uint32_t n = read_lower(seg_last_sso + 1);
+                    rows_may_survive = n > 0 && uint64_t((*pmax_end)[gh.read_off + n - 1]) >= sg.splice_end;
+                } else {        // a read listed so far (start >= lowest key) that is not cleaned up: start <= sso
+                    rows_may_survive = seg_low_key <= sg.sso && read_lower(seg_low_key) < read_lower(sg.sso + 1);
+                }
+                if (std::getenv("MP_DEBUG_SEG")) std::fprintf(stderr, "seg? tx %u %s sso %llu end %llu cols %zu del %zu last_sso %llu low_key %llu survive %d\n", tx_idx, is_fwd ? "+" : "-", (unsigned long long)sg.sso, (unsigned long long)sg.splice_end, cols.size(), sg.deleted, (unsigned long long)seg_last_sso, (unsigned long long)seg_low_key, int(rows_may_survive));
+                if (!rows_may_survive) {
+                    b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, 0});
+                    seg_start = here;
+                    seg_low_key = ~0ull;
+                    b.seg_break_del.push_back(st.n_del);   // kept so that merge_short_segments can undo the break
+                    st.n_del = 0;   // the new segment's wave starts with an empty column deque: nothing to drop
+                }
+            }
+            seg_any = true;
+            seg_last_sso = is_fwd ? std::max(seg_last_sso, sg.sso) : sg.sso;
+            seg_low_key = std::min(seg_low_key, sg.cand_lo);
+        }
         for (size_t k = 0; k < sg.deleted; k++) cols.pop_front();
         if (sg.deleted || !new_cols.empty()) cols_dirty = true;
         for (size_t k : new_cols) {
@@ -198,6 +240,11 @@ struct PlannerHooksT {
         return {std::move(v), std::move(fsf)};
     }
 
+    void finish() {  // close the transcript's last segment
+        const uint32_t here = uint32_t(b.steps.size());
+        if (seg_start != 0xFFFFFFFFu && here > seg_start) b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, 0});
+    }
+
     void routed(bool to_prev) { (to_prev ? held_prev : held_hap) = last_print_win; }
 
     // the merge reads the full records of both carried-over windows (:1527-1540)
@@ -213,13 +260,64 @@ struct PlannerHooksT {
 
 }  // namespace
 
-static void build_batch_range(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
+// One wave per exon shortens the critical path but costs throughput (per-wave start-up, one partly used output chunk per
+// wave). Exon segments of one transcript are therefore merged back, in order, up to a target length that still leaves
+// every SIMD several waves: target = total steps / (2 x 8192 wave slots), at least 256 steps.
+static void merge_short_segments(Batch& b) {
+    if (b.segs.empty()) return;
+    if (b.seg_break_del.size() != b.segs.size()) throw Error("internal error: segment break bookkeeping out of step");
+    const uint64_t target = std::max<uint64_t>(256, b.steps.size() / 16384);
+    std::vector<SegDev> out;
+    out.reserve(b.segs.size());
+    for (size_t i = 0; i < b.segs.size(); i++) {
+        const SegDev& g = b.segs[i];
+        if (!out.empty() && out.back().tx == g.tx && out.back().step_off + out.back().n_steps == g.step_off &&
+            uint64_t(out.back().n_steps) + g.n_steps <= target) {
+            b.steps[g.step_off].n_del = b.seg_break_del[i];   // undo the break: the wave carries its columns across this exon start
+            out.back().n_steps += g.n_steps;
+        } else {
+            out.push_back(g);
+        }
+    }
+    b.segs.swap(out);
+    b.seg_break_del.clear();
+}
+
+// The replay kernels trust the plan: check on the host that every segment's column arithmetic stays in range.
+static void validate_segments(const Batch& b) {
+    uint64_t covered = 0;
+    for (const SegDev& g : b.segs) {
+        if (g.tx >= b.tx.size() || uint64_t(g.step_off) + g.n_steps > b.steps.size()) throw Error("internal error: segment outside the plan");
+        uint32_t ncols = 0;
+        for (uint32_t k = 0; k < g.n_steps; k++) {
+            const Step& st = b.steps[g.step_off + k];
+            if (st.n_del > ncols) throw Error("internal error: segment drops more columns than it holds");
+            ncols = ncols - st.n_del + st.n_add;
+            if (ncols > 63) throw Error("internal error: more than 63 live columns in a segment");
+            if (st.n_add > st.col_hi) throw Error("internal error: column index underflow in the plan");
+        }
+        covered += g.n_steps;
+    }
+    if (covered != b.steps.size()) throw Error("internal error: segments do not cover the plan");
+    if (b.normal && b.step_aux.size() != b.steps.size()) throw Error("internal error: step_aux out of step with the plan");
+}
+
+static void finalize_segments(Batch& b) {
+    merge_short_segments(b);
+    b.seg_order.resize(b.segs.size());
+    std::iota(b.seg_order.begin(), b.seg_order.end(), 0u);
+    std::stable_sort(b.seg_order.begin(), b.seg_order.end(), [&](uint32_t a, uint32_t c) { return b.segs[a].n_steps > b.segs[c].n_steps; });
+    validate_segments(b);
+}
+
+static void build_batch_range(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b, bool finalize) {
     const uint8_t mapq_min = normal ? 0 : 5;  // src/microphasing.rs:910 vs src/normal_microphasing.rs:676-684
     b = Batch();
     b.window_len = window_len;
     b.normal = normal;
     b.genes.resize(n_genes);
     uint32_t max_span_vars = 0;
+    std::vector<uint32_t> pmax_end;
     {   // reserve the big pools once
         size_t nr = 0, nref = 0, nv = 0;
         for (size_t g = 0; g < n_genes; g++) { nr += genes[g].reads.size(); nref += genes[g].refseq.size(); nv += genes[g].variants.size(); }
@@ -322,6 +420,9 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
                 max_span_vars = std::max<uint32_t>(max_span_vars, uint32_t(hi2 - vlo));
             }
         }
+        // prefix maximum of the read ends (reads are start-sorted): "can a read starting at or before X still reach Y"
+        pmax_end.resize(b.r_end.size());
+        for (uint32_t k = 0, m = 0; k < gh.n_reads; k++) { m = std::max(m, b.r_end[gh.read_off + k]); pmax_end[gh.read_off + k] = m; }
         // ---- refseq
         gh.ref_off = b.ref_pool.size();
         b.ref_pool.insert(b.ref_pool.end(), gi.refseq.begin(), gi.refseq.end());
@@ -352,7 +453,9 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
                 break;
             }
             auto run = [&](auto& hooks) {
+                hooks.pmax_end = &pmax_end;
                 walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks);
+                hooks.finish();
                 td.n_steps = uint32_t(b.steps.size()) - td.step_off;
                 b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
                 while (b.seq_cap < hooks.max_seq_len) b.seq_cap = b.seq_cap == SEQ_CAPS[0] ? SEQ_CAPS[1] : SEQ_CAPS[2];
@@ -373,9 +476,7 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
     b.g_var_off.push_back(uint32_t(b.v_pos.size()));
     b.mask_words = max_span_vars <= 64 ? 1 : max_span_vars <= 128 ? 2 : 4;
     if (max_span_vars > 256) throw Error("a read spans more than 256 variants; mask width not supported");
-    b.tx_order.resize(b.tx.size());
-    std::iota(b.tx_order.begin(), b.tx_order.end(), 0u);
-    std::stable_sort(b.tx_order.begin(), b.tx_order.end(), [&](uint32_t a, uint32_t c) { return b.tx[a].n_steps > b.tx[c].n_steps; });
+    if (finalize) finalize_segments(b);
 }
 
 size_t host_threads() {
@@ -414,6 +515,8 @@ void merge_batch(Batch& b, Batch& s) {
     for (uint32_t o : s.v_insoff) b.v_insoff.push_back(o + insOff);
     append(b.ins_pool, s.ins_pool); append(b.ref_pool, s.ref_pool);
     for (TxDev t : s.tx) { t.gene += gOff; t.step_off += sOff; t.id_off += strOff; b.tx.push_back(t); }
+    for (SegDev g : s.segs) { g.tx += tOff; g.step_off += sOff; b.segs.push_back(g); }
+    append(b.seg_break_del, s.seg_break_del);
     for (Step st : s.steps) { if (st.win != 0xFFFFFFFFu) st.win += wOff; st.exon += eOff; b.steps.push_back(st); }
     b.step_aux.insert(b.step_aux.end(), s.step_aux.begin(), s.step_aux.end());
     for (WinStatic w : s.wins) { w.tx += tOff; w.col_off += wcOff; w.ref_off += uint32_t(refOff); w.vbase += vOff; w.step += sOff; b.wins.push_back(w); }
@@ -431,7 +534,7 @@ void merge_batch(Batch& b, Batch& s) {
 // Genes are independent: plan gene ranges on worker threads, then concatenate the sub-batches in gene order.
 void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
     size_t nthreads = std::min(host_threads(), std::max<size_t>(1, n_genes / 8));
-    if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, normal, b); return; }
+    if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, normal, b, true); return; }
     std::vector<uint64_t> cost(n_genes + 1, 0);
     for (size_t g = 0; g < n_genes; g++) cost[g + 1] = cost[g] + genes[g].reads.size() + genes[g].refseq.size() / 8 + 1;
     std::vector<size_t> cut(nthreads + 1, n_genes);
@@ -446,7 +549,7 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
     std::vector<std::thread> th;
     for (size_t t = 0; t < nthreads; t++)
         th.emplace_back([&, t] {
-            try { build_batch_range(genes + cut[t], cut[t + 1] - cut[t], rs, window_len, normal, parts[t]); }
+            try { build_batch_range(genes + cut[t], cut[t + 1] - cut[t], rs, window_len, normal, parts[t], false); }
             catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
         });
     for (auto& x : th) x.join();
@@ -458,9 +561,7 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
     for (size_t t = 0; t < nthreads; t++) merge_batch(b, parts[t]);
     b.g_read_off.push_back(uint32_t(b.r_pos.size()));
     b.g_var_off.push_back(uint32_t(b.v_pos.size()));
-    b.tx_order.resize(b.tx.size());
-    std::iota(b.tx_order.begin(), b.tx_order.end(), 0u);
-    std::stable_sort(b.tx_order.begin(), b.tx_order.end(), [&](uint32_t a, uint32_t c) { return b.tx[a].n_steps > b.tx[c].n_steps; });
+    finalize_segments(b);
 }
 
 uint64_t Batch::bytes_k1_in() const {

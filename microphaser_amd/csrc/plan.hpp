@@ -36,6 +36,16 @@ struct TxDev {           // one per coding transcript
     uint32_t id_off, id_len; // transcript id bytes in the string pool (hashed into haplotype ids)
 };
 
+// A transcript is replayed as one or more independent segments (whole exons): a new segment starts at the first window
+// of an exon when the planner can prove that no row, pending candidate or column of the matrix survives into it, so
+// the replay kernels give one wave to each segment instead of one to each transcript (shorter critical path).
+struct SegDev {
+    uint32_t tx;         // TxDev index
+    uint32_t step_off;   // first Step of the segment
+    uint32_t n_steps;
+    uint32_t pad;
+};
+
 // Step.flags
 enum : uint8_t {
     SF_PRINT = 1,        // print_haplotypes may be called at this step (superset)
@@ -84,6 +94,8 @@ enum : uint8_t {
     WS_CARRY = 2,        // the window's haplotypes are carried into a splice-side merge -> records
 };
 constexpr uint8_t WSF_REVERSE = 128;  // transcript on the '-' strand (SF_* use bits 0..6)
+constexpr uint8_t WSF_SIMPLE = 1;     // (replaces SF_PRINT, always set for a window) SNV-only columns at strictly increasing positions inside
+                                      // the window, wlen <= 32: K3 builds the sequences by byte substitution instead of walking
 struct WinCol {          // one live variant column of a printing window
     uint32_t f;          // gene-relative forward variant index
     uint32_t pos;        // v_pos
