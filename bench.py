@@ -143,6 +143,18 @@ def main():
         dom = max(kern, key=lambda k: kern[k][0])
         dom_ms, dom_bytes = kern[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes of this very command, so
+        # they come from the committed summary of those passes (tools/pmc_traffic.py), only when it is for this workload
+        traffic, traffic_src = None, None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+            try:
+                pt = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            if pt.get("config") == args.config and not args.transcripts and dom in pt.get("kernels", {}):
+                traffic, traffic_src = pt["kernels"][dom]["hbm_bytes"], os.path.relpath(path, ROOT)
+                break
         out = {
             "metric": "peptide-windows/s (somatic, 9-mer)", "value": value, "unit": "peptide-windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -152,7 +164,7 @@ def main():
                        "windows_per_gpu": int(windows), "reads_per_gpu": int(st.n_reads), "variants_per_gpu": int(st.n_variants),
                        "transcripts_per_gpu": int(st.n_transcripts), "window_len": 27, "sharding": "genes, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
             "kernels_ms": {k: v[0] for k, v in kern.items()},
             "kernels_algorithmic_bytes": {k: int(v[1]) for k, v in kern.items()},

@@ -173,14 +173,20 @@ void DeviceContext::run(RunTiming& t) {
         }
         const uint64_t slots = cur[0], rec_slots = cur[1];
         // dense lists: K3 over the used group slots, K3b over the records that need an id (cursors[3] = list length)
+        // (the list only pays when many slots are unused - many short segments; otherwise K3 walks the raw range)
         uint64_t n_live = 0, n_want = 0;
-        if (slots) {
+        const bool dense = slots && (slots - cur[2]) * 4 > slots;
+        DeviceBatch d3 = d_;
+        if (dense) {
             launch_compact_live_groups(d_, slots, sel_temp_, sel_temp_bytes_, reinterpret_cast<uint64_t*>(d_.cursors + 3), stream_);
             HIP_OK(hipMemcpyAsync(&n_live, d_.cursors + 3, 8, hipMemcpyDeviceToHost, stream_));
             HIP_OK(hipStreamSynchronize(stream_));
+        } else {
+            d3.live_groups = nullptr;
+            n_live = slots;
         }
         HIP_OK(hipMemsetAsync(d_.rec_want, 0, rec_cap_, stream_));
-        launch_k3_window_seq(d_, n_live, stream_);
+        launch_k3_window_seq(d3, n_live, stream_);
         if (rec_slots) {
             launch_compact_wanted_recs(d_, rec_slots, sel_temp_, sel_temp_bytes_, reinterpret_cast<uint64_t*>(d_.cursors + 3), stream_);
             HIP_OK(hipMemcpyAsync(&n_want, d_.cursors + 3, 8, hipMemcpyDeviceToHost, stream_));
@@ -199,7 +205,7 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         last_slots_ = slots;
         last_recs_ = rec_slots;
-        t.n_group_slots = n_live;   // what K3 / K3b actually processed
+        t.n_group_slots = dense ? n_live : cur[2];   // groups K3 processed / records K3b hashed
         t.n_recs = n_want;
         t.n_groups = cur[2];
         return;

@@ -930,7 +930,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;   // index into the dense list of live group slots
-    const uint64_t g = li < n_slots ? d.live_groups[li] : 0;
+    const uint64_t g = li < n_slots ? (d.live_groups ? uint64_t(d.live_groups[li]) : li) : 0;   // dense list, or the raw slot range
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         else if (ws.splice_pos == 0 && !insertion) nhi = this_len;
         bool stop = false;
         uint32_t nlen = nhi - nlo;
-        if (nlen >= 3) {
+        if (nlen >= 3 && !(ws.flags & WSF_NOSTOP)) {   // WSF_NOSTOP: planner proved that no haplotype of this window can hold a stop
             if (!is_rev) {
                 for (uint32_t c = 0; c + 3 <= nlen; c += 3)
                     if (stop_codon_at(seq + nlo, c, true)) { stop = true; break; }
@@ -1103,10 +1103,14 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                     if (stop_codon_at(seq + nlo, uint32_t(c), false)) { stop = true; break; }
             }
         }
-        bool differs = seq_len != germ_len;
-        if (!differs)
-            for (uint32_t k = 0; k < seq_len; k++)
-                if (seq[k] != germ[k]) { differs = true; break; }
+        bool differs;
+        if (ws.flags & WSF_SIMPLE) differs = nsom > 0;   // a set somatic SNV always changes its byte (base or case)
+        else {
+            differs = seq_len != germ_len;
+            if (!differs)
+                for (uint32_t k = 0; k < seq_len; k++)
+                    if (seq[k] != germ[k]) { differs = true; break; }
+        }
         sumflags = GS_VALID | (stop ? GS_STOP : 0) | (differs ? GS_DIFFERS : 0) | (indel ? GS_INDEL : 0) |
                    (insertion ? GS_INSERTION : 0) | (broke_flag ? GS_BROKE : 0);
         need_rec = nsom > 0 || ws.need_recs != 0;
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;
-    const uint64_t g = li < n_slots ? d.live_groups[li] : 0;
+    const uint64_t g = li < n_slots ? (d.live_groups ? uint64_t(d.live_groups[li]) : li) : 0;   // dense list, or the raw slot range
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;

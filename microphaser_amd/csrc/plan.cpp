@@ -85,7 +85,7 @@ struct PlannerHooksT {
         w.ewl = uint8_t(eg.ewl);
         w.splice_pos = uint8_t(sg.splice_pos);
         w.splice_gap = uint8_t(sg.splice_gap);
-        w.flags = uint8_t((st.flags & 0x7E) | (is_fwd ? 0 : WSF_REVERSE));
+        w.flags = uint8_t((st.flags & 0x7C) | (is_fwd ? 0 : WSF_REVERSE));
         {   // WSF_SIMPLE: every column an SNV, positions strictly increasing in walk order (ascending) and inside the window
             bool simple = !NORMAL && st.wlen <= 32;
             uint64_t prev = 0;
@@ -97,6 +97,27 @@ struct PlannerHooksT {
                 first = false;
             }
             if (simple) w.flags |= WSF_SIMPLE;
+            if (simple) {   // WSF_NOSTOP: has_stop_codon (:42-76) on the reference slice, which no SNV haplotype can extend
+                const uint8_t* rw = gh.input->refseq.data() + (st.sso - gh.input->gene.start());
+                bool upper = true;
+                for (uint32_t k = 0; k < st.wlen; k++) upper &= rw[k] >= 'A' && rw[k] <= 'Z';
+                const uint32_t seq_len = st.wlen, this_len = std::min<uint32_t>(seq_len, uint32_t(eg.ewl));
+                uint32_t nlo = 0, nhi = seq_len;
+                if (sg.splice_pos == 1) nlo = std::min<uint32_t>(uint32_t(sg.splice_gap), seq_len);
+                else if (sg.splice_pos == 0) nhi = this_len;
+                bool ref_stop = false;
+                auto is_stop = [&](uint32_t c) {
+                    const uint8_t a = rw[nlo + c], b2 = rw[nlo + c + 1], e = rw[nlo + c + 2];
+                    if (is_fwd) return a == 'T' && ((b2 == 'G' && e == 'A') || (b2 == 'A' && (e == 'G' || e == 'A')));
+                    return (a == 'T' && b2 == 'C' && e == 'A') || (a == 'C' && b2 == 'T' && e == 'A') || (a == 'T' && b2 == 'T' && e == 'A');
+                };
+                const uint32_t nlen = nhi - nlo;
+                if (nlen >= 3) {
+                    if (is_fwd) { for (uint32_t c = 0; c + 3 <= nlen; c += 3) ref_stop |= is_stop(c); }
+                    else { for (int c = int(nlen) - 3; c >= 0; c -= 3) ref_stop |= is_stop(uint32_t(c)); }
+                }
+                if (upper && !ref_stop) w.flags |= WSF_NOSTOP;
+            }
         }
         b.wins.push_back(w);
         // upper bound of the sequence lengths print_haplotypes can build for this window: the window itself, plus the

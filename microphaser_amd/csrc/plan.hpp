@@ -94,6 +94,8 @@ enum : uint8_t {
     WS_CARRY = 2,        // the window's haplotypes are carried into a splice-side merge -> records
 };
 constexpr uint8_t WSF_REVERSE = 128;  // transcript on the '-' strand (SF_* use bits 0..6)
+constexpr uint8_t WSF_NOSTOP = 2;     // (replaces SF_FULL_RANGE) simple window over an all-upper-case reference without a stop codon in the
+                                      // peptide frame: a variant base is lower-case there and can never complete a stop (:42-76) -> no scan
 constexpr uint8_t WSF_SIMPLE = 1;     // (replaces SF_PRINT, always set for a window) SNV-only columns at strictly increasing positions inside
                                       // the window, wlen <= 32: K3 builds the sequences by byte substitution instead of walking
 struct WinCol {          // one live variant column of a printing window
