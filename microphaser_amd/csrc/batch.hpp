@@ -57,7 +57,19 @@ struct Batch {
     std::vector<uint8_t> str_pool;        // transcript ids
     std::vector<SegDev> segs;             // independent replay units (whole exons of one transcript), see plan.hpp
     std::vector<uint32_t> seg_order;      // launch order (longest first)
-    std::vector<uint8_t> seg_break_del;   // planner scratch: the n_del each segment's first step had before the break
+    // window-parallel replay (somatic): per-step side arrays, eligible exons, their work items
+    std::vector<uint8_t> step_ncols;      // live columns after the step's appends
+    std::vector<uint32_t> step_rlo;       // gene-relative index of the first read that can still enclose the step's window
+    std::vector<uint16_t> step_rn;        // number of reads from there up to start <= sso (saturating)
+    struct SegInfo {                      // planner scratch, parallel to segs until finalize
+        uint32_t n_exons = 0; bool cols_ok = true; uint32_t max_rn = 0; uint32_t read_lo = 0xFFFFFFFFu, read_hi = 0;
+        uint32_t first_key_lo = 0, range = 0, tr0 = 0, f0 = 0; bool have_col = false; bool dup = false;
+    };
+    std::vector<SegInfo> seg_info;
+    std::vector<ExonW> exons_w;
+    std::vector<WChunk> wchunks;
+    uint64_t n_adm = 0;                   // AdmEntry count (sum of ExonW::n_reads)
+    std::vector<uint64_t> v_sombits;      // bit (variant index in the batch) set <=> somatic
     // ---- sizing
     uint32_t seq_cap = 48;                // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks

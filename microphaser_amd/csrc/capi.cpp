@@ -144,8 +144,12 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
         if (std::getenv("MP_DEBUG")) {
             uint32_t mx = 0;
             for (const SegDev& g : b->batch.segs) mx = std::max(mx, g.n_steps);
-            std::fprintf(stderr, "[mp] plan: %zu transcripts, %zu segments (longest %u steps), %zu steps, %zu windows\n", b->batch.tx.size(),
-                         b->batch.segs.size(), mx, b->batch.steps.size(), b->batch.wins.size());
+            uint64_t wsteps = 0;
+            for (const ExonW& e : b->batch.exons_w) wsteps += e.n_steps;
+            std::fprintf(stderr, "[mp] plan: %zu transcripts, %zu steps, %zu windows; sequential replay: %zu segments (longest %u steps); "
+                         "window-parallel: %zu exons, %llu steps, %zu work items, %llu admission entries\n", b->batch.tx.size(),
+                         b->batch.steps.size(), b->batch.wins.size(), b->batch.segs.size(), mx, b->batch.exons_w.size(),
+                         (unsigned long long)wsteps, b->batch.wchunks.size(), (unsigned long long)b->batch.n_adm);
         }
         if (ctx->dev) {
             ctx->dev->upload(b->batch);

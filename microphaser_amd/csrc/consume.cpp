@@ -171,7 +171,7 @@ struct ConsumerHooks {
         uint64_t zero_slot = ~0ull;
         for (uint32_t k = 0; k < wd.ngroups; k++) {
             uint64_t slot = uint64_t(wd.group_off) + k;
-            const Group& G = res.groups[slot];
+            const Group& G = res.grp(slot);
             if (G.hap == 0 && zero_slot == ~0ull) zero_slot = slot;
             if (G.count == 0) continue;
             uint64_t f0 = G.aux >> 1;
@@ -201,7 +201,7 @@ struct ConsumerHooks {
         std::vector<HapSeq> haplotypes_vec;
         uint64_t shift_in_window = 0;
         for (const Key& key : keys) {
-            const GroupSum& gs = res.gsum[key.slot];
+            const GroupSum& gs = res.gsm(key.slot);
             if (!(gs.flags & GS_VALID)) throw Error("internal error: haplotype was not processed by the window-sequence kernel");
             const HapRecHdr* rec = (gs.flags & GS_HAS_REC) ? res.rec(gs.rec) : nullptr;
             const uint8_t* rseq = rec ? res.rec_seq(gs.rec) : nullptr;
@@ -541,13 +541,13 @@ struct NormalConsumerHooks {
         const uint32_t nrows = wd.nrows;
         std::vector<HapSeq> haplotypes_vec;
         bool any_counted = false;
-        for (uint32_t k = 0; k < wd.ngroups; k++) any_counted |= res.groups[uint64_t(wd.group_off) + k].count != 0;
+        for (uint32_t k = 0; k < wd.ngroups; k++) any_counted |= res.grp(uint64_t(wd.group_off) + k).count != 0;
         for (uint32_t k = 0; k < wd.ngroups; k++) {
             const uint64_t slot = uint64_t(wd.group_off) + k;
-            const Group& G = res.groups[slot];
+            const Group& G = res.grp(slot);
             // the zero-count reference group only stands in when no read covers the window (:388-390)
             if (G.count == 0 && (any_counted || G.hap != 0)) continue;
-            const GroupSum& gs = res.gsum[slot];
+            const GroupSum& gs = res.gsm(slot);
             if (!(gs.flags & GS_VALID) || !(gs.flags & GS_HAS_REC))
                 throw Error("internal error: haplotype was not processed by the window-sequence kernel");
             if (gs.flags & GS_BROKE) throw Error("internal error: haplotype sequence exceeds the record capacity");

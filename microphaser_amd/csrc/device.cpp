@@ -91,6 +91,16 @@ void DeviceContext::upload(const Batch& b) {
     d_.wins = up(b.wins);
     d_.win_cols = up(b.win_cols);
     d_.str_pool = up(b.str_pool);
+    d_.exons_w = up(b.exons_w);
+    d_.wchunks = up(b.wchunks);
+    d_.step_ncols = up(b.step_ncols);
+    d_.step_rlo = up(b.step_rlo);
+    d_.step_rn = up(b.step_rn);
+    d_.v_sombits = up(b.v_sombits);
+    d_.n_exons_w = uint32_t(b.exons_w.size());
+    d_.n_wchunks = uint32_t(b.wchunks.size());
+    d_.n_adm = b.n_adm;
+    d_.adm = static_cast<AdmEntry*>(dalloc(size_t(b.n_adm + 1) * sizeof(AdmEntry))); allocs_.push_back(d_.adm);
     d_.segs = up(b.segs);
     d_.seg_order = up(b.seg_order);
     d_.n_segs = uint32_t(b.segs.size());
@@ -106,33 +116,41 @@ void DeviceContext::upload(const Batch& b) {
     d_.r_sup = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_sup);
     d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);
     d_.win_dyn = static_cast<WinDyn*>(dalloc(size_t(d_.n_wins) * sizeof(WinDyn))); allocs_.push_back(d_.win_dyn);
-    d_.cursors = static_cast<unsigned long long*>(dalloc(32)); allocs_.push_back(d_.cursors);
+    d_.cursors = static_cast<unsigned long long*>(dalloc((NPART * 32 + 16) * 8)); allocs_.push_back(d_.cursors);
+    part_prefix_ = static_cast<unsigned long long*>(dalloc(2 * (NPART + 1) * 8)); allocs_.push_back(part_prefix_);
+    d_.part_prefix = part_prefix_;
+    d_.want_prefix = part_prefix_ + (NPART + 1);
     d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
-    // first guess: 6 distinct haplotypes per window + chunk slack per transcript
-    group_cap_ = uint64_t(d_.n_wins) * 6 + uint64_t(d_.n_tx + 1) * 1024 + 4096;  // slack: one partly used chunk per transcript
-    rec_cap_ = group_cap_ / 3 + uint64_t(d_.n_tx + 1) * 128 + 4096;
-    if (b.normal) rec_cap_ = group_cap_;   // every haplotype of every window has a record in this mode
+    // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
+    const uint64_t waves = b.wchunks.size() + b.segs.size();
+    uint64_t g_need = uint64_t(d_.n_wins) * 6 + waves * 256 + 4096;
+    uint64_t r_need = g_need / 3 + waves * 128 + 4096;
+    if (b.normal) { g_need += waves * 1024; r_need = g_need; }   // every haplotype of every window has a record in this mode
+    glog_ = 12; rlog_ = 12;
+    while ((uint64_t(NPART) << glog_) < g_need + g_need / 4) glog_++;
+    while ((uint64_t(NPART) << rlog_) < r_need + r_need / 4) rlog_++;
     alloc_outputs();
     HIP_OK(hipStreamSynchronize(stream_));
 }
 
 void DeviceContext::alloc_outputs() {
     free_outputs();
+    group_cap_ = uint64_t(NPART) << glog_;
+    rec_cap_ = uint64_t(NPART) << rlog_;
+    if (group_cap_ > 0x7FFFFFFFull || rec_cap_ > 0x7FFFFFFFull) throw Error("result buffers exceed 2^31 slots: split the batch by genes");
     auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); return p; };
     d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
     d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
     d_.recs = static_cast<uint8_t*>(oalloc(rec_cap_ * d_.rec_stride));
-    d_.live_groups = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
-    d_.rec_want = static_cast<uint8_t*>(oalloc(rec_cap_));
     d_.want_recs = static_cast<uint32_t*>(oalloc(rec_cap_ * 4));
-    sel_temp_bytes_ = compaction_temp_bytes(std::max(group_cap_, rec_cap_));
-    sel_temp_ = oalloc(sel_temp_bytes_);
+    d_.group_part_log2 = glog_;
+    d_.rec_part_log2 = rlog_;
     d_.group_cap = group_cap_;
     d_.rec_cap = rec_cap_;
 }
@@ -143,7 +161,7 @@ void DeviceContext::run(RunTiming& t) {
     for (int attempt = 0; attempt < 8; attempt++) {
         t.attempts = uint32_t(attempt + 1);
         t.rows_per_lane = rpl_;
-        HIP_OK(hipMemsetAsync(d_.cursors, 0, 32, stream_));
+        HIP_OK(hipMemsetAsync(d_.cursors, 0, (NPART * 32 + 16) * 8, stream_));
         HIP_OK(hipMemsetAsync(d_.err, 0, 4, stream_));
         HIP_OK(hipMemsetAsync(d_.g_win, 0xFF, group_cap_ * 4, stream_));
         HIP_OK(hipMemsetAsync(d_.win_dyn, 0, size_t(d_.n_wins) * sizeof(WinDyn), stream_));
@@ -151,11 +169,12 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(ev_[0], stream_));
         launch_k1_pileup_bits(d_, stream_);
         HIP_OK(hipEventRecord(ev_[1], stream_));
-        launch_k2_window_replay(d_, rpl_, stream_);
+        launch_k2_window_replay(d_, rpl_, stream_);     // sequential replay of the segments that need it
+        launch_k2_window_parallel(d_, stream_);          // K2a + K2w: everything else, window-parallel
         HIP_OK(hipEventRecord(ev_[2], stream_));
-        unsigned long long cur[4] = {0, 0, 0, 0};
+        std::vector<unsigned long long> cur(NPART * 32);
         uint32_t err = 0;
-        HIP_OK(hipMemcpyAsync(cur, d_.cursors, 32, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(cur.data(), d_.cursors, cur.size() * 8, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
         if (err & WD_ROW_OVERFLOW) {
@@ -165,34 +184,43 @@ void DeviceContext::run(RunTiming& t) {
         }
         if (err & WD_EPOCH_OVERFLOW) throw Error("normal mode: more than 128 live column epochs in one transcript (variant density too high for this build)");
         if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 1024 distinct haplotypes in one window");
-        if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || cur[0] > group_cap_ || cur[1] > rec_cap_) {
-            if ((err & WD_GROUP_OVERFLOW) || cur[0] > group_cap_) group_cap_ = std::max<uint64_t>(group_cap_ * 2, cur[0] + 4096);
-            if ((err & WD_REC_OVERFLOW) || cur[1] > rec_cap_) rec_cap_ = std::max<uint64_t>(rec_cap_ * 2, cur[1] + 4096);
+        uint64_t max_g = 0, max_r = 0;
+        for (uint32_t p = 0; p < NPART; p++) { max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]); }
+        if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || max_g > (1ull << glog_) || max_r > (1ull << rlog_)) {
+            while ((1ull << glog_) < max_g + max_g / 8) glog_++;
+            while ((1ull << rlog_) < max_r + max_r / 8) rlog_++;
+            if ((err & WD_GROUP_OVERFLOW) && max_g <= (1ull << glog_) / 2) glog_++;   // flagged without a cursor past the end: grow anyway
+            if ((err & WD_REC_OVERFLOW) && max_r <= (1ull << rlog_) / 2) rlog_++;
             alloc_outputs();
             continue;
         }
-        const uint64_t slots = cur[0], rec_slots = cur[1];
-        // dense lists: K3 over the used group slots, K3b over the records that need an id (cursors[3] = list length)
-        // (the list only pays when many slots are unused - many short segments; otherwise K3 walks the raw range)
-        uint64_t n_live = 0, n_want = 0;
-        const bool dense = slots && (slots - cur[2]) * 4 > slots;
-        DeviceBatch d3 = d_;
-        if (dense) {
-            launch_compact_live_groups(d_, slots, sel_temp_, sel_temp_bytes_, reinterpret_cast<uint64_t*>(d_.cursors + 3), stream_);
-            HIP_OK(hipMemcpyAsync(&n_live, d_.cursors + 3, 8, hipMemcpyDeviceToHost, stream_));
-            HIP_OK(hipStreamSynchronize(stream_));
-        } else {
-            d3.live_groups = nullptr;
-            n_live = slots;
+        unsigned long long prefix[NPART + 1];
+        uint64_t slots = 0, rec_slots = 0;
+        for (uint32_t p = 0; p < NPART; p++) {
+            used_g_[p] = cur[p * 32];
+            used_r_[p] = cur[p * 32 + 16];
+            prefix[p] = slots;
+            slots += used_g_[p];
+            rec_slots += used_r_[p];
         }
-        HIP_OK(hipMemsetAsync(d_.rec_want, 0, rec_cap_, stream_));
-        launch_k3_window_seq(d3, n_live, stream_);
-        if (rec_slots) {
-            launch_compact_wanted_recs(d_, rec_slots, sel_temp_, sel_temp_bytes_, reinterpret_cast<uint64_t*>(d_.cursors + 3), stream_);
-            HIP_OK(hipMemcpyAsync(&n_want, d_.cursors + 3, 8, hipMemcpyDeviceToHost, stream_));
-        }
+        prefix[NPART] = slots;
+        HIP_OK(hipMemcpyAsync(part_prefix_, prefix, sizeof prefix, hipMemcpyHostToDevice, stream_));
+        // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
+        uint64_t n_want = 0;
+        launch_k3_window_seq(d_, slots, stream_);
         HIP_OK(hipEventRecord(ev_[3], stream_));
+        HIP_OK(hipMemcpyAsync(cur.data(), d_.cursors, cur.size() * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
+        if (err & WD_REC_OVERFLOW) {   // a wanted list outgrew its sub-range (or K3 found a record slot missing): more room, again
+            rlog_++;
+            alloc_outputs();
+            continue;
+        }
+        unsigned long long wprefix[NPART + 1];
+        for (uint32_t p = 0; p < NPART; p++) { wprefix[p] = n_want; n_want += cur[p * 32 + 24]; }
+        wprefix[NPART] = n_want;
+        HIP_OK(hipMemcpyAsync(part_prefix_ + (NPART + 1), wprefix, sizeof wprefix, hipMemcpyHostToDevice, stream_));
         launch_k3b_haplotype_ids(d_, n_want, stream_);
         HIP_OK(hipEventRecord(ev_[4], stream_));
         HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
@@ -205,9 +233,9 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         last_slots_ = slots;
         last_recs_ = rec_slots;
-        t.n_group_slots = dense ? n_live : cur[2];   // groups K3 processed / records K3b hashed
+        t.n_group_slots = slots;    // group slots K3 walked (incl. the unused tail of each wave's last chunk) / records K3b hashed
         t.n_recs = n_want;
-        t.n_groups = cur[2];
+        t.n_groups = slots;
         return;
     }
     throw Error("device result buffers kept overflowing");
@@ -223,12 +251,25 @@ void DeviceContext::download(HostResults& r) {
     r.seq_cap = d_.seq_cap;
     r.rec_stride = d_.rec_stride;
     r.recs.resize(last_recs_ * d_.rec_stride);
+    r.group_part_log2 = glog_;
+    r.rec_part_log2 = rlog_;
     if (d_.n_wins) HIP_OK(hipMemcpyAsync(r.win_dyn.data(), d_.win_dyn, size_t(d_.n_wins) * sizeof(WinDyn), hipMemcpyDeviceToHost, stream_));
-    if (last_slots_) {
-        HIP_OK(hipMemcpyAsync(r.groups.data(), d_.groups, last_slots_ * sizeof(Group), hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(r.gsum.data(), d_.gsum, last_slots_ * sizeof(GroupSum), hipMemcpyDeviceToHost, stream_));
+    uint64_t go = 0, ro = 0;
+    for (uint32_t p = 0; p < NPART; p++) {   // the used prefix of every allocator's sub-range, back to back
+        r.group_prefix[p] = go;
+        r.rec_prefix[p] = ro;
+        if (used_g_[p]) {
+            HIP_OK(hipMemcpyAsync(r.groups.data() + go, d_.groups + (uint64_t(p) << glog_), used_g_[p] * sizeof(Group), hipMemcpyDeviceToHost, stream_));
+            HIP_OK(hipMemcpyAsync(r.gsum.data() + go, d_.gsum + (uint64_t(p) << glog_), used_g_[p] * sizeof(GroupSum), hipMemcpyDeviceToHost, stream_));
+        }
+        if (used_r_[p])
+            HIP_OK(hipMemcpyAsync(r.recs.data() + ro * d_.rec_stride, d_.recs + (uint64_t(p) << rlog_) * d_.rec_stride, used_r_[p] * d_.rec_stride,
+                                  hipMemcpyDeviceToHost, stream_));
+        go += used_g_[p];
+        ro += used_r_[p];
     }
-    if (last_recs_) HIP_OK(hipMemcpyAsync(r.recs.data(), d_.recs, last_recs_ * d_.rec_stride, hipMemcpyDeviceToHost, stream_));
+    r.group_prefix[NPART] = go;
+    r.rec_prefix[NPART] = ro;
     HIP_OK(hipStreamSynchronize(stream_));
 }
 

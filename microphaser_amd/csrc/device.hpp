@@ -10,14 +10,22 @@
 namespace mp {
 
 struct HostResults {         // device results copied back for the consumer
+    // Group / record slots are global indices (allocator << log2 size) + offset (kernels.hpp NPART); only the used prefix
+    // of every allocator's sub-range is copied, back to back, and the accessors translate.
     std::vector<WinDyn> win_dyn;
     std::vector<Group> groups;
     std::vector<GroupSum> gsum;
-    std::vector<uint8_t> recs;   // n_recs records of rec_stride bytes (HapRecHdr + seq + germ)
+    std::vector<uint8_t> recs;   // records of rec_stride bytes (HapRecHdr + seq + germ)
     uint32_t seq_cap = 48, rec_stride = 128;
-    const HapRecHdr* rec(uint64_t i) const { return reinterpret_cast<const HapRecHdr*>(recs.data() + i * rec_stride); }
-    const uint8_t* rec_seq(uint64_t i) const { return recs.data() + i * rec_stride + 32; }
-    const uint8_t* rec_germ(uint64_t i) const { return recs.data() + i * rec_stride + 32 + seq_cap; }
+    uint32_t group_part_log2 = 0, rec_part_log2 = 0;
+    uint64_t group_prefix[NPART + 1] = {0}, rec_prefix[NPART + 1] = {0};
+    size_t gidx(uint64_t slot) const { return size_t(group_prefix[slot >> group_part_log2] + (slot & ((1ull << group_part_log2) - 1))); }
+    size_t ridx(uint64_t i) const { return size_t(rec_prefix[i >> rec_part_log2] + (i & ((1ull << rec_part_log2) - 1))); }
+    const Group& grp(uint64_t slot) const { return groups[gidx(slot)]; }
+    const GroupSum& gsm(uint64_t slot) const { return gsum[gidx(slot)]; }
+    const HapRecHdr* rec(uint64_t i) const { return reinterpret_cast<const HapRecHdr*>(recs.data() + ridx(i) * rec_stride); }
+    const uint8_t* rec_seq(uint64_t i) const { return recs.data() + ridx(i) * rec_stride + 32; }
+    const uint8_t* rec_germ(uint64_t i) const { return recs.data() + ridx(i) * rec_stride + 32 + seq_cap; }
     uint64_t n_group_slots = 0, n_recs = 0;
 };
 
@@ -55,12 +63,13 @@ class DeviceContext {
     std::vector<void*> allocs_, out_allocs_;
     DeviceBatch d_{};
     uint64_t hbm_bytes_ = 0;
-    uint64_t group_cap_ = 0, rec_cap_ = 0;
+    uint64_t group_cap_ = 0, rec_cap_ = 0;          // NPART << log2
+    uint32_t glog_ = 12, rlog_ = 12;                // log2 of one allocator's sub-range
+    uint64_t used_g_[NPART] = {0}, used_r_[NPART] = {0};   // slots used by each allocator in the last run()
+    unsigned long long* part_prefix_ = nullptr;
     int rpl_ = 1;
     uint32_t max_rows_bound_ = 0;
     uint64_t last_slots_ = 0, last_recs_ = 0;
-    void* sel_temp_ = nullptr;      // rocPRIM select workspace for the dense K3 / K3b index lists
-    size_t sel_temp_bytes_ = 0;
 };
 
 }  // namespace mp

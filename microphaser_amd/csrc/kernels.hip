@@ -10,7 +10,6 @@
 //                         profile, stop scan, SHA-1 id (reference: src/microphasing.rs:434-603,
 //                         :42-76, :667-675)
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include "kernels.hpp"
 
@@ -156,6 +155,12 @@ template <int RPL>
 __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     constexpr uint32_t GROUP_CHUNK = RPL <= 4 ? 256u : 64u * RPL;  // group slots per allocation (>= rows of one window)
     const uint32_t lane = threadIdx.x;
+    // this wave's output allocator (kernels.hpp NPART)
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long* const gcur = d.cursors + part * 32;
+    unsigned long long* const rcur = gcur + 16;
+    const uint64_t gpart_lo = uint64_t(part) << d.group_part_log2, gpart_hi = uint64_t(part + 1) << d.group_part_log2;
+    const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_hi = uint64_t(part + 1) << d.rec_part_log2;
     const SegDev S = d.segs[d.seg_order[blockIdx.x]];
     const TxDev T = d.tx[S.tx];
     const uint32_t rbase = d.g_read_off[T.gene];
@@ -219,6 +224,37 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
         }
         if (q || (fl[r] & (RF_BAD | RF_SL))) { hap[r] = 0; fl[r] |= RF_BAD; }
     };
+
+    // extend_right for one column (transcription-order index tr): bookkeeping + the new bit of every row (:232-256)
+    auto append_column = [&](uint32_t tr) {
+        uint32_t f = is_rev ? d.v_rev2fwd[vbase + tr] : tr;
+        uint32_t info = d.v_info[vbase + f];
+        uint32_t pos = d.v_pos[vbase + f];
+        if (pos >= T.sl_lo && pos < T.sl_hi) info |= 0x80000000u; else info &= 0x7FFFFFFFu;
+        __syncthreads();
+        if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
+        if (ncols == 0) { contig = true; f_oldest = f; }
+        else contig = contig && (f == (is_rev ? f_newest - 1 : f_newest + 1));
+        f_newest = f;
+        ncols++;
+        som_mask = (som_mask << 1) | ((info & VI_GERMLINE) ? 0ull : 1ull);
+        special_mask = (special_mask << 1) | (((info & VI_FS_MASK) || (info & 0x80000000u)) ? 1ull : 0ull);
+        n_special = uint32_t(__popcll(special_mask));
+#pragma unroll
+        for (int r = 0; r < RPL; r++)
+            if ((fl[r] & ST_MASK) == ST_ROW) {
+                bool s, q;
+                bits_of(r, f, info, s, q);
+                hap[r] <<= 1;
+                update_row(r, s, q, info);
+            }
+    };
+    // the columns that were alive when the previous exon ended (no row is): the segment's initial deque
+    if (S.init_cols) {
+        const Step st0 = d.steps[S.step_off];
+        const uint32_t x = st0.col_hi - st0.n_add;
+        for (uint32_t a = 0; a < S.init_cols; a++) append_column(x - S.init_cols + a);
+    }
 
     for (uint32_t s0 = 0; s0 < S.n_steps; s0 += 64) {
         const uint32_t nb = min(64u, S.n_steps - s0);
@@ -378,30 +414,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     if ((fl[r] & ST_MASK) == ST_PENDING) fl[r] = ST_EMPTY;
             }
             // ---- extend_right (:232-256)
-            for (uint32_t a = 0; a < n_add; a++) {
-                uint32_t tr = col_hi - n_add + a;
-                uint32_t f = is_rev ? d.v_rev2fwd[vbase + tr] : tr;
-                uint32_t info = d.v_info[vbase + f];
-                uint32_t pos = d.v_pos[vbase + f];
-                if (pos >= T.sl_lo && pos < T.sl_hi) info |= 0x80000000u; else info &= 0x7FFFFFFFu;
-                __syncthreads();
-                if (lane == 0) { colf[(head + ncols) & 63] = f; colinfo[(head + ncols) & 63] = info; }
-                if (ncols == 0) { contig = true; f_oldest = f; }
-                else contig = contig && (f == (is_rev ? f_newest - 1 : f_newest + 1));
-                f_newest = f;
-                ncols++;
-                som_mask = (som_mask << 1) | ((info & VI_GERMLINE) ? 0ull : 1ull);
-                special_mask = (special_mask << 1) | (((info & VI_FS_MASK) || (info & 0x80000000u)) ? 1ull : 0ull);
-                n_special = uint32_t(__popcll(special_mask));
-#pragma unroll
-                for (int r = 0; r < RPL; r++)
-                    if ((fl[r] & ST_MASK) == ST_ROW) {
-                        bool s, q;
-                        bits_of(r, f, info, s, q);
-                        hap[r] <<= 1;
-                        update_row(r, s, q, info);
-                    }
-            }
+            for (uint32_t a = 0; a < n_add; a++) append_column(col_hi - n_add + a);
             // ---- count phase of print_haplotypes (:383-411)
             if (sflags & SF_PRINT) {
                 uint32_t nrows = 0, nvalid = 0;
@@ -423,12 +436,12 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                 uint32_t werr = sticky_err;
                 if (chunk_pos + nvalid > chunk_end) {
                     unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(d.cursors, (unsigned long long)GROUP_CHUNK);
+                    if (lane == 0) base = atomicAdd(gcur, (unsigned long long)GROUP_CHUNK);
                     uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
-                    chunk_pos = (uint64_t(bhi) << 32) | blo;
+                    chunk_pos = gpart_lo + ((uint64_t(bhi) << 32) | blo);
                     chunk_end = chunk_pos + GROUP_CHUNK;
                 }
-                const bool can_write = chunk_end <= d.group_cap && nvalid <= GROUP_CHUNK;
+                const bool can_write = chunk_end <= gpart_hi && nvalid <= GROUP_CHUNK;
                 if (!can_write) werr |= WD_GROUP_OVERFLOW;
                 const uint64_t gbase = chunk_pos;
                 uint32_t ng = 0;
@@ -442,17 +455,17 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     const uint32_t nneed = __popcll(nm);
                     if (nneed && rec_pos + nneed > rec_end) {
                         unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)REC_CHUNK);
+                        if (lane == 0) base = atomicAdd(rcur, (unsigned long long)REC_CHUNK);
                         uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
-                        rec_pos = (uint64_t(bhi) << 32) | blo;
+                        rec_pos = rpart_lo + ((uint64_t(bhi) << 32) | blo);
                         rec_end = rec_pos + REC_CHUNK;
                     }
                     uint32_t rec = 0xFFFFFFFFu;
                     if (need) {
                         const uint64_t r = rec_pos + lanes_below(nm, lane);
-                        if (r < d.rec_cap) rec = uint32_t(r);
+                        if (r < rpart_hi) rec = uint32_t(r);
                     }
-                    if (nneed && rec_pos + nneed > d.rec_cap) sticky_err |= WD_REC_OVERFLOW;
+                    if (nneed && rec_pos + nneed > rpart_hi) sticky_err |= WD_REC_OVERFLOW;
                     rec_pos += nneed;
                     if (on && can_write) {
                         Group G; G.hap = key; G.count = cnt; G.aux = ka;
@@ -556,7 +569,260 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
             }
         }
     }
-    if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
+    if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
+}
+
+// ====================================================================== K2a + K2w (window-parallel replay)
+// For an ExonW (plan.hpp) the observation matrix needs no sequential replay. push_read inserts a read at the first
+// step at which it is a candidate, encloses the window and carries no low-quality / start-loss support bit on a live
+// column (:297-343; '+': offered exactly once, '-': offered again until it is inserted or cleaned up); from then on
+// its row is sticky-bad iff such a bit shows up on any column appended later (:157-197), and its haplotype is its
+// support mask over the live columns. So:
+//   K2a  one thread per (exon, read): the insertion step and the oldest column the row has seen  -> AdmEntry
+//   K2w  one wave per run of steps: at every printing step the lanes take the <= 64 reads that can enclose the window,
+//        derive row / bad / haplotype from AdmEntry + K1 masks + the step's column range, then count exactly like K2.
+__device__ __forceinline__ uint64_t bit_range(uint32_t flo, uint32_t fhi, uint32_t base) {  // bits (f - base) for f in [flo, fhi), f - base in [0, 64)
+    const uint32_t lo = flo > base ? flo - base : 0u;
+    const uint32_t hi = fhi > base ? min(fhi - base, 64u) : 0u;
+    if (hi <= lo) return 0ull;
+    const uint64_t upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    return upto_hi & ~((1ull << lo) - 1ull);
+}
+// forward-index range [flo, fhi) of the columns with transcription-order index in [tlo, thi)
+__device__ __forceinline__ void tr_to_f(const ExonW& e, bool is_rev, uint32_t tlo, uint32_t thi, uint32_t& flo, uint32_t& fhi) {
+    if (thi <= tlo) { flo = fhi = 0; return; }
+    if (!is_rev) { flo = tlo; fhi = thi; }
+    else { flo = e.f0 - (thi - 1 - e.tr0); fhi = e.f0 - (tlo - e.tr0) + 1; }
+}
+
+__global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
+    const ExonW e = d.exons_w[blockIdx.x];   // one wave per exon, lanes stride over its reads
+    const TxDev T = d.tx[e.tx];
+    const bool is_rev = T.strand != 0;
+    const uint32_t rbase = d.g_read_off[T.gene] + e.read_lo;
+    const uint32_t sso0 = d.steps[e.step_off].sso;
+    const uint32_t sso1 = e.n_steps > 1 ? d.steps[e.step_off + 1].sso : sso0;
+    for (uint32_t k = threadIdx.x; k < e.n_reads; k += 64) {
+        const uint32_t gi = rbase + k;
+        const uint32_t start = d.r_pos[gi], end = d.r_end[gi], rvl = d.r_varlo[gi];
+        const uint64_t sup = d.r_sup[gi], lq = d.r_lq[gi];
+        const uint64_t dirty = lq | (sup & bit_range(e.sl_f_lo, e.sl_f_hi, rvl));   // low quality, or support of a start-loss variant
+        AdmEntry out;
+        out.ord = 0xFFFFFFFFu;
+        out.seen_lo = 0;
+        auto try_step = [&](uint32_t si) -> bool {   // push_read at step si (after shrink_left, before extend_right)
+            const Step st = d.steps[si];
+            if (end < st.sso + uint32_t(st.wlen) || start > st.sso) return false;
+            const uint32_t nc = d.step_ncols[si];
+            const uint32_t tlo = st.col_hi - nc, thi = st.col_hi - st.n_add;
+            uint32_t flo, fhi;
+            tr_to_f(e, is_rev, tlo, thi, flo, fhi);
+            if (dirty & bit_range(flo, fhi, rvl)) return false;
+            out.ord = si;
+            out.seen_lo = tlo;
+            return true;
+        };
+        if (!is_rev) {
+            if (start >= e.first_key_lo && start <= sso0) {
+                try_step(e.step_off);                   // the first window's candidate range (:1229-1240)
+            } else if (start > sso0 && e.n_steps > 1 && start >= sso1) {
+                // afterwards only the reads that start exactly at sso (:1241-1248); steps 1.. advance by one nt each
+                uint32_t t = 1 + (start - sso1);
+                if (t < e.n_steps) {
+                    uint32_t s_t = d.steps[e.step_off + t].sso;
+                    while (s_t > start && t > 1) s_t = d.steps[e.step_off + --t].sso;            // (never taken for unit steps)
+                    while (s_t < start && t + 1 < e.n_steps) s_t = d.steps[e.step_off + ++t].sso;
+                    if (s_t == start) try_step(e.step_off + t);
+                }
+            }
+        } else {
+            // candidate while sso - R <= start <= sso; sso never increases along the exon (one nt per step, repeats at the end)
+            const uint32_t top = start + e.range;
+            uint32_t t = sso0 > top ? sso0 - top : 0;   // first step with sso <= start + R if every step moved by one
+            if (t >= e.n_steps) t = e.n_steps - 1;
+            while (t > 0 && d.steps[e.step_off + t - 1].sso <= top) t--;
+            while (t < e.n_steps && d.steps[e.step_off + t].sso > top) t++;
+            for (; t < e.n_steps; t++) {
+                if (d.steps[e.step_off + t].sso < start) break;
+                if (try_step(e.step_off + t)) break;
+            }
+        }
+        d.adm[uint64_t(e.adm_off) + k] = out;
+    }
+}
+
+constexpr uint32_t K2W_ITEMS = 4;
+__global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
+    constexpr uint32_t GROUP_CHUNK = 64, REC_CHUNK_W = 64;   // small chunks: 64 allocators share the atomics, and the unused
+                                                             // tail of a wave's last chunk is all the slack K3 has to skip
+    const uint32_t lane = threadIdx.x;
+    // this wave's output allocator (kernels.hpp NPART)
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long* const gcur = d.cursors + part * 32;
+    unsigned long long* const rcur = gcur + 16;
+    const uint64_t gpart_lo = uint64_t(part) << d.group_part_log2, gpart_hi = uint64_t(part + 1) << d.group_part_log2;
+    const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_hi = uint64_t(part + 1) << d.rec_part_log2;
+    uint64_t chunk_pos = 0, chunk_end = 0, rec_pos = 0, rec_end = 0;
+    uint32_t sticky_err = 0;
+    // a wave takes K2W_ITEMS consecutive work items, so that one chunk tail is shared by ~100+ windows
+    for (uint32_t item = blockIdx.x * K2W_ITEMS; item < min(d.n_wchunks, (blockIdx.x + 1) * K2W_ITEMS); item++) {
+    const WChunk C = d.wchunks[item];
+    const ExonW e = d.exons_w[C.exon];
+    const TxDev T = d.tx[e.tx];
+    const bool is_rev = T.strand != 0;
+    const uint32_t rbase = d.g_read_off[T.gene];
+    const uint32_t vbase = d.g_var_off[T.gene];
+    // the lanes hold a sliding block of 64 consecutive reads [L, L + 64) of the exon's candidate range; a window's rows are
+    // the lanes inside its own range [r_lo, r_lo + r_n). The block moves only when a window's range leaves it.
+    uint32_t L = 0;
+    bool have_block = false;
+    uint32_t q_start = 0, q_end = 0, q_rvl = 0, q_ord = 0xFFFFFFFFu, q_seen = 0;
+    uint64_t q_sup = 0, q_dirty = 0;
+    for (uint32_t s0 = 0; s0 < C.n_steps; s0 += 64) {
+        const uint32_t nb = min(64u, C.n_steps - s0);
+        uint32_t w0 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0, w8 = 0, w9 = 0;
+        if (lane < nb) {
+            const uint32_t si = C.step_first + s0 + lane;
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + si);
+            w0 = sp[0]; w2 = sp[2]; w3 = sp[3]; w4 = sp[4]; w5 = sp[5];
+            w6 = d.step_rlo[si];
+            const uint32_t nc = d.step_ncols[si];
+            w7 = uint32_t(d.step_rn[si]) | (nc << 16);
+            if (((w5 >> 8) & SF_PRINT) && nc) {   // somatic columns of the step's window, already in haplotype bit order
+                uint32_t flo, fhi;
+                tr_to_f(e, is_rev, w2 - nc, w2, flo, fhi);
+                const uint64_t gv = uint64_t(vbase) + flo;
+                const uint64_t x0 = d.v_sombits[gv >> 6], x1 = d.v_sombits[(gv >> 6) + 1];
+                const uint32_t sh = uint32_t(gv & 63);
+                uint64_t bits = (sh ? ((x0 >> sh) | (x1 << (64 - sh))) : x0) & (~0ull >> (64 - nc));
+                if (!is_rev) bits = __brevll(bits) >> (64 - nc);
+                w8 = uint32_t(bits); w9 = uint32_t(bits >> 32);
+            }
+        }
+        uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT));
+        while (printing) {
+            const uint32_t i = uint32_t(__builtin_ctzll(printing));
+            printing &= printing - 1;
+            const uint32_t si = C.step_first + s0 + i;
+            const uint32_t sso = rdlane(w0, i), col_hi = rdlane(w2, i), win = rdlane(w3, i);
+            const uint32_t p4 = rdlane(w4, i), p5 = rdlane(w5, i), r_lo = rdlane(w6, i), p7 = rdlane(w7, i);
+            const uint64_t som_mask = (uint64_t(rdlane(w9, i)) << 32) | rdlane(w8, i);
+            const uint32_t wlen = (p4 >> 16) & 0xFF, sflags = (p5 >> 8) & 0xFF;
+            const uint32_t r_n = p7 & 0xFFFF, ncols = p7 >> 16;
+            const uint32_t splice_end = sso + wlen;
+            uint32_t flo, fhi;   // live columns: transcription order [col_hi - ncols, col_hi) -> forward indices [flo, fhi)
+            tr_to_f(e, is_rev, col_hi - ncols, col_hi, flo, fhi);
+            const uint64_t cmask = ncols ? (~0ull >> (64 - ncols)) : 0ull;
+            // ---- make sure the lanes hold this window's reads
+            if (r_n && (!have_block || r_lo < L || r_lo + r_n > L + 64)) {
+                const uint32_t r_hi = r_lo + r_n;
+                if (!is_rev) L = r_lo;                                   // '+' windows move to later reads
+                else L = r_hi > e.read_lo + 64 ? r_hi - 64 : e.read_lo;   // '-' windows move to earlier reads
+                have_block = true;
+                const uint32_t ri = L + lane;
+                q_ord = 0xFFFFFFFFu;
+                if (ri >= e.read_lo && ri < e.read_lo + e.n_reads) {
+                    const uint32_t gi = rbase + ri;
+                    q_start = d.r_pos[gi]; q_end = d.r_end[gi]; q_rvl = d.r_varlo[gi];
+                    q_sup = d.r_sup[gi];
+                    q_dirty = d.r_lq[gi] | (q_sup & bit_range(e.sl_f_lo, e.sl_f_hi, q_rvl));
+                    const AdmEntry a = d.adm[uint64_t(e.adm_off) + (ri - e.read_lo)];
+                    q_ord = a.ord; q_seen = a.seen_lo;
+                }
+                // consume the loads inside this (rare) branch: otherwise the wait for them lands after the join, where it would
+                // also drain the previous window's stores on every iteration
+                asm volatile("" : "+v"(q_start), "+v"(q_end), "+v"(q_rvl), "+v"(q_ord), "+v"(q_seen), "+v"(q_sup), "+v"(q_dirty));
+            }
+            // ---- the rows of this window
+            const uint32_t ri = L + lane;
+            bool row = r_n && ri >= r_lo && ri < r_lo + r_n && q_ord <= si &&
+                       (is_rev ? q_start <= sso : q_end >= splice_end);   // inserted, and not cleaned up since (:259-278)
+            bool act = false;
+            uint64_t hap = 0;
+            if (row) {
+                uint32_t slo, shi;
+                tr_to_f(e, is_rev, q_seen, col_hi, slo, shi);             // every column the row has seen
+                act = (q_dirty & bit_range(slo, shi, q_rvl)) == 0;
+                if (act && ncols) {
+                    const uint64_t sb = (flo >= q_rvl ? (flo - q_rvl < 64 ? q_sup >> (flo - q_rvl) : 0ull)
+                                                      : (q_rvl - flo < 64 ? q_sup << (q_rvl - flo) : 0ull)) & cmask;
+                    hap = is_rev ? sb : (__brevll(sb) >> (64 - ncols));
+                }
+            }
+            // ---- count phase of print_haplotypes (:383-411), as in k2_window_replay<1>
+            const uint32_t nrows = __popcll(__ballot(row));
+            const bool has_zero = __ballot(act && hap == 0) != 0;
+            uint32_t ng = has_zero ? 0u : 1u;   // lane 0 = zero-count reference haplotype
+            const bool need_all = (sflags & SF_NEED_RECS) != 0;
+            uint32_t khi_s = 0, klo_s = 0, cnt_s = 0;
+            const uint32_t my_hi = uint32_t(hap >> 32), my_lo = uint32_t(hap);
+            uint64_t rem = __ballot(act);
+            while (rem) {
+                const uint32_t l = __builtin_ctzll(rem);
+                const uint32_t kh = rdlane(my_hi, l), kl = rdlane(my_lo, l);
+                const uint64_t m = __ballot(act && my_hi == kh && my_lo == kl);
+                rem &= ~m;
+                if (lane == ng) { khi_s = kh; klo_s = kl; cnt_s = uint32_t(__popcll(m)); }
+                ng++;
+            }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < ng; j++) {
+                const uint32_t oh = rdlane(khi_s, j), ol = rdlane(klo_s, j);
+                rank += (oh < khi_s || (oh == khi_s && ol < klo_s)) ? 1u : 0u;
+            }
+            // group slots: exactly ng, from this wave's current chunk
+            uint32_t werr = sticky_err;
+            if (chunk_pos + ng > chunk_end) {
+                unsigned long long base = 0;
+                const uint32_t want = max(GROUP_CHUNK, ng);
+                if (lane == 0) base = atomicAdd(gcur, (unsigned long long)want);
+                const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                chunk_pos = gpart_lo + ((uint64_t(bhi) << 32) | blo);
+                chunk_end = chunk_pos + want;
+            }
+            const bool can_write = chunk_end <= gpart_hi;
+            if (!can_write) werr |= WD_GROUP_OVERFLOW;
+            const uint64_t gbase = chunk_pos;
+            {
+                const bool on = lane < ng;
+                const uint64_t key = (uint64_t(khi_s) << 32) | klo_s;
+                const bool need = on && can_write && (need_all || (key & som_mask) != 0);
+                const uint64_t nm = __ballot(need);
+                const uint32_t nneed = __popcll(nm);
+                if (nneed && rec_pos + nneed > rec_end) {
+                    unsigned long long base = 0;
+                    const uint32_t want = max(REC_CHUNK_W, nneed);
+                    if (lane == 0) base = atomicAdd(rcur, (unsigned long long)want);
+                    const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                    rec_pos = rpart_lo + ((uint64_t(bhi) << 32) | blo);
+                    rec_end = rec_pos + want;
+                }
+                uint32_t rec = 0xFFFFFFFFu;
+                if (need) {
+                    const uint64_t r = rec_pos + lanes_below(nm, lane);
+                    if (r < rpart_hi) rec = uint32_t(r);
+                }
+                if (nneed && rec_pos + nneed > rpart_hi) sticky_err |= WD_REC_OVERFLOW;
+                rec_pos += nneed;
+                if (on && can_write) {
+                    Group G; G.hap = key; G.count = cnt_s; G.aux = 0;
+                    d.groups[gbase + rank] = G;
+                    d.g_win[gbase + rank] = win;
+                    d.g_rec[gbase + rank] = rec;
+                }
+            }
+            if (lane == 0) {
+                WinDyn wd;
+                wd.group_off = uint32_t(gbase);
+                wd.ngroups = ng;
+                wd.nrows = nrows;
+                wd.flags = WD_DONE | werr;
+                d.win_dyn[win] = wd;
+            }
+            if (can_write) chunk_pos += ng;
+        }
+    }
+    }   // work items of this wave
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
 
@@ -581,6 +847,12 @@ struct EpochMeta { int32_t xmin, xmax; int32_t w, range; };
 template <int RPL>
 __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
     const uint32_t lane = threadIdx.x;
+    // this wave's output allocator (kernels.hpp NPART)
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long* const gcur = d.cursors + part * 32;
+    unsigned long long* const rcur = gcur + 16;
+    const uint64_t gpart_lo = uint64_t(part) << d.group_part_log2, gpart_hi = uint64_t(part + 1) << d.group_part_log2;
+    const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_hi = uint64_t(part + 1) << d.rec_part_log2;
     const SegDev S = d.segs[d.seg_order[blockIdx.x]];
     const TxDev T = d.tx[S.tx];
     const uint32_t rbase = d.g_read_off[T.gene];
@@ -640,6 +912,17 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
         }
         return hi >= lo ? uint32_t(hi - lo + 1) : 0u;
     };
+
+    if (S.init_cols) {   // the columns that were alive when the previous exon ended: the segment's initial deque
+        const Step st0 = d.steps[S.step_off];
+        const uint32_t x = st0.col_hi - st0.n_add;
+        for (uint32_t a = lane; a < S.init_cols; a += 64) {
+            const uint32_t tr = x - S.init_cols + a;
+            colf[a & 63] = uint16_t(is_rev ? d.v_rev2fwd[vbase + tr] : tr);
+        }
+        ncols = S.init_cols;
+        __syncthreads();
+    }
 
     for (uint32_t s0 = 0; s0 < S.n_steps; s0 += 64) {
         const uint32_t nb = min(64u, S.n_steps - s0);
@@ -791,22 +1074,22 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
             // group slots + one HapRec slot per haplotype (every haplotype of every window can be emitted in this mode)
             if (chunk_pos + ng > chunk_end) {
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(d.cursors, (unsigned long long)K2N_GROUP_CHUNK);
+                if (lane == 0) base = atomicAdd(gcur, (unsigned long long)K2N_GROUP_CHUNK);
                 const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
-                chunk_pos = (uint64_t(bhi) << 32) | blo;
+                chunk_pos = gpart_lo + ((uint64_t(bhi) << 32) | blo);
                 chunk_end = chunk_pos + K2N_GROUP_CHUNK;
             }
-            const bool can_write = chunk_end <= d.group_cap;
+            const bool can_write = chunk_end <= gpart_hi;
             if (!can_write) werr |= WD_GROUP_OVERFLOW;
             if (can_write && rec_pos + ng > rec_end) {
                 const uint32_t want = max(uint32_t(REC_CHUNK), ng);
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(d.cursors + 1, (unsigned long long)want);
+                if (lane == 0) base = atomicAdd(rcur, (unsigned long long)want);
                 const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
-                rec_pos = (uint64_t(bhi) << 32) | blo;
+                rec_pos = rpart_lo + ((uint64_t(bhi) << 32) | blo);
                 rec_end = rec_pos + want;
             }
-            if (can_write && rec_pos + ng > d.rec_cap) sticky_err |= WD_REC_OVERFLOW;
+            if (can_write && rec_pos + ng > rpart_hi) sticky_err |= WD_REC_OVERFLOW;
             const uint64_t gbase = chunk_pos;
             if (can_write) {
                 for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
@@ -819,7 +1102,7 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
                         d.groups[gbase + rank] = G;
                         d.g_win[gbase + rank] = win;
                         const uint64_t rec = rec_pos + rank;
-                        d.g_rec[gbase + rank] = rec < d.rec_cap ? uint32_t(rec) : 0xFFFFFFFFu;
+                        d.g_rec[gbase + rank] = rec < rpart_hi ? uint32_t(rec) : 0xFFFFFFFFu;
                     }
                 }
                 rec_pos += ng;
@@ -837,7 +1120,6 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
             __syncthreads();
         }
     }
-    if (lane == 0 && n_groups_tx) atomicAdd(d.cursors + 2, (unsigned long long)n_groups_tx);
     if (sticky_err) atomicOr(d.err, sticky_err);
 }
 
@@ -851,6 +1133,38 @@ __device__ __forceinline__ bool is_upper(uint8_t c) { return c >= 'A' && c <= 'Z
 __device__ __forceinline__ uint8_t to_lower(uint8_t c) { return is_upper(c) ? uint8_t(c + 32) : c; }
 __device__ __forceinline__ uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? uint8_t(c - 32) : c; }
 __device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+// li-th used group slot overall -> global slot: the used slots of allocator p are [p << log2, (p << log2) + used_p).
+// The search runs once per wave on its first index (uniform, scalar loads); a wave that straddles an allocator boundary
+// fixes up its upper lanes.
+__device__ __forceinline__ uint64_t slot_of(const DeviceBatch& d, uint64_t li, uint64_t wave_first) {
+    uint32_t lo = 0, hi = NPART;   // last p with part_prefix[p] <= wave_first
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (d.part_prefix[mid] <= wave_first) lo = mid; else hi = mid;
+    }
+    uint32_t p = lo;
+    while (p + 1 < NPART && d.part_prefix[p + 1] <= li) p++;
+    return (uint64_t(p) << d.group_part_log2) + (li - d.part_prefix[p]);
+}
+
+// K3 -> K3b: the records that need a SHA-1 id are appended to a dense list, one wave-aggregated atomic per wave on the
+// wave's own allocator (same NPART scheme as the output slots; list p lives at want_recs[p << rec_part_log2 ...]).
+__device__ __forceinline__ void append_wanted(const DeviceBatch& d, bool want, uint32_t rec_slot) {
+    const uint64_t m = __ballot(want);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t leader = uint32_t(__builtin_ctzll(m));
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(d.cursors + part * 32 + 24, (unsigned long long)__popcll(m));
+    const uint64_t b0 = (uint64_t(rdlane(uint32_t(base >> 32), leader)) << 32) | rdlane(uint32_t(base), leader);
+    if (want) {
+        const uint64_t off = b0 + lanes_below(m, lane);
+        if (off < (1ull << d.rec_part_log2)) d.want_recs[(uint64_t(part) << d.rec_part_log2) + off] = rec_slot;
+        else atomicOr(d.err, WD_REC_OVERFLOW);
+    }
+}
 
 constexpr int K3_THREADS = 64;                             // one wave per workgroup: LDS granularity 10.5 KB -> 15 waves/CU
 constexpr int K3_REFCAP = 36;                              // staged reference bytes (31-nt window + 3 alignment + 2)
@@ -930,7 +1244,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;   // index into the dense list of live group slots
-    const uint64_t g = li < n_slots ? (d.live_groups ? uint64_t(d.live_groups[li]) : li) : 0;   // dense list, or the raw slot range
+    const uint64_t g = li < n_slots ? slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS) : 0;   // li counts the used slots of all allocators
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -1130,7 +1444,6 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                 out[5] = nsom | (first_fs << 8) | (first_fs_j << 16);
                 out[6] = w;
                 out[7] = want_id ? 1u : 0u;
-                if (want_id) d.rec_want[slot_idx] = 1;
                 const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
                 for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
@@ -1143,6 +1456,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
             atomicOr(d.err, WD_REC_OVERFLOW);  // K2's superset rule missed a haplotype (must not happen) or the record buffer is full
         }
     }
+    append_wanted(d, live && (sumflags & GS_ID_VALID), recidx);
     if (live) {
         GroupSum gs;
         gs.flags = sumflags;
@@ -1163,7 +1477,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;
-    const uint64_t g = li < n_slots ? (d.live_groups ? uint64_t(d.live_groups[li]) : li) : 0;   // dense list, or the raw slot range
+    const uint64_t g = li < n_slots ? slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS) : 0;   // li counts the used slots of all allocators
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -1265,7 +1579,6 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
         out[5] = min(nsom, 255u);
         out[6] = w;
         out[7] = skipped ? 0u : 1u;
-        if (!skipped) d.rec_want[slot_idx] = 1;
         const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
         for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
@@ -1274,6 +1587,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     } else {
         atomicOr(d.err, WD_REC_OVERFLOW);
     }
+    append_wanted(d, (sumflags & GS_ID_VALID) != 0, recidx);
     GroupSum gs;
     gs.flags = sumflags;
     gs.rec = recidx;
@@ -1287,7 +1601,16 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
     __shared__ uint32_t lds_blk[64 * 17];
     const uint64_t li = uint64_t(blockIdx.x) * 64 + threadIdx.x;   // index into the dense list of records that need an id
     if (li >= n_recs) return;
-    const uint64_t r = d.want_recs[li];
+    uint32_t wp = 0;   // li-th wanted record overall -> list wp, offset li - want_prefix[wp]
+    {
+        uint32_t lo = 0, hi = NPART;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (d.want_prefix[mid] <= li) lo = mid; else hi = mid;
+        }
+        wp = lo;
+    }
+    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + (li - d.want_prefix[wp])];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
     const uint32_t seq_len = rec[4] & 0xFF;
     const WinStatic ws = d.wins[rec[6]];
@@ -1320,39 +1643,6 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
     uint64_t id60 = (uint64_t(sh.h0) << 28) | (uint64_t(sh.h1) >> 4);
     rec[2] = uint32_t(id60);
     rec[3] = uint32_t(id60 >> 32);
-}
-
-// ====================================================================== compaction
-// K2's chunk allocators leave unused slots behind (one partly used chunk per wave); K3 / K3b therefore run over dense
-// index lists built here (rocPRIM select through hipCUB) instead of over the raw slot ranges.
-struct LiveGroupPred {
-    const uint32_t* g_win;
-    __device__ bool operator()(uint32_t i) const { return g_win[i] != 0xFFFFFFFFu; }
-};
-struct WantRecPred {
-    const uint8_t* want;
-    __device__ bool operator()(uint32_t i) const { return want[i] != 0; }
-};
-size_t compaction_temp_bytes(uint64_t n_max) {
-    size_t a = 0, b = 0;
-    uint32_t* out = nullptr;
-    uint64_t* cnt = nullptr;
-    hipcub::CountingInputIterator<uint32_t> it(0u);
-    if (hipcub::DeviceSelect::If(nullptr, a, it, out, cnt, int(n_max), LiveGroupPred{nullptr}, nullptr) != hipSuccess) throw_hip(hipErrorUnknown, __FILE__, __LINE__);
-    if (hipcub::DeviceSelect::If(nullptr, b, it, out, cnt, int(n_max), WantRecPred{nullptr}, nullptr) != hipSuccess) throw_hip(hipErrorUnknown, __FILE__, __LINE__);
-    return std::max(a, b) + 256;
-}
-void launch_compact_live_groups(const DeviceBatch& d, uint64_t n_slots, void* temp, size_t temp_bytes, uint64_t* d_count, hipStream_t stream) {
-    if (n_slots > 0x7FFFFFFFull) throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
-    hipcub::CountingInputIterator<uint32_t> it(0u);
-    hipError_t e = hipcub::DeviceSelect::If(temp, temp_bytes, it, d.live_groups, d_count, int(n_slots), LiveGroupPred{d.g_win}, stream);
-    if (e != hipSuccess) throw_hip(e, __FILE__, __LINE__);
-}
-void launch_compact_wanted_recs(const DeviceBatch& d, uint64_t n_recs, void* temp, size_t temp_bytes, uint64_t* d_count, hipStream_t stream) {
-    if (n_recs > 0x7FFFFFFFull) throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
-    hipcub::CountingInputIterator<uint32_t> it(0u);
-    hipError_t e = hipcub::DeviceSelect::If(temp, temp_bytes, it, d.want_recs, d_count, int(n_recs), WantRecPred{d.rec_want}, stream);
-    if (e != hipSuccess) throw_hip(e, __FILE__, __LINE__);
 }
 
 // ====================================================================== launchers
@@ -1397,6 +1687,17 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
         default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
     HIP_CHECK_LAUNCH();
+}
+
+void launch_k2_window_parallel(const DeviceBatch& d, hipStream_t stream) {
+    if (d.n_adm) {
+        hipLaunchKernelGGL(k2a_admission, dim3(d.n_exons_w), dim3(64), 0, stream, d);
+        HIP_CHECK_LAUNCH();
+    }
+    if (d.n_wchunks) {
+        hipLaunchKernelGGL(k2w_window_rows, dim3((d.n_wchunks + K2W_ITEMS - 1) / K2W_ITEMS), dim3(64), 0, stream, d);
+        HIP_CHECK_LAUNCH();
+    }
 }
 
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {

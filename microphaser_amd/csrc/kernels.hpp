@@ -6,6 +6,8 @@
 
 namespace mp {
 
+constexpr uint32_t NPART = 64;   // output allocators (power of two)
+
 struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     // genes
     const uint32_t *g_read_off, *g_var_off, *g_start;
@@ -29,6 +31,16 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const SegDev* segs;           // replay units (K2 / K2n launch one wave per segment)
     const uint32_t* seg_order;
     uint32_t n_segs;
+    // window-parallel replay (K2a + K2w), see plan.hpp ExonW
+    const ExonW* exons_w;
+    const WChunk* wchunks;
+    const uint8_t* step_ncols;
+    const uint32_t* step_rlo;
+    const uint16_t* step_rn;
+    const uint64_t* v_sombits;      // bit (var_off + f) set <=> that variant is somatic
+    AdmEntry* adm;                  // K2a output
+    uint32_t n_exons_w, n_wchunks;
+    uint64_t n_adm;
     uint32_t n_reads, n_tx, n_wins, mask_words;
     uint32_t normal;              // 1: `microphaser normal` semantics (src/normal_microphasing.rs)
     const uint32_t* r_varlo;      // planner: gene-relative index of the first variant with pos >= r_pos
@@ -40,11 +52,16 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     Group* groups;
     uint32_t* g_win;              // window of each group slot (0xFFFFFFFF = unused slot)
     uint32_t* g_rec;              // HapRec slot reserved for the group by K2 (0xFFFFFFFF = none)
-    uint32_t* live_groups;        // dense list of the used group slots (built after K2; K3 runs over it)
-    uint8_t* rec_want;            // K3: 1 = this HapRec needs a SHA-1 id
-    uint32_t* want_recs;          // dense list of those records (built after K3; K3b runs over it)
-    unsigned long long* cursors;  // [0] group-slot cursor, [1] record-slot cursor, [2] number of groups
-    uint64_t group_cap, rec_cap;
+    uint32_t* want_recs;          // K3: NPART dense lists of the records that need a SHA-1 id (K3b runs over them)
+    const unsigned long long* want_prefix;   // after K3: [p] = number of entries in the lists < p (NPART + 1 entries)
+    // Output slots are handed out by NPART independent allocators (a wave uses allocator blockIdx & (NPART - 1)), each with
+    // its own cursors in their own 128-byte lines and its own power-of-two sub-range of the output arrays: slot =
+    // (partition << log2 size) + offset. One shared cursor serialises in L2 at ~60 atomics/us - with one wave per run of
+    // windows that alone would bound the replay.
+    unsigned long long* cursors;  // [p * 32] group-slot cursor of partition p, [p * 32 + 16] record-slot cursor, [p * 32 + 24] length of K3's wanted list p
+    const unsigned long long* part_prefix;   // after K2: [p] = number of group slots used by partitions < p (NPART + 1 entries)
+    uint32_t group_part_log2, rec_part_log2;
+    uint64_t group_cap, rec_cap;  // NPART << log2
     uint32_t* err;                // sticky error word (WD_* bits)
     // K3 output
     GroupSum* gsum;
@@ -56,10 +73,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
 // rows_per_lane in {1,2,4,8,16}. All launches are asynchronous on `stream`.
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
-// dense index lists for K3 / K3b (the chunk allocators of K2 leave unused slots behind); counts land in *d_count (u64)
-size_t compaction_temp_bytes(uint64_t n_max);
-void launch_compact_live_groups(const DeviceBatch& d, uint64_t n_slots, void* temp, size_t temp_bytes, uint64_t* d_count, hipStream_t stream);
-void launch_compact_wanted_recs(const DeviceBatch& d, uint64_t n_recs, void* temp, size_t temp_bytes, uint64_t* d_count, hipStream_t stream);
+void launch_k2_window_parallel(const DeviceBatch& d, hipStream_t stream);   // K2a + K2w over the ExonW part of the plan
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_live_groups, hipStream_t stream);
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream);
 

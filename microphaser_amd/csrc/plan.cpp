@@ -41,6 +41,16 @@ struct PlannerHooksT {
     uint32_t seg_start = 0xFFFFFFFFu;
     uint64_t seg_last_sso = 0, seg_low_key = ~0ull;
     bool seg_any = false;
+    Batch::SegInfo seg_info;       // eligibility inputs of the current segment (window-parallel replay)
+    uint32_t seg_prev_f = 0, seg_init_cols = 0;
+
+    // window-parallel replay wants SNV columns at consecutive forward indices (a linear tr -> f map over the segment)
+    void note_column(uint32_t f) {
+        if (!seg_info.have_col) { seg_info.have_col = true; seg_info.tr0 = tr_index(f); seg_info.f0 = f; }
+        else if (f != (is_fwd ? seg_prev_f + 1 : seg_prev_f - 1)) seg_info.cols_ok = false;
+        seg_prev_f = f;
+        if (vars[f].kind != VK_SNV) seg_info.cols_ok = false;
+    }
     // normal mode: list-once bookkeeping and the geometry of the previous step (epoch breaks)
     bool have_listed = false;
     uint32_t listed_lo = 0, listed_hi = 0;
@@ -55,6 +65,7 @@ struct PlannerHooksT {
         cur_exon = uint32_t(b.exons.size());
         b.exons.push_back(ep);
         have_prev_cand = false;
+        seg_info.n_exons++;
     }
 
     // gene-relative index of the first kept read with pos >= key
@@ -158,8 +169,8 @@ struct PlannerHooksT {
         // ---- segment break: nothing of the matrix may survive into this step (rows, pending candidates, columns)
         {
             const uint32_t here = uint32_t(b.steps.size());
-            if (seg_start == 0xFFFFFFFFu) { seg_start = here; b.seg_break_del.push_back(0); }   // one entry per segment (first of a transcript: no break)
-            else if (sg.is_first_exon_window && seg_any && cols.size() == sg.deleted) {
+            if (seg_start == 0xFFFFFFFFu) seg_start = here;
+            else if (sg.is_first_exon_window && seg_any) {
                 bool rows_may_survive;
                 if (is_fwd) {   // a read listed so far (start <= last sso) that still encloses: end >= splice_end
                     const uint32_t n = read_lower(seg_last_sso + 1);
@@ -169,11 +180,15 @@ struct PlannerHooksT {
                 }
                 if (std::getenv("MP_DEBUG_SEG")) std::fprintf(stderr, "seg? tx %u %s sso %llu end %llu cols %zu del %zu last_sso %llu low_key %llu survive %d\n", tx_idx, is_fwd ? "+" : "-", (unsigned long long)sg.sso, (unsigned long long)sg.splice_end, cols.size(), sg.deleted, (unsigned long long)seg_last_sso, (unsigned long long)seg_low_key, int(rows_may_survive));
                 if (!rows_may_survive) {
-                    b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, 0});
+                    seg_info.n_exons--;   // this exon's on_exon() already counted itself on the segment being closed
+                    b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, seg_init_cols});
+                    b.seg_info.push_back(seg_info);
+                    seg_info = Batch::SegInfo();
+                    seg_info.n_exons = 1;
                     seg_start = here;
                     seg_low_key = ~0ull;
-                    b.seg_break_del.push_back(st.n_del);   // kept so that merge_short_segments can undo the break
-                    st.n_del = 0;   // the new segment's wave starts with an empty column deque: nothing to drop
+                    seg_init_cols = uint32_t(cols.size());   // columns alive before this step's shrink_left
+                    for (uint32_t c : cols) note_column(c);  // they belong to the new segment's column range
                 }
             }
             seg_any = true;
@@ -182,6 +197,7 @@ struct PlannerHooksT {
         }
         for (size_t k = 0; k < sg.deleted; k++) cols.pop_front();
         if (sg.deleted || !new_cols.empty()) cols_dirty = true;
+        for (size_t k : new_cols) note_column(uint32_t(k));
         for (size_t k : new_cols) {
             // NOTE: the live columns are not always the window's own variants - the reference can leave a
             // stale column behind (deleted_vars forced to 0 when offset == old_offset, :1159) - so every
@@ -247,8 +263,22 @@ struct PlannerHooksT {
         // pending reverse-strand candidates have start >= sso - (max_read_len - ewl)
         uint64_t lo_rows = sg.splice_end > gh.max_ref_span ? sg.splice_end - gh.max_ref_span : 0;
         uint64_t lo_cand = sg.sso > gh.max_read_len - eg.ewl ? sg.sso - (gh.max_read_len - eg.ewl) : 0;
-        uint64_t span = uint64_t(read_lower(sg.cand_hi)) - read_lower(std::min(lo_rows, lo_cand));
+        const uint32_t r_hi = read_lower(sg.cand_hi), r_lo_rows = read_lower(lo_rows);
+        uint64_t span = uint64_t(r_hi) - std::min(r_lo_rows, read_lower(lo_cand));
         max_live = std::max(max_live, span);
+        if (!NORMAL) {   // side arrays of the window-parallel replay
+            const uint32_t rn = r_hi > r_lo_rows ? r_hi - r_lo_rows : 0;
+            b.step_ncols.push_back(uint8_t(cols.size()));
+            b.step_rlo.push_back(r_lo_rows);
+            b.step_rn.push_back(uint16_t(std::min<uint32_t>(rn, 0xFFFF)));
+            seg_info.max_rn = std::max(seg_info.max_rn, rn);
+            seg_info.read_lo = std::min(seg_info.read_lo, r_lo_rows);
+            seg_info.read_hi = std::max(seg_info.read_hi, r_hi);
+            if (b.steps.size() - 1 == seg_start) {   // first step of the segment
+                seg_info.first_key_lo = uint32_t(sg.cand_lo);
+                seg_info.range = uint32_t(sg.sso - sg.cand_lo);
+            }
+        }
         if (fs_seen) ensure_window(eg, sg);
     }
 
@@ -263,7 +293,7 @@ struct PlannerHooksT {
 
     void finish() {  // close the transcript's last segment
         const uint32_t here = uint32_t(b.steps.size());
-        if (seg_start != 0xFFFFFFFFu && here > seg_start) b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, 0});
+        if (seg_start != 0xFFFFFFFFu && here > seg_start) { b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, seg_init_cols}); b.seg_info.push_back(seg_info); }
     }
 
     void routed(bool to_prev) { (to_prev ? held_prev : held_hap) = last_print_win; }
@@ -286,22 +316,17 @@ struct PlannerHooksT {
 // every SIMD several waves: target = total steps / (2 x 8192 wave slots), at least 256 steps.
 static void merge_short_segments(Batch& b) {
     if (b.segs.empty()) return;
-    if (b.seg_break_del.size() != b.segs.size()) throw Error("internal error: segment break bookkeeping out of step");
     const uint64_t target = std::max<uint64_t>(256, b.steps.size() / 16384);
     std::vector<SegDev> out;
     out.reserve(b.segs.size());
-    for (size_t i = 0; i < b.segs.size(); i++) {
-        const SegDev& g = b.segs[i];
+    for (const SegDev& g : b.segs) {
         if (!out.empty() && out.back().tx == g.tx && out.back().step_off + out.back().n_steps == g.step_off &&
-            uint64_t(out.back().n_steps) + g.n_steps <= target) {
-            b.steps[g.step_off].n_del = b.seg_break_del[i];   // undo the break: the wave carries its columns across this exon start
-            out.back().n_steps += g.n_steps;
-        } else {
+            uint64_t(out.back().n_steps) + g.n_steps <= target)
+            out.back().n_steps += g.n_steps;   // the wave simply carries its columns across this exon start
+        else
             out.push_back(g);
-        }
     }
     b.segs.swap(out);
-    b.seg_break_del.clear();
 }
 
 // The replay kernels trust the plan: check on the host that every segment's column arithmetic stays in range.
@@ -309,7 +334,8 @@ static void validate_segments(const Batch& b) {
     uint64_t covered = 0;
     for (const SegDev& g : b.segs) {
         if (g.tx >= b.tx.size() || uint64_t(g.step_off) + g.n_steps > b.steps.size()) throw Error("internal error: segment outside the plan");
-        uint32_t ncols = 0;
+        uint32_t ncols = g.init_cols;
+        if (g.n_steps && g.init_cols + b.steps[g.step_off].n_add > b.steps[g.step_off].col_hi) throw Error("internal error: initial columns underflow");
         for (uint32_t k = 0; k < g.n_steps; k++) {
             const Step& st = b.steps[g.step_off + k];
             if (st.n_del > ncols) throw Error("internal error: segment drops more columns than it holds");
@@ -319,11 +345,69 @@ static void validate_segments(const Batch& b) {
         }
         covered += g.n_steps;
     }
+    for (const ExonW& e : b.exons_w) {
+        if (uint64_t(e.step_off) + e.n_steps > b.steps.size() || e.tx >= b.tx.size()) throw Error("internal error: window-parallel exon outside the plan");
+        covered += e.n_steps;
+    }
+    for (const WChunk& c : b.wchunks)
+        if (c.exon >= b.exons_w.size() || c.step_first < b.exons_w[c.exon].step_off ||
+            uint64_t(c.step_first) + c.n_steps > uint64_t(b.exons_w[c.exon].step_off) + b.exons_w[c.exon].n_steps)
+            throw Error("internal error: work item outside its exon");
+    if (!b.normal && (b.step_ncols.size() != b.steps.size() || b.step_rlo.size() != b.steps.size() || b.step_rn.size() != b.steps.size()))
+        throw Error("internal error: step side arrays out of step with the plan");
     if (covered != b.steps.size()) throw Error("internal error: segments do not cover the plan");
     if (b.normal && b.step_aux.size() != b.steps.size()) throw Error("internal error: step_aux out of step with the plan");
 }
 
+// Decide which single-exon segments go to the window-parallel replay (plan.hpp ExonW) and cut them into work items.
+static void route_window_parallel(Batch& b) {
+    // packed somatic flags of all variants (K2w derives a window's somatic-column mask from it)
+    b.v_sombits.assign(b.v_pos.size() / 64 + 2, 0);
+    for (size_t v = 0; v < b.v_info.size(); v++)
+        if (!(b.v_info[v] & VI_GERMLINE)) b.v_sombits[v >> 6] |= 1ull << (v & 63);
+    b.exons_w.clear();
+    b.wchunks.clear();
+    b.n_adm = 0;
+    if (b.seg_info.size() != b.segs.size()) throw Error("internal error: segment info out of step");
+    const bool enabled = !b.normal && b.mask_words == 1 && !std::getenv("MP_SEQUENTIAL_REPLAY");
+    std::vector<SegDev> keep;
+    constexpr uint32_t CHUNK_STEPS = 96;
+    for (size_t i = 0; i < b.segs.size(); i++) {
+        const SegDev& g = b.segs[i];
+        const Batch::SegInfo& si = b.seg_info[i];
+        const TxDev& T = b.tx[g.tx];
+        const GeneHost& gh = b.genes[T.gene];
+        bool ok = enabled && si.n_exons == 1 && si.cols_ok && si.max_rn <= 64 && g.n_steps > 0;
+        const uint32_t read_lo = si.read_lo == 0xFFFFFFFFu ? 0 : si.read_lo;
+        const uint32_t read_hi = std::max(si.read_hi, read_lo);
+        if (ok && T.strand)   // `contains` (:281-294) can only hit when two reads of the range share a name
+            for (uint32_t r = read_lo; r < read_hi && ok; r++) ok = !(b.r_dup[gh.read_off + r] >> 31);
+        if (!ok && std::getenv("MP_DEBUG_SEG")) std::fprintf(stderr, "seq: tx %u steps %u n_exons %u cols_ok %d max_rn %u\n", g.tx, g.n_steps, si.n_exons, int(si.cols_ok), si.max_rn);
+        if (!ok) { keep.push_back(g); continue; }
+        ExonW e{};
+        e.tx = g.tx; e.step_off = g.step_off; e.n_steps = g.n_steps;
+        e.read_lo = read_lo; e.n_reads = read_hi - read_lo;
+        if (b.n_adm + e.n_reads > 0xFFFFFFF0ull) throw Error("batch too large for 32-bit admission-table offsets: split the batch by genes");
+        e.adm_off = uint32_t(b.n_adm);
+        b.n_adm += e.n_reads;
+        e.first_key_lo = si.first_key_lo; e.range = si.range; e.tr0 = si.tr0; e.f0 = si.f0;
+        const uint32_t* vp = b.v_pos.data() + gh.var_off;
+        e.sl_f_lo = e.sl_f_hi = 0;
+        if (T.sl_lo < T.sl_hi) {
+            e.sl_f_lo = uint32_t(std::lower_bound(vp, vp + gh.n_vars, T.sl_lo) - vp);
+            e.sl_f_hi = uint32_t(std::lower_bound(vp, vp + gh.n_vars, T.sl_hi) - vp);
+        }
+        const uint32_t ei = uint32_t(b.exons_w.size());
+        b.exons_w.push_back(e);
+        for (uint32_t s0 = 0; s0 < g.n_steps; s0 += CHUNK_STEPS)
+            b.wchunks.push_back(WChunk{ei, g.step_off + s0, std::min(CHUNK_STEPS, g.n_steps - s0), 0});
+    }
+    b.segs.swap(keep);
+    b.seg_info.clear();
+}
+
 static void finalize_segments(Batch& b) {
+    route_window_parallel(b);
     merge_short_segments(b);
     b.seg_order.resize(b.segs.size());
     std::iota(b.seg_order.begin(), b.seg_order.end(), 0u);
@@ -537,7 +621,8 @@ void merge_batch(Batch& b, Batch& s) {
     append(b.ins_pool, s.ins_pool); append(b.ref_pool, s.ref_pool);
     for (TxDev t : s.tx) { t.gene += gOff; t.step_off += sOff; t.id_off += strOff; b.tx.push_back(t); }
     for (SegDev g : s.segs) { g.tx += tOff; g.step_off += sOff; b.segs.push_back(g); }
-    append(b.seg_break_del, s.seg_break_del);
+    append(b.step_ncols, s.step_ncols); append(b.step_rlo, s.step_rlo); append(b.step_rn, s.step_rn);
+    b.seg_info.insert(b.seg_info.end(), s.seg_info.begin(), s.seg_info.end());
     for (Step st : s.steps) { if (st.win != 0xFFFFFFFFu) st.win += wOff; st.exon += eOff; b.steps.push_back(st); }
     b.step_aux.insert(b.step_aux.end(), s.step_aux.begin(), s.step_aux.end());
     for (WinStatic w : s.wins) { w.tx += tOff; w.col_off += wcOff; w.ref_off += uint32_t(refOff); w.vbase += vOff; w.step += sOff; b.wins.push_back(w); }

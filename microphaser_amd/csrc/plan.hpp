@@ -37,13 +37,36 @@ struct TxDev {           // one per coding transcript
 };
 
 // A transcript is replayed as one or more independent segments (whole exons): a new segment starts at the first window
-// of an exon when the planner can prove that no row, pending candidate or column of the matrix survives into it, so
-// the replay kernels give one wave to each segment instead of one to each transcript (shorter critical path).
+// of an exon when the planner can prove that no row or pending candidate of the matrix survives into it; the columns that
+// do survive (the reference can leave stale columns behind, :1159) are handed to the segment as its initial deque. The
+// replay kernels give one wave to each segment instead of one to each transcript (shorter critical path).
 struct SegDev {
     uint32_t tx;         // TxDev index
     uint32_t step_off;   // first Step of the segment
     uint32_t n_steps;
-    uint32_t pad;
+    uint32_t init_cols;  // live columns before the first step: transcription-order indices [x - init_cols, x), x = col_hi - n_add of that step
+};
+
+// Window-parallel replay (somatic mode, K2a + K2w): an independent single-exon segment whose columns are all SNVs at
+// consecutive variant indices, with at most 64 candidate reads per window and W = 1, needs no sequential state machine:
+// a read's admission step follows from its K1 masks and the plan (K2a), and the rows of a window are then a closed form
+// of (admission step, read span, masks, live column range) - one wave per run of windows (K2w).
+struct ExonW {
+    uint32_t tx;
+    uint32_t step_off, n_steps;
+    uint32_t read_lo, n_reads;      // gene-relative range of the reads that can be candidates in this exon
+    uint32_t adm_off;               // first AdmEntry of the exon (one per read of the range)
+    uint32_t first_key_lo;          // '+': lowest start key of the first window's candidate range (:1229-1248)
+    uint32_t range;                 // '-': candidate key range extent R - candidates have start in [sso - R, sso] (:1198-1226)
+    uint32_t tr0, f0;               // transcription-order index -> forward index: f = strand ? f0 - (tr - tr0) : tr
+    uint32_t sl_f_lo, sl_f_hi;      // forward index range of the variants inside the start-loss interval
+};
+struct WChunk {                     // K2w work item: a run of steps of one ExonW
+    uint32_t exon, step_first, n_steps, pad;
+};
+struct AdmEntry {                   // K2a output per (ExonW, read)
+    uint32_t ord;                   // step (index into steps) at which push_read inserts the read; 0xFFFFFFFF = never
+    uint32_t seen_lo;               // transcription-order index of the oldest column the row has seen (deque at that push)
 };
 
 // Step.flags
