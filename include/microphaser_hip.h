@@ -70,6 +70,12 @@ typedef struct mp_run_stats {
     uint64_t bytes_k1, bytes_k2, bytes_k3, bytes_k3b; /* algorithmic HBM bytes per launch */
     uint64_t hbm_bytes;                    /* device memory held by the batch */
     uint32_t rows_per_lane, mask_words, attempts;
+    uint32_t pad_;
+    /* k2_ms is three launches: the sequential replay of the segments that need it (k2_window_replay / k2n_window_replay), and
+     * the window-parallel replay of everything else (k2a_admission, k2w_window_rows); their times and algorithmic bytes */
+    double k2seq_ms, k2a_ms, k2w_ms;
+    uint64_t bytes_k2seq, bytes_k2a, bytes_k2w;
+    uint64_t n_steps_seq, n_steps_w, n_adm;    /* steps replayed sequentially / window-parallel, (exon, read) admission entries */
 } mp_run_stats;
 
 /* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM

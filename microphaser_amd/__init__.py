@@ -42,7 +42,10 @@ class RunStats(ctypes.Structure):
         ("n_groups", ctypes.c_uint64), ("n_records", ctypes.c_uint64),
         ("bytes_k1", ctypes.c_uint64), ("bytes_k2", ctypes.c_uint64), ("bytes_k3", ctypes.c_uint64), ("bytes_k3b", ctypes.c_uint64),
         ("hbm_bytes", ctypes.c_uint64),
-        ("rows_per_lane", ctypes.c_uint32), ("mask_words", ctypes.c_uint32), ("attempts", ctypes.c_uint32),
+        ("rows_per_lane", ctypes.c_uint32), ("mask_words", ctypes.c_uint32), ("attempts", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
+        ("k2seq_ms", ctypes.c_double), ("k2a_ms", ctypes.c_double), ("k2w_ms", ctypes.c_double),
+        ("bytes_k2seq", ctypes.c_uint64), ("bytes_k2a", ctypes.c_uint64), ("bytes_k2w", ctypes.c_uint64),
+        ("n_steps_seq", ctypes.c_uint64), ("n_steps_w", ctypes.c_uint64), ("n_adm", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -30,6 +30,8 @@ struct mp_batch {
     bool uploaded = false, ran = false;
     RunTiming timing;
     uint64_t sum_wlen = 0, sum_cols = 0;  // cached for the byte accounting
+    uint64_t w_steps = 0, w_wins = 0;     // steps / printing steps replayed window-parallel
+    bool w_wins_known = false;
 };
 struct mp_results {
     SomaticOutput out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty
@@ -179,8 +181,28 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 for (const WinStatic& w : b.wins) { batch->sum_wlen += w.wlen; batch->sum_cols += w.ncols; }
             const uint64_t sum_wlen = batch->sum_wlen, sum_cols = batch->sum_cols;
             st->bytes_k1 = b.bytes_k1_in() + b.bytes_k1_out();
-            st->bytes_k2 = b.steps.size() * sizeof(Step) + b.r_pos.size() * (20 + 16ull * b.mask_words) +
-                           b.wins.size() * sizeof(WinDyn) + t.n_groups * (sizeof(Group) + 4);
+            {   // the three parts of K2 (see include/microphaser_hip.h): each byte of its inputs / outputs counted once per launch
+                if (!batch->w_wins_known) {   // once per batch: these walk the whole plan
+                    for (const ExonW& e : b.exons_w) {
+                        batch->w_steps += e.n_steps;
+                        for (uint32_t k = 0; k < e.n_steps; k++) batch->w_wins += (b.steps[e.step_off + k].flags & SF_PRINT) ? 1 : 0;
+                    }
+                    batch->w_wins_known = true;
+                }
+                const uint64_t w_steps = batch->w_steps;
+                const uint64_t seq_steps = b.steps.size() - w_steps, seq_wins = b.wins.size() - batch->w_wins;
+                const double wfrac = b.wins.empty() ? 0.0 : double(batch->w_wins) / double(b.wins.size());
+                const uint64_t groups_w = uint64_t(double(t.n_groups) * wfrac), groups_seq = t.n_groups - groups_w;
+                const uint64_t read_bytes = 20 + 16ull * b.mask_words;   // start, end, first variant, coverage, dup + the two masks
+                st->k2seq_ms = t.k2seq_ms; st->k2a_ms = t.k2a_ms; st->k2w_ms = t.k2w_ms;
+                st->n_steps_seq = seq_steps; st->n_steps_w = w_steps; st->n_adm = b.n_adm;
+                st->bytes_k2a = b.n_adm * (read_bytes + sizeof(AdmEntry)) + b.exons_w.size() * sizeof(ExonW);
+                st->bytes_k2w = w_steps * (sizeof(Step) + 7) + b.n_adm * (read_bytes + sizeof(AdmEntry)) + batch->w_wins * sizeof(WinDyn) +
+                                groups_w * (sizeof(Group) + 8);
+                st->bytes_k2seq = seq_steps * sizeof(Step) + (b.steps.empty() ? 0 : uint64_t(double(b.r_pos.size()) * double(seq_steps) / double(b.steps.size()))) * read_bytes +
+                                  seq_wins * sizeof(WinDyn) + groups_seq * (sizeof(Group) + 8);
+                st->bytes_k2 = st->bytes_k2a + st->bytes_k2w + st->bytes_k2seq;
+            }
             st->bytes_k3 = t.n_groups * (sizeof(Group) + 4 + sizeof(GroupSum)) +
                            b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols + t.n_recs * hap_rec_stride(b.seq_cap);
             st->bytes_k3b = t.n_recs * (32 + b.seq_cap + 8);

@@ -170,7 +170,10 @@ void DeviceContext::run(RunTiming& t) {
         launch_k1_pileup_bits(d_, stream_);
         HIP_OK(hipEventRecord(ev_[1], stream_));
         launch_k2_window_replay(d_, rpl_, stream_);     // sequential replay of the segments that need it
-        launch_k2_window_parallel(d_, stream_);          // K2a + K2w: everything else, window-parallel
+        HIP_OK(hipEventRecord(ev_[5], stream_));
+        launch_k2_admission(d_, stream_);                // K2a + K2w: everything else, window-parallel
+        HIP_OK(hipEventRecord(ev_[6], stream_));
+        launch_k2_window_rows(d_, stream_);
         HIP_OK(hipEventRecord(ev_[2], stream_));
         std::vector<unsigned long long> cur(NPART * 32);
         uint32_t err = 0;
@@ -229,6 +232,9 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
         HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
+        HIP_OK(hipEventElapsedTime(&t.k2seq_ms, ev_[1], ev_[5]));
+        HIP_OK(hipEventElapsedTime(&t.k2a_ms, ev_[5], ev_[6]));
+        HIP_OK(hipEventElapsedTime(&t.k2w_ms, ev_[6], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         last_slots_ = slots;

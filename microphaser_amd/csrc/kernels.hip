@@ -1689,15 +1689,15 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
     HIP_CHECK_LAUNCH();
 }
 
-void launch_k2_window_parallel(const DeviceBatch& d, hipStream_t stream) {
-    if (d.n_adm) {
-        hipLaunchKernelGGL(k2a_admission, dim3(d.n_exons_w), dim3(64), 0, stream, d);
-        HIP_CHECK_LAUNCH();
-    }
-    if (d.n_wchunks) {
-        hipLaunchKernelGGL(k2w_window_rows, dim3((d.n_wchunks + K2W_ITEMS - 1) / K2W_ITEMS), dim3(64), 0, stream, d);
-        HIP_CHECK_LAUNCH();
-    }
+void launch_k2_admission(const DeviceBatch& d, hipStream_t stream) {
+    if (!d.n_exons_w) return;
+    hipLaunchKernelGGL(k2a_admission, dim3(d.n_exons_w), dim3(64), 0, stream, d);
+    HIP_CHECK_LAUNCH();
+}
+void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
+    if (!d.n_wchunks) return;
+    hipLaunchKernelGGL(k2w_window_rows, dim3((d.n_wchunks + K2W_ITEMS - 1) / K2W_ITEMS), dim3(64), 0, stream, d);
+    HIP_CHECK_LAUNCH();
 }
 
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {

@@ -73,7 +73,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
 // rows_per_lane in {1,2,4,8,16}. All launches are asynchronous on `stream`.
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
-void launch_k2_window_parallel(const DeviceBatch& d, hipStream_t stream);   // K2a + K2w over the ExonW part of the plan
+void launch_k2_admission(const DeviceBatch& d, hipStream_t stream);     // K2a over the ExonW part of the plan
+void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream);   // K2w, after K2a
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_live_groups, hipStream_t stream);
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream);
 
