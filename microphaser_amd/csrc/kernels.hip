@@ -1173,7 +1173,12 @@ template <int CAP> struct K3Cfg {
     static constexpr int SLOT_DW = (SLOT_BYTES / 4) | 1;    // odd dword stride (33 at CAP = 48)
 };
 
-struct ShaStream {
+// BUF = false: the message streams through a 16-word block buffer and is compressed as it goes. BUF = true: the whole padded
+// message is first laid out in a larger per-thread buffer and compressed afterwards in a wave-uniform loop - with variable
+// length decimal text the lanes reach their block boundaries at different feeds, and the streaming form then executes the
+// (fully unrolled, ~800 instruction) compression once per distinct boundary instead of once per block.
+template <bool BUF>
+struct ShaStreamT {
     uint32_t h0, h1, h2, h3, h4;
     uint64_t q;       // byte queue (big-endian, low `nq` bytes valid)
     uint32_t nq, widx, total;
@@ -1182,10 +1187,10 @@ struct ShaStream {
         h0 = 0x67452301u; h1 = 0xEFCDAB89u; h2 = 0x98BADCFEu; h3 = 0x10325476u; h4 = 0xC3D2E1F0u;
         q = 0; nq = 0; widx = 0; total = 0; blk = b;
     }
-    __device__ void compress() {
+    __device__ void compress(uint32_t off = 0) {
         uint32_t w[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = blk[i];
+        for (int i = 0; i < 16; i++) w[i] = blk[off + i];
         uint32_t a = h0, b = h1, c = h2, d = h3, e = h4;
 #pragma unroll
         for (int i = 0; i < 80; i++) {
@@ -1210,23 +1215,36 @@ struct ShaStream {
         q = (q << (8 * n)) | v;
         nq += n;
         total += n;
-        while (nq >= 4) {
-            uint32_t wv = uint32_t(q >> (8 * (nq - 4)));
+        if (nq >= 4) {
             nq -= 4;
-            blk[widx++] = wv;
-            if (widx == 16) { compress(); widx = 0; }
+            blk[widx++] = uint32_t(q >> (8 * nq));
+            if constexpr (!BUF) { if (widx == 16) { compress(); widx = 0; } }
+            if (nq >= 4) {
+                nq -= 4;
+                blk[widx++] = uint32_t(q >> (8 * nq));
+                if constexpr (!BUF) { if (widx == 16) { compress(); widx = 0; } }
+            }
         }
     }
-    __device__ void feed_dec(uint32_t v) {  // decimal digits of v, most significant first
-        uint32_t div = 1000000000u;
-        while (div > 1 && v < div) div /= 10;
-        while (div) { feed('0' + (v / div) % 10, 1); div /= 10; }
+    __device__ void feed_dec(uint32_t v) {  // decimal digits of v, most significant first, fed in chunks of <= 5 characters
+        const uint32_t hi = v / 100000u, lo = v - hi * 100000u;
+        auto chunk = [&](uint32_t x, bool pad) {   // x < 100000; pad: always five digits (the low half below a non-zero high half)
+            uint64_t txt = 0;
+            uint32_t n = 0;
+            const uint32_t dg[5] = {x / 10000u, (x / 1000u) % 10u, (x / 100u) % 10u, (x / 10u) % 10u, x % 10u};
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (pad || n || dg[k] || k == 4) { txt = (txt << 8) | ('0' + dg[k]); n++; }
+            feed(txt, n);
+        };
+        if (hi) { chunk(hi, false); chunk(lo, true); }
+        else chunk(lo, false);
     }
     __device__ void finish() {
         const uint32_t bits = total * 8;
         feed(0x80, 1);
         if (nq) feed(0, 4 - nq);                 // complete the current word
-        while (widx != 14) feed(0, 4);           // zero words up to the 64-bit length field
+        while ((widx & 15) != 14) feed(0, 4);    // zero words up to the 64-bit length field
         feed(0, 4);
         feed(bits, 4);
     }
@@ -1596,9 +1614,21 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
 
 // K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
 // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
+constexpr uint32_t K3B_BUF_WORDS = 48;   // three SHA-1 blocks per thread (a 27..31-nt window + an id of <= 17 characters always fits)
 template <int SEQ_CAP>
 __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t n_recs) {
-    __shared__ uint32_t lds_blk[64 * 17];
+    __shared__ uint32_t lds_blk[64 * (K3B_BUF_WORDS + 1)];   // odd stride: bank-conflict free
+    __shared__ uint64_t byte_text[256];   // decimal text of a byte value followed by ", ", packed big-endian: text << 8 | length
+    for (uint32_t v = threadIdx.x; v < 256; v += 64) {
+        uint64_t txt;
+        uint32_t n;
+        if (v >= 100) { txt = (uint64_t('0' + v / 100) << 16) | (uint64_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10); n = 3; }
+        else if (v >= 10) { txt = (uint64_t('0' + v / 10) << 8) | ('0' + v % 10); n = 2; }
+        else { txt = '0' + v; n = 1; }
+        txt = (txt << 16) | (uint64_t(',') << 8) | ' ';
+        byte_text[v] = (txt << 8) | (n + 2);
+    }
+    __syncthreads();
     const uint64_t li = uint64_t(blockIdx.x) * 64 + threadIdx.x;   // index into the dense list of records that need an id
     if (li >= n_recs) return;
     uint32_t wp = 0;   // li-th wanted record overall -> list wp, offset li - want_prefix[wp]
@@ -1615,32 +1645,53 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
     const uint32_t seq_len = rec[4] & 0xFF;
     const WinStatic ws = d.wins[rec[6]];
     const TxDev T = d.tx[ws.tx];
-    ShaStream sh;
-    sh.init(lds_blk + threadIdx.x * 17);
-    sh.feed('[', 1);
-    for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP) && k0 < seq_len; k0 += 4) {
-        const uint32_t dw = rec[8 + (k0 >> 2)];
+    auto feed_message = [&](auto& sh) {
+        sh.feed('[', 1);
+        for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP) && k0 < seq_len; k0 += 4) {
+            const uint32_t dw = rec[8 + (k0 >> 2)];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint32_t k = k0 + b;
-            if (k < seq_len) {
-                // "{:?}" of a Vec<u8>: decimal value, then ", " unless it is the last element - one feed of <= 5 bytes
-                const uint32_t v = (dw >> (8 * b)) & 0xFF;
-                uint64_t txt;
-                uint32_t n;
-                if (v >= 100) { txt = (uint64_t('0' + v / 100) << 16) | (uint64_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10); n = 3; }
-                else if (v >= 10) { txt = (uint64_t('0' + v / 10) << 8) | ('0' + v % 10); n = 2; }
-                else { txt = '0' + v; n = 1; }
-                if (k + 1 < seq_len) { txt = (txt << 16) | (uint64_t(',') << 8) | ' '; n += 2; }
-                sh.feed(txt, n);
+            for (int b = 0; b < 4; b++) {
+                const uint32_t k = k0 + b;
+                if (k < seq_len) {
+                    // "{:?}" of a Vec<u8>: decimal value, then ", " unless it is the last element - one feed of <= 5 bytes
+                    const uint64_t e = byte_text[(dw >> (8 * b)) & 0xFF];   // text << 8 | length, incl. the separator
+                    uint64_t txt = e >> 8;
+                    uint32_t n = uint32_t(e & 0xFF);
+                    if (k + 1 >= seq_len) { txt >>= 16; n -= 2; }
+                    sh.feed(txt, n);
+                }
             }
         }
+        sh.feed(']', 1);
+        for (uint32_t k = 0; k < T.id_len; k += 4) {   // transcript id, four characters per feed
+            uint64_t txt = 0;
+            const uint32_t n = min(4u, T.id_len - k);
+            for (uint32_t c = 0; c < n; c++) txt = (txt << 8) | d.str_pool[T.id_off + k + c];
+            sh.feed(txt, n);
+        }
+        sh.feed_dec(ws.sso);
+        sh.finish();
+    };
+    uint32_t o0, o1;
+    // <= 256 bytes incl. padding (every 27..31-nt window with a transcript id of up to ~80 characters): buffered form
+    const bool fits = 5 * seq_len + T.id_len + 20 <= K3B_BUF_WORDS * 4;
+    if (__ballot(!fits) == 0) {
+        ShaStreamT<true> sh;
+        sh.init(lds_blk + threadIdx.x * (K3B_BUF_WORDS + 1));
+        feed_message(sh);
+        const uint32_t nblk = sh.widx >> 4;
+        // wave-uniform trip count from ballots (only the active lanes vote; nblk <= K3B_BUF_WORDS / 16 = 3)
+        const uint32_t maxblk = __ballot(nblk >= 3) ? 3u : __ballot(nblk >= 2) ? 2u : 1u;
+        for (uint32_t bk = 0; bk < maxblk; bk++)
+            if (bk < nblk) sh.compress(bk * 16);
+        o0 = sh.h0; o1 = sh.h1;
+    } else {
+        ShaStreamT<false> sh;
+        sh.init(lds_blk + threadIdx.x * (K3B_BUF_WORDS + 1));
+        feed_message(sh);
+        o0 = sh.h0; o1 = sh.h1;
     }
-    sh.feed(']', 1);
-    for (uint32_t k = 0; k < T.id_len; k++) sh.feed(d.str_pool[T.id_off + k], 1);
-    sh.feed_dec(ws.sso);
-    sh.finish();
-    uint64_t id60 = (uint64_t(sh.h0) << 28) | (uint64_t(sh.h1) >> 4);
+    uint64_t id60 = (uint64_t(o0) << 28) | (uint64_t(o1) >> 4);
     rec[2] = uint32_t(id60);
     rec[3] = uint32_t(id60 >> 32);
 }

@@ -280,3 +280,21 @@ def test_gpu_config_e_pipeline_matches_oracle(ctx, tmp_path):
     # the buffer entry point gives the same result
     f2 = ctx.filter(info.read_bytes(), ref_bin.read_bytes(), 9)
     assert (f2.fasta, f2.tsv, f2.removed_tsv) == (f.fasta, f.tsv, f.removed_tsv)
+
+
+def test_gpu_sequential_and_window_parallel_replay_agree(ctx, monkeypatch):
+    """The two replay paths (K2 state machine per segment; K2a + K2w closed form per window) write identical results:
+    the same exome planned with MP_SEQUENTIAL_REPLAY=1 (everything through K2) and by default (everything eligible
+    through K2a + K2w), incl. low-quality rejections, start-codon variants and both strands."""
+    ds = ctx.synth(4242, 60, 40.0, 4.0)
+    b = ds.batch()
+    st = b.run()
+    fast = b.results()
+    assert st.n_steps_w > 0 and st.n_steps_w >= 9 * st.n_steps_seq
+    monkeypatch.setenv("MP_SEQUENTIAL_REPLAY", "1")
+    b2 = ds.batch()
+    st2 = b2.run()
+    slow = b2.results()
+    assert st2.n_steps_w == 0 and st2.n_steps_seq == st.n_steps_w + st.n_steps_seq
+    assert (fast.fasta, fast.normal_fasta, fast.tsv, fast.windows) == (slow.fasta, slow.normal_fasta, slow.tsv, slow.windows)
+    assert fast.tsv.count(b"\n") > 1000
