@@ -49,18 +49,25 @@ __device__ __forceinline__ int cigar_read_pos_dev(const uint32_t* cig, uint32_t 
     return -1;
 }
 
-// One thread per read. The first variant at or after the read start (r_varlo) comes from the planner, the variants the
-// read can see are then a short contiguous run of the gene's variant array; the run is walked twice - first only to find
-// its end (independent v_pos loads), then to evaluate the predicates with the loads of four variants in flight at once.
+// K1_LANES lanes per read. The first variant at or after the read start (r_varlo) comes from the planner; the variants the
+// read can see are then a short contiguous run of the gene's variant array. Lane k of the group takes variants k, k + K1_LANES,
+// ... of that run, so more of a read's ~20 (variant position -> base, quality) gathers are in flight at once than in one
+// thread's chain of dependent loads; a K1_LANES-bit slice of a wave ballot IS the next K1_LANES bits of the read's mask.
 __device__ __forceinline__ uint8_t decode_base4(uint32_t code) {  // BAM 4-bit code -> "=ACMGRSVTWYHKDBN"
     const uint64_t lo = 0x565352474d43413dull, hi = 0x4e42444b48595754ull;
     return uint8_t(((code & 8) ? hi : lo) >> (8 * (code & 7)));
 }
 
+constexpr uint32_t K1_LANES = 4;    // lanes per read (measured at config C: 1 lane 1.40 ms, 2: 1.07, 4: 1.10, 8: 1.31, 16: 1.71)
+constexpr uint32_t K1_SLICE = (1u << K1_LANES) - 1u;
 template <int W>
 __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= d.n_reads) return;
+    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t sub = threadIdx.x & (K1_LANES - 1);             // lane within the read's group
+    const uint32_t gshift = (threadIdx.x & 63u) & ~(K1_LANES - 1); // bit position of the group's slice in a wave ballot
+    const uint64_t i_raw = t / K1_LANES;
+    const bool valid = i_raw < d.n_reads;
+    const uint32_t i = valid ? uint32_t(i_raw) : d.n_reads - 1;              // surplus groups shadow the last read (no stores)
     const uint32_t g = d.r_gene[i];
     const uint32_t vbase = d.g_var_off[g];
     const uint32_t nv = d.g_var_off[g + 1] - vbase;
@@ -72,74 +79,60 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     // a variant can be a (stale) column of a window the read encloses without lying inside the read's aligned span;
     // bad_quality still indexes the qualities by reference offset (:82-88): cover max(end, start + l_seq)
     const uint32_t cover_end = max(rend, rpos + lseq);
-    uint32_t ncov = 0;
-    {
-        const uint32_t maxn = min(nv - lo, 64u * W);
-        const uint32_t* vp = d.v_pos + vbase + lo;
-        while (ncov + 4 <= maxn) {
-            uint32_t p0 = vp[ncov], p1 = vp[ncov + 1], p2 = vp[ncov + 2], p3 = vp[ncov + 3];
-            if (p3 < cover_end) { ncov += 4; continue; }
-            ncov += (p0 < cover_end) + (p1 < cover_end) + (p2 < cover_end);
-            goto counted;
-        }
-        while (ncov < maxn && vp[ncov] < cover_end) ncov++;
-    counted:;
-    }
+    const uint32_t maxn = min(nv - lo, 64u * W);
     const uint32_t c0 = ncig > 0 ? cig[0] : 0;
     const bool simple = ncig == 1 && (c0 & 0xF) == 0;  // a single M op: read_pos(p) = p - start
     uint64_t sup[W], lq[W];
 #pragma unroll
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
-    for (uint32_t b0 = 0; b0 < ncov; b0 += 4) {
-        uint32_t vpos[4], info[4];
-        uint8_t qb[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t k = min(b0 + u, ncov - 1);
-            vpos[u] = d.v_pos[vbase + lo + k];
-            info[u] = d.v_info[vbase + lo + k];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t rel = vpos[u] - rpos;
-            qb[u] = rel < lseq ? qual[rel] : uint8_t(255);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t b = b0 + u;
-            if (b >= ncov) break;
-            const uint32_t kind = info[u] & VI_KIND_MASK;
-            bool s = false, q = false;
+    uint32_t ncov = 0;
+    bool more = true;   // the group's run may continue (every variant of the previous round was covered)
+    for (uint32_t b0 = 0; b0 < 64u * W; b0 += K1_LANES) {
+        if (__ballot(more) == 0) break;   // wave-uniform
+        const uint32_t b = b0 + sub;
+        const bool in = more && b < maxn;
+        uint32_t vpos = 0xFFFFFFFFu, info = 0;
+        if (in) { vpos = d.v_pos[vbase + lo + b]; info = d.v_info[vbase + lo + b]; }
+        const bool cov = in && vpos < cover_end;
+        bool s = false, q = false;
+        if (cov) {
+            const uint32_t kind = info & VI_KIND_MASK;
             if (kind == 0) {  // SNV (:97-112, :80-92)
-                q = !d.normal && qb[u] < 10;  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
+                const uint32_t rel = vpos - rpos;
+                const uint8_t qb = rel < lseq ? qual[rel] : uint8_t(255);
+                q = !d.normal && qb < 10;  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
                 if (!q) {
-                    int p = simple ? int(vpos[u] - rpos) : cigar_read_pos_dev(cig, ncig, rpos, vpos[u]);
+                    int p = simple ? int(vpos - rpos) : cigar_read_pos_dev(cig, ncig, rpos, vpos);
                     if (simple && uint32_t(p) >= (c0 >> 4)) p = -1;
                     if (p >= 0 && uint32_t(p) < lseq) {
-                        uint8_t b4 = seq4[p >> 1];
-                        uint32_t code = (p & 1) ? (b4 & 0xF) : (b4 >> 4);
-                        s = decode_base4(code) == uint8_t(info[u] >> VI_ALT_SHIFT);
+                        const uint8_t b4 = seq4[p >> 1];
+                        const uint32_t code = (p & 1) ? (b4 & 0xF) : (b4 >> 4);
+                        s = decode_base4(code) == uint8_t(info >> VI_ALT_SHIFT);
                     }
                 }
             } else {  // insertion / deletion: any I / D op of exactly that length (:113-137)
-                uint32_t want = kind == 1 ? 1u : 2u;
-                uint32_t vlen = d.v_len[vbase + lo + b];
+                const uint32_t want = kind == 1 ? 1u : 2u;
+                const uint32_t vlen = d.v_len[vbase + lo + b];
                 for (uint32_t c = 0; c < ncig; c++)
                     if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
             }
-#pragma unroll
-            for (int w = 0; w < W; w++)
-                if ((b >> 6) == uint32_t(w)) {
-                    if (s) sup[w] |= 1ull << (b & 63);
-                    if (q) lq[w] |= 1ull << (b & 63);
-                }
         }
-    }
-    d.r_ncov[i] = ncov;
+        // the group's slices of the three wave ballots: coverage (a prefix of the lanes), support, low quality
+        const uint32_t covm = uint32_t(__ballot(cov) >> gshift) & K1_SLICE;
+        const uint64_t supm = (__ballot(s) >> gshift) & uint64_t(K1_SLICE), lqm = (__ballot(q) >> gshift) & uint64_t(K1_SLICE);
+        ncov += __popc(covm);
 #pragma unroll
-    for (int w = 0; w < W; w++) {
-        d.r_sup[uint64_t(i) * W + w] = sup[w];
-        d.r_lq[uint64_t(i) * W + w] = lq[w];
+        for (int w = 0; w < W; w++)
+            if ((b0 >> 6) == uint32_t(w)) { sup[w] |= supm << (b0 & 63); lq[w] |= lqm << (b0 & 63); }
+        more = more && covm == K1_SLICE;
+    }
+    if (valid && sub == 0) {
+        d.r_ncov[i] = ncov;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            d.r_sup[uint64_t(i) * W + w] = sup[w];
+            d.r_lq[uint64_t(i) * W + w] = lq[w];
+        }
     }
 }
 
@@ -597,11 +590,9 @@ __device__ __forceinline__ void tr_to_f(const ExonW& e, bool is_rev, uint32_t tl
 
 __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
     const ExonW e = d.exons_w[blockIdx.x];   // one wave per exon, lanes stride over its reads
-    const TxDev T = d.tx[e.tx];
-    const bool is_rev = T.strand != 0;
-    const uint32_t rbase = d.g_read_off[T.gene] + e.read_lo;
-    const uint32_t sso0 = d.steps[e.step_off].sso;
-    const uint32_t sso1 = e.n_steps > 1 ? d.steps[e.step_off + 1].sso : sso0;
+    const bool is_rev = e.strand != 0;
+    const uint32_t rbase = e.rbase + e.read_lo;
+    const uint32_t sso0 = e.sso0, sso1 = e.sso1;
     for (uint32_t k = threadIdx.x; k < e.n_reads; k += 64) {
         const uint32_t gi = rbase + k;
         const uint32_t start = d.r_pos[gi], end = d.r_end[gi], rvl = d.r_varlo[gi];
@@ -668,10 +659,9 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
     for (uint32_t item = blockIdx.x * K2W_ITEMS; item < min(d.n_wchunks, (blockIdx.x + 1) * K2W_ITEMS); item++) {
     const WChunk C = d.wchunks[item];
     const ExonW e = d.exons_w[C.exon];
-    const TxDev T = d.tx[e.tx];
-    const bool is_rev = T.strand != 0;
-    const uint32_t rbase = d.g_read_off[T.gene];
-    const uint32_t vbase = d.g_var_off[T.gene];
+    const bool is_rev = e.strand != 0;
+    const uint32_t rbase = e.rbase;
+    const uint32_t vbase = e.vbase;
     // the lanes hold a sliding block of 64 consecutive reads [L, L + 64) of the exon's candidate range; a window's rows are
     // the lanes inside its own range [r_lo, r_lo + r_n). The block moves only when a window's range leaves it.
     uint32_t L = 0;
@@ -1268,6 +1258,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     uint8_t* seq = refb + K3_REFCAP;
     uint8_t* germ = seq + SEQ_CAP;
     const uint32_t w = li < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
+    // the other two per-slot loads do not depend on the window: issue them now (unused slots hold defined junk)
+    const uint64_t hap_pre = li < n_slots ? d.groups[g].hap : 0;
+    const uint32_t rec_pre = li < n_slots ? d.g_rec[g] : 0xFFFFFFFFu;
     const bool live = w != 0xFFFFFFFFu;
     uint32_t sumflags = 0;
     bool need_rec = false;
@@ -1277,7 +1270,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     if (live) {
         const WinStatic ws = d.wins[w];
         const uint32_t vbase = ws.vbase;
-        const uint64_t hap = d.groups[g].hap;
+        const uint64_t hap = hap_pre;
         const bool is_rev = (ws.flags & WSF_REVERSE) != 0;
         const uint32_t ncols = ws.ncols;
         const uint32_t window_end = ws.sso + ws.wlen;
@@ -1306,21 +1299,26 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
                 slot[K3_REFCAP / 4 + k] = v;
                 slot[(K3_REFCAP + SEQ_CAP) / 4 + k] = v;
             }
-            uint64_t rem = hap & (ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull));
-            while (rem) {
-                const uint32_t bit = uint32_t(__builtin_ctzll(rem));
-                rem &= rem - 1;
-                const uint32_t dq = ncols - 1 - bit;
-                const WinCol wc = d.win_cols[ws.col_off + dq];
-                const uint32_t off = wc.pos - ws.sso;
+            auto substitute = [&](uint32_t dq, uint32_t pos, uint32_t info) {   // deque column dq is set on this haplotype
+                const uint32_t off = pos - ws.sso;
                 const uint8_t r = refb[mis + off];
-                const uint8_t alt = uint8_t(wc.info >> VI_ALT_SHIFT);
+                const uint8_t alt = uint8_t(info >> VI_ALT_SHIFT);
                 const uint8_t sw = is_upper(r) ? to_lower(alt) : alt;
                 seq[off] = sw;
-                if (wc.info & VI_GERMLINE) germ[off] = sw; else nsom++;
+                if (info & VI_GERMLINE) germ[off] = sw; else nsom++;
                 nvar++;
-                prof_set |= 1ull << (is_rev ? bit : dq);
-            }
+                prof_set |= 1ull << (is_rev ? (ncols - 1 - dq) : dq);
+            };
+            // the first eight columns are fetched together (independent loads), the rare rest one by one
+            uint32_t cp[8], ci[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (uint32_t(k) < ncols) { const WinCol* wc = d.win_cols + ws.col_off + k; cp[k] = wc->pos; ci[k] = wc->info; }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (uint32_t(k) < ncols && ((hap >> (ncols - 1 - k)) & 1)) substitute(uint32_t(k), cp[k], ci[k]);
+            for (uint32_t k = 8; k < ncols; k++)
+                if ((hap >> (ncols - 1 - k)) & 1) { const WinCol wc = d.win_cols[ws.col_off + k]; substitute(k, wc.pos, wc.info); }
             ns = ngm = ws.wlen;
             j = ncols;
         } else {
@@ -1452,7 +1450,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     // the record slot (if any) was assigned by K2; a slot K3 turns out not to need is marked "no id"
     uint32_t recidx = 0;
     if (live) {
-        const uint32_t slot_idx = d.g_rec[g];
+        const uint32_t slot_idx = rec_pre;
         if (slot_idx != 0xFFFFFFFFu) {
             uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
             if (need_rec) {
@@ -1699,7 +1697,7 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
 // ====================================================================== launchers
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
     if (d.n_reads == 0) return;
-    dim3 grid((d.n_reads + 255) / 256), block(256);
+    dim3 grid(uint32_t((uint64_t(d.n_reads) * K1_LANES + 255) / 256)), block(256);
     switch (d.mask_words) {
         case 1: hipLaunchKernelGGL(k1_pileup_bits<1>, grid, block, 0, stream, d); break;
         case 2: hipLaunchKernelGGL(k1_pileup_bits<2>, grid, block, 0, stream, d); break;

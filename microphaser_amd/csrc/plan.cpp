@@ -397,6 +397,9 @@ static void route_window_parallel(Batch& b) {
             e.sl_f_lo = uint32_t(std::lower_bound(vp, vp + gh.n_vars, T.sl_lo) - vp);
             e.sl_f_hi = uint32_t(std::lower_bound(vp, vp + gh.n_vars, T.sl_hi) - vp);
         }
+        e.strand = T.strand; e.rbase = gh.read_off; e.vbase = gh.var_off;
+        e.sso0 = b.steps[g.step_off].sso;
+        e.sso1 = g.n_steps > 1 ? b.steps[g.step_off + 1].sso : e.sso0;
         const uint32_t ei = uint32_t(b.exons_w.size());
         b.exons_w.push_back(e);
         for (uint32_t s0 = 0; s0 < g.n_steps; s0 += CHUNK_STEPS)

@@ -60,6 +60,10 @@ struct ExonW {
     uint32_t range;                 // '-': candidate key range extent R - candidates have start in [sso - R, sso] (:1198-1226)
     uint32_t tr0, f0;               // transcription-order index -> forward index: f = strand ? f0 - (tr - tr0) : tr
     uint32_t sl_f_lo, sl_f_hi;      // forward index range of the variants inside the start-loss interval
+    // flattened copies (one hop instead of three for every wave that starts on this exon)
+    uint32_t strand;                // TxDev::strand
+    uint32_t rbase, vbase;          // batch index of the gene's first read / first variant
+    uint32_t sso0, sso1;            // splice_side_offset of the exon's first and second step
 };
 struct WChunk {                     // K2w work item: a run of steps of one ExonW
     uint32_t exon, step_first, n_steps, pad;
