@@ -1314,13 +1314,16 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (uint32_t(k) < ncols) { const WinCol* wc = d.win_cols + ws.col_off + k; cp[k] = wc->pos; ci[k] = wc->info; }
+            // only the first `vis` columns in walk order can ever be visited: deque columns [0, vis) on '+', [ncols - vis, ncols) on '-'
+            const uint32_t vis = ws.need_recs >> WS_PREFIX_SHIFT;
+            const uint32_t dlo = is_rev ? ncols - vis : 0u, dhi = is_rev ? ncols : vis;
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (uint32_t(k) < ncols && ((hap >> (ncols - 1 - k)) & 1)) substitute(uint32_t(k), cp[k], ci[k]);
-            for (uint32_t k = 8; k < ncols; k++)
+                if (uint32_t(k) >= dlo && uint32_t(k) < dhi && ((hap >> (ncols - 1 - k)) & 1)) substitute(uint32_t(k), cp[k], ci[k]);
+            for (uint32_t k = max(8u, dlo); k < dhi; k++)
                 if ((hap >> (ncols - 1 - k)) & 1) { const WinCol wc = d.win_cols[ws.col_off + k]; substitute(k, wc.pos, wc.info); }
             ns = ngm = ws.wlen;
-            j = ncols;
+            j = vis;
         } else {
             uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
             // the first 8 columns (in walk order) are fetched up front so their loads overlap instead of forming a dependent chain
@@ -1443,7 +1446,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         }
         sumflags = GS_VALID | (stop ? GS_STOP : 0) | (differs ? GS_DIFFERS : 0) | (indel ? GS_INDEL : 0) |
                    (insertion ? GS_INSERTION : 0) | (broke_flag ? GS_BROKE : 0);
-        need_rec = nsom > 0 || ws.need_recs != 0;
+        need_rec = nsom > 0 || (ws.need_recs & WS_MASK) != 0;
         want_id = need_rec && (nsom > 0 || (ws.need_recs & WS_ALL_IDS));  // hashed by k3b_haplotype_ids
         if (stop && ws.splice_pos != 2 && !(ws.flags & SF_FIRST_EXON_WIN)) atomicMin(&d.tx_first_stop[ws.tx], w);
     }

@@ -97,15 +97,31 @@ struct PlannerHooksT {
         w.splice_pos = uint8_t(sg.splice_pos);
         w.splice_gap = uint8_t(sg.splice_gap);
         w.flags = uint8_t((st.flags & 0x7C) | (is_fwd ? 0 : WSF_REVERSE));
-        {   // WSF_SIMPLE: every column an SNV, positions strictly increasing in walk order (ascending) and inside the window
+        uint32_t walk_prefix = 0;
+        {   // WSF_SIMPLE: see plan.hpp. Walk order = ascending position = deque order on '+', reversed deque on '-'.
             bool simple = !NORMAL && st.wlen <= 32;
+            auto col = [&](size_t k) -> const Variant& { return vars[is_fwd ? cols[k] : cols[cols.size() - 1 - k]]; };
             uint64_t prev = 0;
-            bool first = true;
-            for (size_t k = 0; k < cols.size() && simple; k++) {
-                const Variant& v = vars[is_fwd ? cols[k] : cols[cols.size() - 1 - k]];
-                if (v.kind != VK_SNV || v.pos < st.sso || v.pos >= uint64_t(st.sso) + st.wlen || (!first && v.pos <= prev)) simple = false;
+            size_t e = 0;
+            for (; e < cols.size(); e++) {
+                const Variant& v = col(e);
+                if (v.kind != VK_SNV || v.pos < st.sso || v.pos >= uint64_t(st.sso) + st.wlen || (e > 0 && v.pos <= prev)) break;
                 prev = v.pos;
-                first = false;
+            }
+            if (simple && e < cols.size()) {   // the first column outside the prefix must be unreachable for good
+                const Variant& v = col(e);
+                const bool beyond = v.pos >= uint64_t(st.sso) + st.wlen;
+                const bool behind = e == 0 ? v.pos < st.sso : v.pos < prev;   // == prev (second ALT of a site) depends on the haplotype
+                if (!beyond && !behind) simple = false;
+                // the inner loop of the walk (`while j < ncols && i == pos_j`, :479) has no window bound: an applied SNV at the
+                // window's last base moves the cursor to window_end, where a column sitting exactly there is applied too
+                if (beyond && e > 0 && v.pos == uint64_t(st.sso) + st.wlen && prev + 1 == v.pos) simple = false;
+            }
+            walk_prefix = uint32_t(e);
+            if (!simple && !NORMAL && std::getenv("MP_DEBUG_SIMPLE")) {
+                std::string m;
+                for (size_t k = 0; k < cols.size(); k++) { const Variant& v = vars[is_fwd ? cols[k] : cols[cols.size() - 1 - k]]; m += " " + std::to_string(v.pos) + (v.kind != VK_SNV ? "*" : ""); }
+                std::fprintf(stderr, "nonsimple %s sso %u wlen %u cols:%s\n", is_fwd ? "+" : "-", st.sso, unsigned(st.wlen), m.c_str());
             }
             if (simple) w.flags |= WSF_SIMPLE;
             if (simple) {   // WSF_NOSTOP: has_stop_codon (:42-76) on the reference slice, which no SNV haplotype can extend
@@ -141,9 +157,9 @@ struct PlannerHooksT {
             if (v.kind == VK_DEL) max_len += v.len;
             if (v.kind != VK_SNV) non_snv = true;
         }
-        b.wins.back().need_recs = (NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0;  // `normal` emits every haplotype
+        b.wins.back().need_recs = uint8_t(((NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0) | (walk_prefix << WS_PREFIX_SHIFT));  // `normal` emits every haplotype
         if (NORMAL) max_len += 1;  // the unconditional trailing base (src/normal_microphasing.rs:476)
-        if (b.wins.back().need_recs) b.steps[cur_step].flags |= SF_NEED_RECS;
+        if (b.wins.back().need_recs & WS_MASK) b.steps[cur_step].flags |= SF_NEED_RECS;
         if (max_len > SEQ_CAPS[2])
             throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
                         " nt; this build supports at most " + std::to_string(SEQ_CAPS[2]) + " (very long indel in a window)");

@@ -113,18 +113,22 @@ struct WinStatic {       // one per printing step; everything K3 needs that does
     uint8_t splice_pos;
     uint8_t splice_gap;
     uint8_t flags;       // SF_* of the step | WSF_REVERSE
-    uint8_t need_recs;   // WS_* : K3 writes a HapRec for EVERY haplotype of this window
+    uint8_t need_recs;   // bits 0-1 WS_* : K3 writes a HapRec for EVERY haplotype of this window; bits 2-7: simple-walk prefix length
     uint32_t step;       // the Step this window belongs to
 };
 enum : uint8_t {
     WS_ALL_IDS = 1,      // indel / frameshift context: every haplotype can be emitted -> records + SHA-1 ids
     WS_CARRY = 2,        // the window's haplotypes are carried into a splice-side merge -> records
 };
+constexpr uint8_t WS_MASK = 3;
+constexpr uint8_t WS_PREFIX_SHIFT = 2;  // need_recs >> 2 = number of leading walk-order columns the sequence walk can ever visit (WSF_SIMPLE)
 constexpr uint8_t WSF_REVERSE = 128;  // transcript on the '-' strand (SF_* use bits 0..6)
 constexpr uint8_t WSF_NOSTOP = 2;     // (replaces SF_FULL_RANGE) simple window over an all-upper-case reference without a stop codon in the
                                       // peptide frame: a variant base is lower-case there and can never complete a stop (:42-76) -> no scan
-constexpr uint8_t WSF_SIMPLE = 1;     // (replaces SF_PRINT, always set for a window) SNV-only columns at strictly increasing positions inside
-                                      // the window, wlen <= 32: K3 builds the sequences by byte substitution instead of walking
+constexpr uint8_t WSF_SIMPLE = 1;     // (replaces SF_PRINT, always set for a window) wlen <= 32 and the walk of :473-601 can only ever visit a
+                                      // prefix of the columns (walk order), all SNVs at strictly increasing positions inside the window - the
+                                      // next column, if any, lies behind the cursor or beyond the window (a stale column, :1159) and blocks
+                                      // everything after it: K3 builds the sequences by byte substitution instead of walking
 struct WinCol {          // one live variant column of a printing window
     uint32_t f;          // gene-relative forward variant index
     uint32_t pos;        // v_pos
