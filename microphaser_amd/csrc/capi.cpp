@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -64,9 +65,23 @@ DeviceContext& need_device(mp_ctx* ctx) {
 }
 }  // namespace
 
+namespace {
+// MP_DEBUG=1: wall time of every C-ABI call that does real work (where an end-to-end run spends its time)
+struct PhaseTimer {
+    const char* what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PhaseTimer(const char* w) : what(w) {}
+    ~PhaseTimer() {
+        if (std::getenv("MP_DEBUG"))
+            std::fprintf(stderr, "[mp] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+}  // namespace
+
 extern "C" {
 
 int mp_create(int device, mp_ctx** out) {
+    PhaseTimer phase_timer("create");
     if (!out) return 1;
     *out = nullptr;
     std::unique_ptr<mp_ctx> c(new mp_ctx());
@@ -83,6 +98,7 @@ void mp_destroy(mp_ctx* ctx) { delete ctx; }
 const char* mp_last_error(const mp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int mp_dataset_load(mp_ctx* ctx, const char* bam, const char* vcf, const char* fasta, const char* gtf, int warn_only, mp_dataset** out) {
+    PhaseTimer phase_timer("dataset_load");
     return guarded(ctx, [&] {
         std::unique_ptr<mp_dataset> d(new mp_dataset());
         if (gtf) {
@@ -135,6 +151,7 @@ uint64_t mp_dataset_num_reads(const mp_dataset* ds) { return ds ? uint64_t(ds->d
 void mp_dataset_free(mp_dataset* ds) { delete ds; }
 
 int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, uint32_t gene_lo, uint32_t gene_hi, mp_batch** out) {
+    PhaseTimer phase_timer("batch_create");
     return guarded(ctx, [&] {
         if (mode != MP_MODE_SOMATIC && mode != MP_MODE_NORMAL) throw Error("unknown mode");
         const std::vector<GeneInput>& genes = dataset_genes(const_cast<Dataset&>(ds->ds), mode == MP_MODE_NORMAL);
@@ -164,6 +181,7 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
 }
 
 int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
+    PhaseTimer phase_timer("batch_run");
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         if (!batch->uploaded) { dev.upload(batch->batch); batch->uploaded = true; }
@@ -215,6 +233,7 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
 }
 
 int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
+    PhaseTimer phase_timer("batch_results");
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         if (!batch->ran) throw Error("mp_batch_results before mp_batch_run");

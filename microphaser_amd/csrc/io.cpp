@@ -2,6 +2,9 @@
 
 #include <zlib.h>
 
+#include <chrono>
+#include <thread>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -76,26 +79,81 @@ class BgzfReader {
     size_t off_ = 0;
 };
 
+// Whole-file BGZF inflate on all host threads: BGZF blocks are independent deflate streams whose compressed and
+// uncompressed sizes are in the block itself, so one scan lays out the output and the blocks inflate in parallel
+// (the end-to-end path is ingest-bound once the kernels exist).
+std::vector<uint8_t> bgzf_inflate_all(const std::vector<uint8_t>& f) {
+    struct Blk { size_t in_off; uint32_t clen, isize; size_t out_off; };
+    std::vector<Blk> blks;
+    size_t off = 0, total = 0;
+    while (off < f.size()) {
+        if (off + 18 > f.size()) throw Error("truncated BGZF header");
+        const uint8_t* p = f.data() + off;
+        if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) throw Error("not a BGZF block");
+        const uint32_t xlen = p[10] | (p[11] << 8);
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t* e = p + 12 + x;
+            const uint32_t slen = e[2] | (e[3] << 8);
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2) { bsize = (e[4] | (e[5] << 8)) + 1u; found = true; }
+            x += 4 + slen;
+        }
+        if (!found || bsize < xlen + 20 || off + bsize > f.size()) throw Error("bad BGZF block size");
+        const uint32_t isize = p[bsize - 4] | (p[bsize - 3] << 8) | (p[bsize - 2] << 16) | (uint32_t(p[bsize - 1]) << 24);
+        blks.push_back(Blk{off + 12 + xlen, bsize - xlen - 12 - 8, isize, total});
+        total += isize;
+        off += bsize;
+    }
+    auto tA = std::chrono::steady_clock::now();
+    std::vector<uint8_t> out(total);
+    auto tB = std::chrono::steady_clock::now();
+    size_t nthreads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 16));
+    if (const char* e = std::getenv("MP_THREADS")) nthreads = std::max<size_t>(1, size_t(std::atoi(e)));
+    nthreads = std::min(nthreads, std::max<size_t>(1, blks.size() / 16));
+    std::vector<std::string> errors(nthreads);
+    auto work = [&](size_t t) {
+        try {
+            for (size_t b = t; b < blks.size(); b += nthreads) {
+                const Blk& k = blks[b];
+                if (!k.isize) continue;
+                z_stream zs;
+                std::memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) throw Error("inflateInit2 failed");
+                zs.next_in = const_cast<Bytef*>(f.data() + k.in_off);
+                zs.avail_in = k.clen;
+                zs.next_out = out.data() + k.out_off;
+                zs.avail_out = k.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END) throw Error("BGZF inflate failed");
+            }
+        } catch (const std::exception& e) { errors[t] = e.what(); }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthreads; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (const std::string& e : errors) if (!e.empty()) throw Error(e);
+    if (std::getenv("MP_DEBUG")) std::fprintf(stderr, "[mp] bgzf: %zu blocks, %zu threads, alloc %.0f ms, inflate %.0f ms\n", blks.size(), nthreads, std::chrono::duration<double, std::milli>(tB - tA).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tB).count());
+    return out;
+}
+
 inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (uint32_t(p[3]) << 24); }
 inline uint16_t rd16(const uint8_t* p) { return uint16_t(p[0] | (p[1] << 8)); }
 
 }  // namespace
 
 void load_bam(const std::string& path, BamData& out) {
-    FileBytes fb(path);
-    BgzfReader bg(fb.data);
     std::vector<uint8_t> buf;
+    {
+        FileBytes fb(path);
+        buf = bgzf_inflate_all(fb.data);
+    }
     size_t cur = 0;
-    auto need = [&](size_t n) -> bool {
-        while (buf.size() - cur < n) {
-            if (cur > (1u << 20)) {  // compact
-                buf.erase(buf.begin(), buf.begin() + long(cur));
-                cur = 0;
-            }
-            if (!bg.next_block(buf)) return false;
-        }
-        return true;
-    };
+    auto need = [&](size_t n) -> bool { return buf.size() - cur >= n; };
     if (!need(12)) throw Error("empty BAM " + path);
     if (std::memcmp(buf.data() + cur, "BAM\1", 4) != 0) throw Error("bad BAM magic in " + path);
     uint32_t l_text = rd32(buf.data() + cur + 4);

@@ -1,0 +1,38 @@
+"""End-to-end CLI timing (SURVEY 8d ii): write a synthetic exome as BAM / VCF / GTF / FASTA files, then time
+`microphaser somatic` (product, GPU) and `oracle_cli somatic` (CPU restatement, one thread) on those files.
+
+  python tools/e2e_cli.py <config B|C|...> [transcripts]
+"""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import microphaser_amd as m
+cfg = {"B": (1001, 1000, 30.0, 5.4), "C": (2020, 20000, 30.0, 5.4)}[sys.argv[1] if len(sys.argv) > 1 else "B"]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else cfg[1]
+out = os.path.join(ROOT, "gpurun_out", "e2e")
+os.makedirs(out, exist_ok=True)
+prefix = os.path.join(out, "synth")
+ctx = m.Context(-1)
+t = time.perf_counter(); ds = ctx.synth(cfg[0], n, cfg[2], cfg[3]); t_gen = time.perf_counter() - t
+t = time.perf_counter(); ds.write(prefix); t_write = time.perf_counter() - t
+files = {e: prefix + "." + e for e in ("bam", "vcf", "gtf", "fa")}
+sizes = {e: os.path.getsize(p) for e, p in files.items()}
+def run(cmd, stdout_path):
+    t = time.perf_counter()
+    with open(files["gtf"], "rb") as g, open(stdout_path, "wb") as o:
+        r = subprocess.run(cmd, stdin=g, stdout=o, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t
+    if r.returncode != 0: raise SystemExit(r.stderr.decode()[-2000:])
+    return dt
+cli = os.path.join(ROOT, "microphaser_amd", "_lib", "microphaser")
+ocli = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+args = [files["bam"], "--variants", files["vcf"], "--ref", files["fa"]]
+t_gpu = run([cli, "somatic"] + args + ["--tsv", out + "/g.tsv", "--normal-output", out + "/g.normal.fa"], out + "/g.fa")
+res = {"transcripts": n, "file_bytes": sizes, "generate_s": t_gen, "write_files_s": t_write, "microphaser_somatic_cli_s": t_gpu}
+if "--no-oracle" not in sys.argv:
+    t_cpu = run([ocli, "somatic"] + args + ["--tsv", out + "/o.tsv", "--normal-output", out + "/o.normal.fa"], out + "/o.fa")
+    res["oracle_cli_s"] = t_cpu
+    res["identical_outputs"] = all(open(out + "/g" + e, "rb").read() == open(out + "/o" + e, "rb").read() for e in (".fa", ".tsv", ".normal.fa"))
+windows = sum(1 for _ in open(out + "/g.tsv")) - 1
+res["tsv_rows"] = windows
+print(json.dumps(res))
