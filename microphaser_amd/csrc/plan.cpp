@@ -99,7 +99,8 @@ struct PlannerHooksT {
         w.flags = uint8_t((st.flags & 0x7C) | (is_fwd ? 0 : WSF_REVERSE));
         uint32_t walk_prefix = 0;
         {   // WSF_SIMPLE: see plan.hpp. Walk order = ascending position = deque order on '+', reversed deque on '-'.
-            bool simple = !NORMAL && st.wlen <= 32;
+            static const bool general_walk_only = std::getenv("MP_GENERAL_WALK") != nullptr;   // testing: K3's general walk everywhere
+            bool simple = !NORMAL && st.wlen <= 32 && !general_walk_only;
             auto col = [&](size_t k) -> const Variant& { return vars[is_fwd ? cols[k] : cols[cols.size() - 1 - k]]; };
             uint64_t prev = 0;
             size_t e = 0;

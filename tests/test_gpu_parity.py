@@ -298,3 +298,13 @@ def test_gpu_sequential_and_window_parallel_replay_agree(ctx, monkeypatch):
     assert st2.n_steps_w == 0 and st2.n_steps_seq == st.n_steps_w + st.n_steps_seq
     assert (fast.fasta, fast.normal_fasta, fast.tsv, fast.windows) == (slow.fasta, slow.normal_fasta, slow.tsv, slow.windows)
     assert fast.tsv.count(b"\n") > 1000
+
+
+def test_gpu_paths_agree_on_random_exomes(built):
+    """Differential sweep (tools/stress_paths.py): window-parallel replay + byte-substitution sequences vs sequential replay +
+    general sequence walk on random depths / variant spacings / indel, multi-allelic and soft-mask rates."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_paths.py"), "900", "6"], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout
