@@ -1124,18 +1124,29 @@ __device__ __forceinline__ uint8_t to_lower(uint8_t c) { return is_upper(c) ? ui
 __device__ __forceinline__ uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? uint8_t(c - 32) : c; }
 __device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
-// li-th used group slot overall -> global slot: the used slots of allocator p are [p << log2, (p << log2) + used_p).
-// The search runs once per wave on its first index (uniform, scalar loads); a wave that straddles an allocator boundary
-// fixes up its upper lanes.
-__device__ __forceinline__ uint64_t slot_of(const DeviceBatch& d, uint64_t li, uint64_t wave_first) {
-    uint32_t lo = 0, hi = NPART;   // last p with part_prefix[p] <= wave_first
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (d.part_prefix[mid] <= wave_first) lo = mid; else hi = mid;
+// li-th used entry overall -> (allocator p, offset): the used entries of allocator p are counted by prefix[p] .. prefix[p + 1].
+// Every lane holds one of the NPART = 64 prefix values, so the search is one load + one ballot per wave; lanes of a wave
+// that straddles an allocator boundary move on with readlanes.
+__device__ __forceinline__ void locate_in_parts(const unsigned long long* prefix, uint64_t li, uint64_t wave_first, bool valid,
+                                                uint32_t& part, uint64_t& offset) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t pre = prefix[lane];
+    const uint32_t p0 = uint32_t(__popcll(__ballot(pre <= wave_first))) - 1u;   // prefix[0] = 0: at least one lane votes
+    auto pre_of = [&](uint32_t q) { return (uint64_t(rdlane(uint32_t(pre >> 32), q)) << 32) | rdlane(uint32_t(pre), q); };
+    part = p0;
+    uint64_t base = pre_of(p0);
+    for (uint32_t q = p0 + 1; q < NPART; q++) {
+        const uint64_t nb = pre_of(q);
+        if (__ballot(valid && li >= nb) == 0) break;
+        if (li >= nb) { part = q; base = nb; }
     }
-    uint32_t p = lo;
-    while (p + 1 < NPART && d.part_prefix[p + 1] <= li) p++;
-    return (uint64_t(p) << d.group_part_log2) + (li - d.part_prefix[p]);
+    offset = li - base;
+}
+__device__ __forceinline__ uint64_t slot_of(const DeviceBatch& d, uint64_t li, uint64_t wave_first, bool valid) {
+    uint32_t p;
+    uint64_t off;
+    locate_in_parts(d.part_prefix, li, wave_first, valid, p, off);
+    return (uint64_t(p) << d.group_part_log2) + off;
 }
 
 // K3 -> K3b: the records that need a SHA-1 id are appended to a dense list, one wave-aggregated atomic per wave on the
@@ -1252,7 +1263,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;   // index into the dense list of live group slots
-    const uint64_t g = li < n_slots ? slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS) : 0;   // li counts the used slots of all allocators
+    const uint64_t g = slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -1496,7 +1507,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
     const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;
-    const uint64_t g = li < n_slots ? slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS) : 0;   // li counts the used slots of all allocators
+    const uint64_t g = slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -1630,18 +1641,12 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
         byte_text[v] = (txt << 8) | (n + 2);
     }
     __syncthreads();
-    const uint64_t li = uint64_t(blockIdx.x) * 64 + threadIdx.x;   // index into the dense list of records that need an id
+    const uint64_t li = uint64_t(blockIdx.x) * 64 + threadIdx.x;   // index into the dense lists of records that need an id
+    uint32_t wp;       // li-th wanted record overall -> list wp, offset woff
+    uint64_t woff;
+    locate_in_parts(d.want_prefix, li, uint64_t(blockIdx.x) * 64, li < n_recs, wp, woff);
     if (li >= n_recs) return;
-    uint32_t wp = 0;   // li-th wanted record overall -> list wp, offset li - want_prefix[wp]
-    {
-        uint32_t lo = 0, hi = NPART;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (d.want_prefix[mid] <= li) lo = mid; else hi = mid;
-        }
-        wp = lo;
-    }
-    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + (li - d.want_prefix[wp])];
+    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + woff];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
     const uint32_t seq_len = rec[4] & 0xFF;
     const WinStatic ws = d.wins[rec[6]];
