@@ -308,3 +308,37 @@ def test_gpu_paths_agree_on_random_exomes(built):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_paths.py"), "900", "6"], capture_output=True, text=True, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+@pytest.mark.parametrize("window_len", [33, 15])
+def test_gpu_matches_oracle_with_other_window_lengths(ctx, tmp_path, window_len):
+    """-w 33: exons of 30..35 nt become "short" exons (one window spanning the exon, splice_pos 2, multi-exon merges) and
+    windows exceed 32 nt (general sequence walk); -w 15: 5-mers. Same exome, oracle with the same --window-len."""
+    import microphaser_amd as m
+    from microphaser_amd.shard import merge_streams
+    prefix = os.path.join(str(tmp_path), "ow")
+    r = subprocess.run([ORACLE_CLI, "synth", "--seed", "61", "--transcripts", "40", "--window-len", str(window_len), "--skip-panics",
+                        "--prefix", prefix], capture_output=True, check=True)
+    st = json.loads(r.stdout)
+    exp = {e: open(prefix + "." + e, "rb").read() for e in ("fa", "normal.fa", "tsv")}
+    ds = ctx.synth(61, 40)
+    parts, windows, lo = [], 0, 0
+    for g in st["skipped"] + [ds.num_genes]:
+        if g > lo:
+            b = ds.batch(window_len=window_len, gene_lo=lo, gene_hi=g)
+            b.run()
+            res = b.results()
+            parts.append(dict(fasta=res.fasta, normal_fasta=res.normal_fasta, tsv=res.tsv))
+            windows += res.windows
+        if g < ds.num_genes:
+            with pytest.raises(m.MicrophaserError):
+                b = ds.batch(window_len=window_len, gene_lo=g, gene_hi=g + 1)
+                b.run()
+                b.results()
+        lo = g + 1
+    got = merge_streams(parts)
+    assert windows == st["windows"]
+    assert got["fasta"] == exp["fa"]
+    assert got["normal_fasta"] == exp["normal.fa"]
+    assert got["tsv"] == exp["tsv"]
+    assert exp["tsv"].count(b"\n") > 200
