@@ -3,10 +3,14 @@
 //   microphaser somatic <tumor.bam> -r/--ref F -b/--variants V [-t/--tsv info.tsv]
 //              [-n/--normal-output normal.fasta] [-w/--window-len 27] [-u] [-v]  < GTF  > FASTA
 // exit status 1 on error, message on stderr (src/main.rs:260-265).
+// Extra (not in the reference): --device N, or --devices a,b,... = genes sharded over several GPUs from this one process
+// (one context + host thread per GPU, contiguous gene ranges, outputs concatenated in gene order: byte-identical to one GPU).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/microphaser_hip.h"
 
@@ -115,6 +119,7 @@ int main(int argc, char** argv) {
     std::string bam, vcf, ref, tsv = "info.tsv", normal = "normal.fasta";
     unsigned long long window_len = 27;
     int warn_only = 0, device = 0;
+    std::vector<int> devices;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* {
@@ -128,17 +133,73 @@ int main(int argc, char** argv) {
         else if (a == "--window-len" || a == "-w") window_len = std::strtoull(val(), nullptr, 10);
         else if (a == "--unsupported-allele-warning-only" || a == "-u") warn_only = 1;
         else if (a == "--device") device = std::atoi(val());
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char* q = val(); *q;) {
+                char* end = nullptr;
+                devices.push_back(int(std::strtol(q, &end, 10)));
+                if (end == q) { std::fprintf(stderr, "bad --devices list\n"); return 1; }
+                q = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "-v" || a == "--verbose") {}
         else if (!a.empty() && a[0] != '-') bam = a;
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
     }
     if (bam.empty() || vcf.empty() || ref.empty()) { std::fprintf(stderr, "the sample BAM, --variants and --ref are required\n"); return 1; }
+    if (devices.size() == 1) device = devices[0];
     mp_ctx* ctx = nullptr;
-    if (mp_create(device, &ctx) != 0) { int rc = fail(ctx, "mp_create"); mp_destroy(ctx); return rc; }
+    if (mp_create(devices.size() > 1 ? -1 : device, &ctx) != 0) { int rc = fail(ctx, "mp_create"); mp_destroy(ctx); return rc; }   // -1: host-only loader
     mp_dataset* ds = nullptr;
     if (mp_dataset_load(ctx, bam.c_str(), vcf.c_str(), ref.c_str(), nullptr, warn_only, &ds) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
+    const int mode = normal_mode ? MP_MODE_NORMAL : MP_MODE_SOMATIC;
+    if (devices.size() > 1) {
+        // genes are independent units (src/microphasing.rs:895-942): contiguous gene ranges, one context + thread per GPU
+        const uint32_t ng = mp_dataset_num_genes(ds);
+        const size_t nd = devices.size();
+        {   // the data set builds its `normal` gene view lazily: do it once here, the shards then only read
+            mp_batch* warm = nullptr;
+            if (mp_batch_create(ctx, ds, mode, window_len, 0, 0, &warm) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
+            mp_batch_free(warm);
+        }
+        struct Shard { mp_ctx* ctx = nullptr; mp_results* res = nullptr; std::string err; };
+        std::vector<Shard> shards(nd);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < nd; k++)
+            th.emplace_back([&, k] {
+                Shard& sh = shards[k];
+                const uint32_t lo = uint32_t(uint64_t(ng) * k / nd), hi = uint32_t(uint64_t(ng) * (k + 1) / nd);
+                mp_batch* b = nullptr;
+                if (mp_create(devices[k], &sh.ctx) != 0 || mp_batch_create(sh.ctx, ds, mode, window_len, lo, hi, &b) != 0 ||
+                    mp_batch_run(sh.ctx, b, nullptr) != 0 || mp_batch_results(sh.ctx, b, &sh.res) != 0)
+                    sh.err = sh.ctx ? mp_last_error(sh.ctx) : "mp_create failed";
+                if (b) mp_batch_free(b);
+            });
+        for (auto& t : th) t.join();
+        for (size_t k = 0; k < nd; k++)   // the first failing gene range in gene order, like a sequential run
+            if (!shards[k].err.empty()) { std::fprintf(stderr, "microphaser: %s\n", shards[k].err.c_str()); return 1; }
+        std::string fa, nfa, tsvs;
+        for (size_t k = 0; k < nd; k++) {
+            size_t n = 0;
+            const char* p = mp_results_fasta(shards[k].res, &n); fa.append(p, n);
+            p = mp_results_normal_fasta(shards[k].res, &n); nfa.append(p, n);
+            p = mp_results_tsv(shards[k].res, &n);
+            if (n) {   // the header is the first line of every non-empty shard: keep the first one only
+                if (tsvs.empty()) tsvs.append(p, n);
+                else { const char* nl = static_cast<const char*>(std::memchr(p, '\n', n)); if (nl) tsvs.append(nl + 1, size_t(p + n - (nl + 1))); }
+            }
+            mp_results_free(shards[k].res);
+            mp_destroy(shards[k].ctx);
+        }
+        std::fwrite(fa.data(), 1, fa.size(), stdout);
+        if (!normal_mode && !write_file(normal, nfa.data(), nfa.size())) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
+        if (!write_file(tsv, tsvs.data(), tsvs.size())) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
+        mp_dataset_free(ds);
+        mp_destroy(ctx);
+        return 0;
+    }
     mp_results* res = nullptr;
-    if (mp_phase_dataset(ctx, ds, normal_mode ? MP_MODE_NORMAL : MP_MODE_SOMATIC, window_len, &res) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
+    if (mp_phase_dataset(ctx, ds, mode, window_len, &res) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
     size_t n = 0;
     const char* p = mp_results_fasta(res, &n);
     std::fwrite(p, 1, n, stdout);

@@ -342,3 +342,23 @@ def test_gpu_matches_oracle_with_other_window_lengths(ctx, tmp_path, window_len)
     assert got["normal_fasta"] == exp["normal.fa"]
     assert got["tsv"] == exp["tsv"]
     assert exp["tsv"].count(b"\n") > 200
+
+
+def test_gpu_cli_multi_device_sharding_is_byte_identical(built, tmp_path):
+    """`--devices a,b`: one context + host thread per GPU over contiguous gene ranges (here both shards on device 0 - the box
+    has one GPU - which exercises the same code path), outputs concatenated in gene order."""
+    import microphaser_amd as m
+    ctx = m.Context(-1)
+    ds = ctx.synth(77, 24)
+    prefix = str(tmp_path / "s")
+    ds.write(prefix)
+    outs = []
+    for extra in ([], ["--devices", "0,0,0"]):
+        tag = "m" if extra else "s"
+        with open(prefix + ".gtf", "rb") as g:
+            r = subprocess.run([PRODUCT_CLI, "somatic", prefix + ".bam", "-b", prefix + ".vcf", "-r", prefix + ".fa", "-t", str(tmp_path / (tag + ".tsv")),
+                                "-n", str(tmp_path / (tag + ".nfa"))] + extra, stdin=g, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append((r.stdout, (tmp_path / (tag + ".tsv")).read_bytes(), (tmp_path / (tag + ".nfa")).read_bytes()))
+    assert outs[0] == outs[1]
+    assert outs[0][1].count(b"\n") > 1000
