@@ -1,6 +1,7 @@
 #include "device.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace mp {
@@ -133,6 +134,7 @@ void DeviceContext::upload(const Batch& b) {
     glog_ = 12; rlog_ = 12;
     while ((uint64_t(NPART) << glog_) < g_need + g_need / 4) glog_++;
     while ((uint64_t(NPART) << rlog_) < r_need + r_need / 4) rlog_++;
+    if (std::getenv("MP_TEST_SMALL_CAPS")) glog_ = rlog_ = 8;   // tests: start far too small, so that run() has to grow the buffers
     alloc_outputs();
     HIP_OK(hipStreamSynchronize(stream_));
 }

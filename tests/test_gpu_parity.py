@@ -362,3 +362,26 @@ def test_gpu_cli_multi_device_sharding_is_byte_identical(built, tmp_path):
         outs.append((r.stdout, (tmp_path / (tag + ".tsv")).read_bytes(), (tmp_path / (tag + ".nfa")).read_bytes()))
     assert outs[0] == outs[1]
     assert outs[0][1].count(b"\n") > 1000
+
+
+def test_gpu_result_buffers_grow_on_overflow(ctx, monkeypatch):
+    """The output allocators start from an estimate; when any of the 64 sub-ranges (groups, records, wanted-id lists) overflows,
+    run() enlarges the buffers and repeats the pass. Forced here by starting from 256 slots per allocator."""
+    ds = ctx.synth(515, 40)
+    ref = ds.phase()
+    monkeypatch.setenv("MP_TEST_SMALL_CAPS", "1")
+    b = ds.batch()
+    st = b.run()
+    res = b.results()
+    assert st.attempts > 1
+    assert (res.fasta, res.normal_fasta, res.tsv, res.windows) == (ref.fasta, ref.normal_fasta, ref.tsv, ref.windows)
+    # the normal-mode replay allocates larger chunks: same check
+    monkeypatch.delenv("MP_TEST_SMALL_CAPS")
+    import microphaser_amd as m
+    nref = ds.phase(mode=m.MODE_NORMAL)
+    monkeypatch.setenv("MP_TEST_SMALL_CAPS", "1")
+    b = ds.batch(mode=m.MODE_NORMAL)
+    st = b.run()
+    res = b.results()
+    assert st.attempts > 1
+    assert (res.fasta, res.tsv) == (nref.fasta, nref.tsv)
