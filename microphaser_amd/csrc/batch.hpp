@@ -67,7 +67,9 @@ struct Batch {
     };
     std::vector<SegInfo> seg_info;
     std::vector<ExonW> exons_w;
-    std::vector<WChunk> wchunks;
+    std::vector<WChunk> wchunks, wchunks_m;   // single-block / multi-block window-parallel work items (kernels.hpp)
+    uint32_t rows_per_lane_w = 1;
+    std::vector<WChunk> achunks;              // admission work items: (exon, first read, count <= 64)
     uint64_t n_adm = 0;                   // AdmEntry count (sum of ExonW::n_reads)
     std::vector<uint64_t> v_sombits;      // bit (variant index in the batch) set <=> somatic
     // ---- sizing

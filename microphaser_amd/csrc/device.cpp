@@ -94,6 +94,11 @@ void DeviceContext::upload(const Batch& b) {
     d_.str_pool = up(b.str_pool);
     d_.exons_w = up(b.exons_w);
     d_.wchunks = up(b.wchunks);
+    d_.wchunks_m = up(b.wchunks_m);
+    d_.n_wchunks_m = uint32_t(b.wchunks_m.size());
+    d_.rows_per_lane_w = b.rows_per_lane_w;
+    d_.achunks = up(b.achunks);
+    d_.n_achunks = uint32_t(b.achunks.size());
     d_.step_ncols = up(b.step_ncols);
     d_.step_rlo = up(b.step_rlo);
     d_.step_rn = up(b.step_rn);
@@ -127,7 +132,7 @@ void DeviceContext::upload(const Batch& b) {
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
-    const uint64_t waves = b.wchunks.size() + b.segs.size();
+    const uint64_t waves = b.wchunks.size() + b.segs.size() + b.wchunks_m.size() * (1 + b.rows_per_lane_w);
     uint64_t g_need = uint64_t(d_.n_wins) * 6 + waves * 256 + 4096;
     uint64_t r_need = g_need / 3 + waves * 128 + 4096;
     if (b.normal) { g_need += waves * 1024; r_need = g_need; }   // every haplotype of every window has a record in this mode

@@ -588,16 +588,42 @@ __device__ __forceinline__ void tr_to_f(const ExonW& e, bool is_rev, uint32_t tl
     else { flo = e.f0 - (thi - 1 - e.tr0); fhi = e.f0 - (tlo - e.tr0) + 1; }
 }
 
+// mask helpers for W = 1 or 2 words per read (bit b of the mask = variant r_varlo + b)
+template <int W>
+__device__ __forceinline__ bool mask_hits(const uint64_t (&m)[W], uint32_t flo, uint32_t fhi, uint32_t base) {
+    bool hit = false;
+#pragma unroll
+    for (int w = 0; w < W; w++) hit |= (m[w] & bit_range(flo, fhi, base + 64u * w)) != 0;
+    return hit;
+}
+// bits (flo + b - base), b in [0, 64), of the mask as one word (only the low ncols <= 63 bits are used by the caller)
+template <int W>
+__device__ __forceinline__ uint64_t mask_extract(const uint64_t (&m)[W], uint32_t flo, uint32_t base) {
+    if (flo >= base) {
+        const uint32_t rel = flo - base, wi = rel >> 6, sh = rel & 63u;
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) { if (uint32_t(w) == wi) lo = m[w]; if (uint32_t(w) == wi + 1) hi = m[w]; }
+        return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    }
+    const uint32_t nsh = base - flo;
+    return nsh < 64 ? m[0] << nsh : 0ull;
+}
+
+template <int W>
 __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
-    const ExonW e = d.exons_w[blockIdx.x];   // one wave per exon, lanes stride over its reads
+    const WChunk A = d.achunks[blockIdx.x];   // one wave per 64 candidate reads of an exon: step_first = first read, n_steps = count
+    const ExonW e = d.exons_w[A.exon];
     const bool is_rev = e.strand != 0;
     const uint32_t rbase = e.rbase + e.read_lo;
     const uint32_t sso0 = e.sso0, sso1 = e.sso1;
-    for (uint32_t k = threadIdx.x; k < e.n_reads; k += 64) {
+    for (uint32_t k = A.step_first + threadIdx.x; k < A.step_first + A.n_steps; k += 64) {
         const uint32_t gi = rbase + k;
         const uint32_t start = d.r_pos[gi], end = d.r_end[gi], rvl = d.r_varlo[gi];
-        const uint64_t sup = d.r_sup[gi], lq = d.r_lq[gi];
-        const uint64_t dirty = lq | (sup & bit_range(e.sl_f_lo, e.sl_f_hi, rvl));   // low quality, or support of a start-loss variant
+        uint64_t dirty[W];   // low quality, or support of a start-loss variant
+#pragma unroll
+        for (int w = 0; w < W; w++)
+            dirty[w] = d.r_lq[uint64_t(gi) * W + w] | (d.r_sup[uint64_t(gi) * W + w] & bit_range(e.sl_f_lo, e.sl_f_hi, rvl + 64u * w));
         AdmEntry out;
         out.ord = 0xFFFFFFFFu;
         out.seen_lo = 0;
@@ -608,7 +634,7 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
             const uint32_t tlo = st.col_hi - nc, thi = st.col_hi - st.n_add;
             uint32_t flo, fhi;
             tr_to_f(e, is_rev, tlo, thi, flo, fhi);
-            if (dirty & bit_range(flo, fhi, rvl)) return false;
+            if (mask_hits<W>(dirty, flo, fhi, rvl)) return false;
             out.ord = si;
             out.seen_lo = tlo;
             return true;
@@ -813,6 +839,211 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
         }
     }
     }   // work items of this wave
+    if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
+}
+
+// K2w for deeper data: RPL reads per lane (a block of 64 * RPL consecutive reads) and W mask words per read. Same row
+// derivation as k2w_window_rows; the haplotypes are counted by repeated minimum extraction (bitwise descent with ballots),
+// which yields them in ascending order, 64 at a time.
+template <int RPL, int W>
+__global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
+    constexpr uint32_t CAP = 64u * RPL;
+    constexpr uint32_t GROUP_CHUNK = 64u * RPL + 64u, REC_CHUNK_W = 64;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long* const gcur = d.cursors + part * 32;
+    unsigned long long* const rcur = gcur + 16;
+    const uint64_t gpart_lo = uint64_t(part) << d.group_part_log2, gpart_hi = uint64_t(part + 1) << d.group_part_log2;
+    const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_hi = uint64_t(part + 1) << d.rec_part_log2;
+    uint64_t chunk_pos = 0, chunk_end = 0, rec_pos = 0, rec_end = 0;
+    uint32_t sticky_err = 0;
+    const WChunk C = d.wchunks_m[blockIdx.x];
+    const ExonW e = d.exons_w[C.exon];
+    const bool is_rev = e.strand != 0;
+    const uint32_t rbase = e.rbase;
+    const uint32_t vbase = e.vbase;
+    uint32_t L = 0;
+    bool have_block = false;
+    uint32_t q_start[RPL], q_end[RPL], q_rvl[RPL], q_ord[RPL], q_seen[RPL];
+    uint64_t q_sup[RPL][W], q_dirty[RPL][W];
+#pragma unroll
+    for (int k = 0; k < RPL; k++) {
+        q_start[k] = q_end[k] = q_rvl[k] = q_seen[k] = 0; q_ord[k] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < W; w++) { q_sup[k][w] = 0; q_dirty[k][w] = 0; }
+    }
+    for (uint32_t s0 = 0; s0 < C.n_steps; s0 += 64) {
+        const uint32_t nb = min(64u, C.n_steps - s0);
+        uint32_t w0 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0, w7 = 0, w8 = 0, w9 = 0;
+        if (lane < nb) {
+            const uint32_t si = C.step_first + s0 + lane;
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + si);
+            w0 = sp[0]; w2 = sp[2]; w3 = sp[3]; w4 = sp[4]; w5 = sp[5];
+            w6 = d.step_rlo[si];
+            const uint32_t nc = d.step_ncols[si];
+            w7 = uint32_t(d.step_rn[si]) | (nc << 16);
+            if (((w5 >> 8) & SF_PRINT) && nc) {
+                uint32_t flo, fhi;
+                tr_to_f(e, is_rev, w2 - nc, w2, flo, fhi);
+                const uint64_t gv = uint64_t(vbase) + flo;
+                const uint64_t x0 = d.v_sombits[gv >> 6], x1 = d.v_sombits[(gv >> 6) + 1];
+                const uint32_t sh = uint32_t(gv & 63);
+                uint64_t bits = (sh ? ((x0 >> sh) | (x1 << (64 - sh))) : x0) & (~0ull >> (64 - nc));
+                if (!is_rev) bits = __brevll(bits) >> (64 - nc);
+                w8 = uint32_t(bits); w9 = uint32_t(bits >> 32);
+            }
+        }
+        uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT));
+        while (printing) {
+            const uint32_t i = uint32_t(__builtin_ctzll(printing));
+            printing &= printing - 1;
+            const uint32_t si = C.step_first + s0 + i;
+            const uint32_t sso = rdlane(w0, i), col_hi = rdlane(w2, i), win = rdlane(w3, i);
+            const uint32_t p4 = rdlane(w4, i), p5 = rdlane(w5, i), r_lo = rdlane(w6, i), p7 = rdlane(w7, i);
+            const uint64_t som_mask = (uint64_t(rdlane(w9, i)) << 32) | rdlane(w8, i);
+            const uint32_t wlen = (p4 >> 16) & 0xFF, sflags = (p5 >> 8) & 0xFF;
+            const uint32_t r_n = p7 & 0xFFFF, ncols = p7 >> 16;
+            const uint32_t splice_end = sso + wlen;
+            uint32_t flo, fhi;
+            tr_to_f(e, is_rev, col_hi - ncols, col_hi, flo, fhi);
+            const uint64_t cmask = ncols ? (~0ull >> (64 - ncols)) : 0ull;
+            if (r_n && (!have_block || r_lo < L || r_lo + r_n > L + CAP)) {
+                const uint32_t r_hi = r_lo + r_n;
+                if (!is_rev) L = r_lo;
+                else L = r_hi > e.read_lo + CAP ? r_hi - CAP : e.read_lo;
+                have_block = true;
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    const uint32_t ri = L + 64u * k + lane;
+                    q_ord[k] = 0xFFFFFFFFu;
+                    if (ri >= e.read_lo && ri < e.read_lo + e.n_reads) {
+                        const uint32_t gi = rbase + ri;
+                        q_start[k] = d.r_pos[gi]; q_end[k] = d.r_end[gi]; q_rvl[k] = d.r_varlo[gi];
+#pragma unroll
+                        for (int w = 0; w < W; w++) {
+                            q_sup[k][w] = d.r_sup[uint64_t(gi) * W + w];
+                            q_dirty[k][w] = d.r_lq[uint64_t(gi) * W + w] | (q_sup[k][w] & bit_range(e.sl_f_lo, e.sl_f_hi, q_rvl[k] + 64u * w));
+                        }
+                        const AdmEntry a = d.adm[uint64_t(e.adm_off) + (ri - e.read_lo)];
+                        q_ord[k] = a.ord; q_seen[k] = a.seen_lo;
+                    }
+                }
+            }
+            // ---- the rows of this window
+            bool act[RPL];
+            uint64_t hap[RPL];
+            uint32_t nrows = 0, nvalid = 0;
+            bool zero_here = false;
+#pragma unroll
+            for (int k = 0; k < RPL; k++) {
+                const uint32_t ri = L + 64u * k + lane;
+                const bool row = r_n && ri >= r_lo && ri < r_lo + r_n && q_ord[k] <= si &&
+                                 (is_rev ? q_start[k] <= sso : q_end[k] >= splice_end);
+                act[k] = false;
+                hap[k] = 0;
+                if (row) {
+                    uint32_t slo, shi;
+                    tr_to_f(e, is_rev, q_seen[k], col_hi, slo, shi);
+                    act[k] = !mask_hits<W>(q_dirty[k], slo, shi, q_rvl[k]);
+                    if (act[k] && ncols) {
+                        const uint64_t sb = mask_extract<W>(q_sup[k], flo, q_rvl[k]) & cmask;
+                        hap[k] = is_rev ? sb : (__brevll(sb) >> (64 - ncols));
+                    }
+                }
+                nrows += __popcll(__ballot(row));
+                nvalid += __popcll(__ballot(act[k]));
+                zero_here |= act[k] && hap[k] == 0;
+            }
+            const bool has_zero = __ballot(zero_here) != 0;
+            nvalid += has_zero ? 0u : 1u;
+            uint32_t werr = sticky_err;
+            if (chunk_pos + nvalid > chunk_end) {
+                unsigned long long base = 0;
+                const uint32_t want = max(GROUP_CHUNK, nvalid);
+                if (lane == 0) base = atomicAdd(gcur, (unsigned long long)want);
+                const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                chunk_pos = gpart_lo + ((uint64_t(bhi) << 32) | blo);
+                chunk_end = chunk_pos + want;
+            }
+            const bool can_write = chunk_end <= gpart_hi;
+            if (!can_write) werr |= WD_GROUP_OVERFLOW;
+            const uint64_t gbase = chunk_pos;
+            const bool need_all = (sflags & SF_NEED_RECS) != 0;
+            auto emit = [&](bool on, uint64_t gi, uint32_t kh, uint32_t kl, uint32_t cnt) {
+                const uint64_t key = (uint64_t(kh) << 32) | kl;
+                const bool need = on && can_write && (need_all || (key & som_mask) != 0);
+                const uint64_t nm = __ballot(need);
+                const uint32_t nneed = __popcll(nm);
+                if (nneed && rec_pos + nneed > rec_end) {
+                    unsigned long long base = 0;
+                    const uint32_t want = max(REC_CHUNK_W, nneed);
+                    if (lane == 0) base = atomicAdd(rcur, (unsigned long long)want);
+                    const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                    rec_pos = rpart_lo + ((uint64_t(bhi) << 32) | blo);
+                    rec_end = rec_pos + want;
+                }
+                uint32_t rec = 0xFFFFFFFFu;
+                if (need) {
+                    const uint64_t r = rec_pos + lanes_below(nm, lane);
+                    if (r < rpart_hi) rec = uint32_t(r);
+                }
+                if (nneed && rec_pos + nneed > rpart_hi) sticky_err |= WD_REC_OVERFLOW;
+                rec_pos += nneed;
+                if (on && can_write) {
+                    Group G; G.hap = key; G.count = cnt; G.aux = 0;
+                    d.groups[gi] = G;
+                    d.g_win[gi] = win;
+                    d.g_rec[gi] = rec;
+                }
+            };
+            uint32_t ng = has_zero ? 0u : 1u;   // lane 0 stages the zero-count reference group
+            uint32_t sg_hi = 0, sg_lo = 0, sg_cnt = 0;
+            for (;;) {
+                bool c[RPL];
+                bool any_c = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++) { c[k] = act[k]; any_c |= c[k]; }
+                if (!__ballot(any_c)) break;
+                for (int bit = int(ncols) - 1; bit >= 0; bit--) {
+                    const uint64_t mk = 1ull << bit;
+                    bool z = false;
+#pragma unroll
+                    for (int k = 0; k < RPL; k++) z |= c[k] && !(hap[k] & mk);
+                    if (__ballot(z)) {
+#pragma unroll
+                        for (int k = 0; k < RPL; k++) c[k] = c[k] && !(hap[k] & mk);
+                    }
+                }
+                uint32_t cnt = 0, khi = 0, klo = 0;
+                bool have_key = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    const uint64_t m = __ballot(c[k]);
+                    cnt += __popcll(m);
+                    if (m && !have_key) {
+                        const uint32_t l = __builtin_ctzll(m);
+                        khi = rdlane(uint32_t(hap[k] >> 32), l);
+                        klo = rdlane(uint32_t(hap[k]), l);
+                        have_key = true;
+                    }
+                    if (c[k]) act[k] = false;
+                }
+                if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_cnt = cnt; }
+                ng++;
+                if ((ng & 63) == 0) emit(true, gbase + ng - 64 + lane, sg_hi, sg_lo, sg_cnt);
+            }
+            if (ng & 63) emit(lane < (ng & 63), gbase + (ng & ~63u) + lane, sg_hi, sg_lo, sg_cnt);
+            if (lane == 0) {
+                WinDyn wd;
+                wd.group_off = uint32_t(gbase);
+                wd.ngroups = ng;
+                wd.nrows = nrows;
+                wd.flags = WD_DONE | werr;
+                d.win_dyn[win] = wd;
+            }
+            if (can_write) chunk_pos += ng;
+        }
+    }
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
 
@@ -1748,13 +1979,34 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
 
 void launch_k2_admission(const DeviceBatch& d, hipStream_t stream) {
     if (!d.n_exons_w) return;
-    hipLaunchKernelGGL(k2a_admission, dim3(d.n_exons_w), dim3(64), 0, stream, d);
+    if (!d.n_achunks) return;
+    if (d.mask_words == 1) hipLaunchKernelGGL(k2a_admission<1>, dim3(d.n_achunks), dim3(64), 0, stream, d);
+    else if (d.mask_words == 2) hipLaunchKernelGGL(k2a_admission<2>, dim3(d.n_achunks), dim3(64), 0, stream, d);
+    else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     HIP_CHECK_LAUNCH();
 }
+template <int W>
+static void launch_k2w_multi(const DeviceBatch& d, hipStream_t stream) {
+    dim3 grid(d.n_wchunks_m), block(64);
+    switch (d.rows_per_lane_w) {
+        case 1: hipLaunchKernelGGL((k2w_window_rows_multi<1, W>), grid, block, 0, stream, d); break;
+        case 2: hipLaunchKernelGGL((k2w_window_rows_multi<2, W>), grid, block, 0, stream, d); break;
+        case 4: hipLaunchKernelGGL((k2w_window_rows_multi<4, W>), grid, block, 0, stream, d); break;
+        case 8: hipLaunchKernelGGL((k2w_window_rows_multi<8, W>), grid, block, 0, stream, d); break;
+        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+}
 void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
-    if (!d.n_wchunks) return;
-    hipLaunchKernelGGL(k2w_window_rows, dim3((d.n_wchunks + K2W_ITEMS - 1) / K2W_ITEMS), dim3(64), 0, stream, d);
-    HIP_CHECK_LAUNCH();
+    if (d.n_wchunks) {
+        hipLaunchKernelGGL(k2w_window_rows, dim3((d.n_wchunks + K2W_ITEMS - 1) / K2W_ITEMS), dim3(64), 0, stream, d);
+        HIP_CHECK_LAUNCH();
+    }
+    if (d.n_wchunks_m) {   // exons with more than 64 candidate reads per window, or two mask words per read
+        if (d.mask_words == 1) launch_k2w_multi<1>(d, stream);
+        else if (d.mask_words == 2) launch_k2w_multi<2>(d, stream);
+        else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+        HIP_CHECK_LAUNCH();
+    }
 }
 
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {

@@ -33,13 +33,16 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     uint32_t n_segs;
     // window-parallel replay (K2a + K2w), see plan.hpp ExonW
     const ExonW* exons_w;
-    const WChunk* wchunks;
+    const WChunk* wchunks;          // work items of k2w_window_rows (<= 64 candidate reads per window, one mask word)
+    const WChunk* wchunks_m;        // work items of k2w_window_rows_multi (deeper exons, or two mask words)
     const uint8_t* step_ncols;
     const uint32_t* step_rlo;
     const uint16_t* step_rn;
     const uint64_t* v_sombits;      // bit (var_off + f) set <=> that variant is somatic
     AdmEntry* adm;                  // K2a output
-    uint32_t n_exons_w, n_wchunks;
+    const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
+    uint32_t n_exons_w, n_wchunks, n_wchunks_m, n_achunks;
+    uint32_t rows_per_lane_w;       // RPL of k2w_window_rows_multi: 64 * RPL >= candidate reads of any of its windows
     uint64_t n_adm;
     uint32_t n_reads, n_tx, n_wins, mask_words;
     uint32_t normal;              // 1: `microphaser normal` semantics (src/normal_microphasing.rs)

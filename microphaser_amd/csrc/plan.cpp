@@ -366,7 +366,8 @@ static void validate_segments(const Batch& b) {
         if (uint64_t(e.step_off) + e.n_steps > b.steps.size() || e.tx >= b.tx.size()) throw Error("internal error: window-parallel exon outside the plan");
         covered += e.n_steps;
     }
-    for (const WChunk& c : b.wchunks)
+    for (const std::vector<WChunk>* list : {&b.wchunks, &b.wchunks_m})
+    for (const WChunk& c : *list)
         if (c.exon >= b.exons_w.size() || c.step_first < b.exons_w[c.exon].step_off ||
             uint64_t(c.step_first) + c.n_steps > uint64_t(b.exons_w[c.exon].step_off) + b.exons_w[c.exon].n_steps)
             throw Error("internal error: work item outside its exon");
@@ -386,7 +387,10 @@ static void route_window_parallel(Batch& b) {
     b.wchunks.clear();
     b.n_adm = 0;
     if (b.seg_info.size() != b.segs.size()) throw Error("internal error: segment info out of step");
-    const bool enabled = !b.normal && b.mask_words == 1 && !std::getenv("MP_SEQUENTIAL_REPLAY");
+    const bool enabled = !b.normal && b.mask_words <= 2 && !std::getenv("MP_SEQUENTIAL_REPLAY");
+    b.wchunks_m.clear();
+    b.achunks.clear();
+    uint32_t max_rn_multi = 0;
     std::vector<SegDev> keep;
     constexpr uint32_t CHUNK_STEPS = 96;
     for (size_t i = 0; i < b.segs.size(); i++) {
@@ -394,7 +398,7 @@ static void route_window_parallel(Batch& b) {
         const Batch::SegInfo& si = b.seg_info[i];
         const TxDev& T = b.tx[g.tx];
         const GeneHost& gh = b.genes[T.gene];
-        bool ok = enabled && si.n_exons == 1 && si.cols_ok && si.max_rn <= 64 && g.n_steps > 0;
+        bool ok = enabled && si.n_exons == 1 && si.cols_ok && si.max_rn <= 512 && g.n_steps > 0;
         const uint32_t read_lo = si.read_lo == 0xFFFFFFFFu ? 0 : si.read_lo;
         const uint32_t read_hi = std::max(si.read_hi, read_lo);
         if (ok && T.strand)   // `contains` (:281-294) can only hit when two reads of the range share a name
@@ -419,9 +423,16 @@ static void route_window_parallel(Batch& b) {
         e.sso1 = g.n_steps > 1 ? b.steps[g.step_off + 1].sso : e.sso0;
         const uint32_t ei = uint32_t(b.exons_w.size());
         b.exons_w.push_back(e);
-        for (uint32_t s0 = 0; s0 < g.n_steps; s0 += CHUNK_STEPS)
-            b.wchunks.push_back(WChunk{ei, g.step_off + s0, std::min(CHUNK_STEPS, g.n_steps - s0), 0});
+        for (uint32_t k0 = 0; k0 < e.n_reads; k0 += 64) b.achunks.push_back(WChunk{ei, k0, std::min(64u, e.n_reads - k0), 0});
+        const bool multi = si.max_rn > 64 || b.mask_words > 1;   // needs several reads per lane / two mask words
+        if (multi) max_rn_multi = std::max(max_rn_multi, si.max_rn);
+        // deep windows cost ~RPL x more each and there are few of them: smaller work items keep the chip full
+        const uint32_t chunk = multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
+        for (uint32_t s0 = 0; s0 < g.n_steps; s0 += chunk)
+            (multi ? b.wchunks_m : b.wchunks).push_back(WChunk{ei, g.step_off + s0, std::min(chunk, g.n_steps - s0), 0});
     }
+    b.rows_per_lane_w = 1;
+    while (64u * b.rows_per_lane_w < max_rn_multi) b.rows_per_lane_w *= 2;
     b.segs.swap(keep);
     b.seg_info.clear();
 }
