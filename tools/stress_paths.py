@@ -29,12 +29,12 @@ rng = random.Random(first)
 bad = 0
 for k in range(count):
     seed = first + k
-    depth = rng.choice([8, 20, 30, 45, 60])
-    spacing = rng.choice([2.0, 3.5, 5.4, 9.0, 20.0])
+    depth = rng.choice([8, 20, 30, 45, 60, 110, 220])     # > ~90x: more than 64 candidate reads per window (multi-block replay)
+    spacing = rng.choice([1.35, 2.0, 3.5, 5.4, 9.0, 20.0])   # 1.35 nt: more than 64 variants under a read (two mask words)
     indel = rng.choice([0, 0, 0, 0.03])
     multi = rng.choice([0, 0, 0.08])
     soft = rng.choice([0, 0, 0.4])
-    n = rng.choice([12, 20])
+    n = rng.choice([12, 20]) if depth < 100 else 6
     args = [str(x) for x in (seed, n, depth, spacing, indel, multi, soft)]
     outs = []
     for env_extra in ({}, {"MP_SEQUENTIAL_REPLAY": "1", "MP_GENERAL_WALK": "1"}):
