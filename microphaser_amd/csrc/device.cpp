@@ -193,7 +193,7 @@ void DeviceContext::run(RunTiming& t) {
             continue;
         }
         if (err & WD_EPOCH_OVERFLOW) throw Error("normal mode: more than 128 live column epochs in one transcript (variant density too high for this build)");
-        if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 1024 distinct haplotypes in one window");
+        if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 512 distinct haplotypes in one window");
         uint64_t max_g = 0, max_r = 0;
         for (uint32_t p = 0; p < NPART; p++) { max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]); }
         if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || max_g > (1ull << glog_) || max_r > (1ull << rlog_)) {

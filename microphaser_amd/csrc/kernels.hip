@@ -1061,8 +1061,8 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
 // and at a printing step derives, per (read, epoch), the number of live copies in closed form and the haplotype word
 // from the K1 support mask; haplotypes are counted in an LDS hash table and written in ascending key order.
 constexpr uint32_t K2N_EPOCHS = 128;       // live column epochs of one transcript (ring)
-constexpr uint32_t K2N_TABLE = 1024;       // haplotype hash slots per window
-constexpr uint32_t K2N_GROUP_CHUNK = 1024; // group slots per allocation (>= K2N_TABLE)
+constexpr uint32_t K2N_TABLE = 512;        // haplotype hash slots per window (LDS: 31 KB per wave -> 5 waves per CU; 1024 slots: 43 KB -> 3)
+constexpr uint32_t K2N_GROUP_CHUNK = 512;  // group slots per allocation (>= K2N_TABLE)
 struct EpochMeta { int32_t xmin, xmax; int32_t w, range; };
 
 template <int RPL>
