@@ -88,6 +88,8 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
  * shrink_left, push_read, extend_right} and the count + sequence phases of print_haplotypes,
  * src/microphasing.rs:220-343, 373-603). Inputs and results stay in HBM. */
 int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* stats);
+/* A context keeps ONE batch resident in HBM: creating another batch on the same context evicts the previous one;
+ * mp_batch_run brings its batch back if needed, mp_batch_results fails if another batch ran since. */
 /* Copy the results back and produce the reference's three output streams (replaces the rest of
  * print_haplotypes + phase_gene: :604-880, :1345-1941, src/common.rs:376-568). */
 int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out);

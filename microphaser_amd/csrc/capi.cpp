@@ -20,6 +20,8 @@ using namespace mp;
 
 struct mp_ctx {
     std::unique_ptr<DeviceContext> dev;
+    const void* resident = nullptr;   // the batch whose buffers the device context currently holds (one at a time)
+    const void* last_run = nullptr;   // the batch the device results belong to
     std::string err;
 };
 struct mp_dataset {
@@ -175,6 +177,8 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
         if (ctx->dev) {
             ctx->dev->upload(b->batch);
             b->uploaded = true;
+            ctx->resident = b.get();
+            ctx->last_run = nullptr;
         }
         *out = b.release();
     });
@@ -184,9 +188,14 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
     PhaseTimer phase_timer("batch_run");
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
-        if (!batch->uploaded) { dev.upload(batch->batch); batch->uploaded = true; }
+        if (!batch->uploaded || ctx->resident != batch) {   // another batch was made resident in between: bring this one back
+            dev.upload(batch->batch);
+            batch->uploaded = true;
+            ctx->resident = batch;
+        }
         dev.run(batch->timing);
         batch->ran = true;
+        ctx->last_run = batch;
         if (st) {
             const Batch& b = batch->batch;
             const RunTiming& t = batch->timing;
@@ -237,6 +246,7 @@ int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         if (!batch->ran) throw Error("mp_batch_results before mp_batch_run");
+        if (ctx->last_run != batch) throw Error("mp_batch_results: another batch has been created or run on this context since this one ran - run it again");
         HostResults hr;
         dev.download(hr);
         std::unique_ptr<mp_results> r(new mp_results());
@@ -253,7 +263,7 @@ int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
     });
 }
 
-void mp_batch_free(mp_batch* batch) { delete batch; }
+void mp_batch_free(mp_batch* batch) { delete batch; }   // (a context never dereferences its resident / last_run pointers)
 
 int mp_phase_dataset(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, mp_results** out) {
     mp_batch* b = nullptr;

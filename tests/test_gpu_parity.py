@@ -385,3 +385,21 @@ def test_gpu_result_buffers_grow_on_overflow(ctx, monkeypatch):
     res = b.results()
     assert st.attempts > 1
     assert (res.fasta, res.tsv) == (nref.fasta, nref.tsv)
+
+
+def test_gpu_batches_of_one_context_do_not_alias(ctx):
+    """A context holds one batch in HBM at a time. Running an older batch after a newer one was created re-uploads it;
+    asking for results that were overwritten is an error, not stale data."""
+    import microphaser_amd as m
+    ds = ctx.synth(88, 12)
+    b1 = ds.batch(gene_lo=0, gene_hi=6)
+    b2 = ds.batch(gene_lo=6, gene_hi=12)     # replaces b1 in HBM
+    b1.run()                                 # comes back
+    r1 = b1.results()
+    b2.run()
+    r2 = b2.results()
+    with pytest.raises(m.MicrophaserError):
+        b1.results()                         # b2 ran since
+    whole = ds.phase()
+    assert r1.fasta + r2.fasta == whole.fasta
+    assert r1.windows + r2.windows == whole.windows
