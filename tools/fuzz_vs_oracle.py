@@ -1,0 +1,99 @@
+"""Randomised differential test of the device path against the CPU oracle (test infrastructure, like tests/):
+random synthetic exomes (depth, variant spacing, indels, multi-allelic sites, soft-masked reference, window length, mode)
+are phased by the engine and by `oracle_cli synth` with the same generator parameters; FASTA / normal FASTA / TSV must be
+byte-identical, and genes on which the reference would panic must fail on the engine too. The oracle runs on the host
+cores in a pool while the GPU works through the cases.
+
+  python tools/fuzz_vs_oracle.py [first_seed] [n_cases] [time_budget_s]
+"""
+import json, os, random, subprocess, sys, tempfile, time
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import microphaser_amd as m
+from microphaser_amd.shard import merge_streams
+ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+rng = random.Random(first)
+tmp = tempfile.mkdtemp(prefix="mpfuzz")
+
+
+def make_case(k):
+    mode = rng.choice(["somatic", "somatic", "normal"])
+    depth = rng.choice([6, 15, 30, 30, 50, 90, 160]) if mode == "somatic" else rng.choice([6, 12, 20, 30])
+    spacing = rng.choice([1.35, 2.0, 3.5, 5.4, 5.4, 9.0, 25.0])
+    indel = rng.choice([0, 0, 0.03, 0.1])
+    multi = rng.choice([0, 0, 0.08])
+    soft = rng.choice([0, 0, 0.4])
+    wl = rng.choice([27, 27, 27, 33, 15, 21])
+    n = rng.choice([8, 16]) if depth < 100 else 5
+    return dict(seed=first + k, mode=mode, n=n, depth=depth, spacing=spacing, indel=indel, multi=multi, soft=soft, wl=wl)
+
+
+def run_oracle(c):
+    prefix = os.path.join(tmp, "o%d" % c["seed"])
+    cmd = [ORACLE_CLI, "synth", "--mode", c["mode"], "--seed", str(c["seed"]), "--transcripts", str(c["n"]), "--depth", str(c["depth"]),
+           "--spacing", str(c["spacing"]), "--indel-rate", str(c["indel"]), "--multiallelic-rate", str(c["multi"]),
+           "--softmask-rate", str(c["soft"]), "--window-len", str(c["wl"]), "--skip-panics", "--prefix", prefix]
+    r = subprocess.run(cmd, capture_output=True)
+    if r.returncode != 0:
+        return None, "oracle failed: " + r.stderr.decode()[-300:]
+    st = json.loads(r.stdout)
+    exts = ("fa", "normal.fa", "tsv") if c["mode"] == "somatic" else ("fa", "tsv")
+    out = {}
+    for e in exts:
+        with open(prefix + "." + e, "rb") as f: out[e] = f.read()
+        os.unlink(prefix + "." + e)
+    return st, out
+
+
+def run_engine(ctx, c, skipped):
+    mode = m.MODE_SOMATIC if c["mode"] == "somatic" else m.MODE_NORMAL
+    ds = ctx.synth(c["seed"], c["n"], float(c["depth"]), c["spacing"], indel_rate=c["indel"], multiallelic_rate=c["multi"], softmask_rate=c["soft"])
+    parts, windows, lo, notes = [], 0, 0, []
+    for g in skipped + [ds.num_genes]:
+        if g > lo:
+            b = ds.batch(window_len=c["wl"], gene_lo=lo, gene_hi=g, mode=mode); b.run(); r = b.results()
+            parts.append(dict(fasta=r.fasta, normal_fasta=r.normal_fasta, tsv=r.tsv)); windows += r.windows
+            b.close()
+        if g < ds.num_genes:
+            try:
+                b = ds.batch(window_len=c["wl"], gene_lo=g, gene_hi=g + 1, mode=mode); b.run(); b.results()
+                notes.append("gene %d: reference panics, engine did not fail" % g)
+            except m.MicrophaserError:
+                pass
+        lo = g + 1
+    ds.close()
+    return merge_streams(parts), windows, notes
+
+
+cases = [make_case(k) for k in range(count)]
+ctx = m.Context(0)
+bad = done = 0
+t0 = time.time()
+with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 2)) as pool:
+    futs = [pool.submit(run_oracle, c) for c in cases]
+    for c, f in zip(cases, futs):
+        if time.time() - t0 > budget:
+            for g in futs: g.cancel()
+            break
+        st, exp = f.result()
+        tag = " ".join("%s=%s" % kv for kv in c.items())
+        if st is None:
+            print("ORACLE-ERR", tag, exp, flush=True); bad += 1; continue
+        try:
+            got, windows, notes = run_engine(ctx, c, st["skipped"])
+        except m.MicrophaserError as e:
+            print("ENGINE-ERR", tag, str(e)[:200], flush=True); bad += 1; continue
+        diffs = list(notes)
+        if windows != st["windows"]: diffs.append("windows %d != %d" % (windows, st["windows"]))
+        for e, k in (("fa", "fasta"), ("normal.fa", "normal_fasta"), ("tsv", "tsv")):
+            if e in exp and got[k] != exp[e]: diffs.append(e + " differs")
+        done += 1
+        if diffs: bad += 1
+        print("DIFF" if diffs else "ok  ", tag, "windows=%d skipped=%d" % (windows, len(st["skipped"])), "; ".join(diffs), flush=True)
+print("cases: %d, mismatches: %d, %.0f s" % (done, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
