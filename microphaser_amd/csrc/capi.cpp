@@ -156,7 +156,10 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
     PhaseTimer phase_timer("batch_create");
     return guarded(ctx, [&] {
         if (mode != MP_MODE_SOMATIC && mode != MP_MODE_NORMAL) throw Error("unknown mode");
+        const auto t_genes = std::chrono::steady_clock::now();
         const std::vector<GeneInput>& genes = dataset_genes(const_cast<Dataset&>(ds->ds), mode == MP_MODE_NORMAL);
+        if (std::getenv("MP_DEBUG"))
+            std::fprintf(stderr, "[mp]   gene inputs %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_genes).count());
         if (gene_hi > genes.size()) gene_hi = uint32_t(genes.size());
         if (gene_lo > gene_hi) gene_lo = gene_hi;
         std::unique_ptr<mp_batch> b(new mp_batch());

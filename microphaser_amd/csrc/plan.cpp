@@ -2,6 +2,10 @@
 // reference: the data-independent part of phase_gene (src/microphasing.rs:905-942 loading,
 // :944-1342 scheduler) - see walk.hpp for the shared control flow.
 #include <algorithm>
+#include <atomic>
+#include <functional>
+#include <chrono>
+#include <cstdio>
 #include <deque>
 #include <map>
 #include <cstdlib>
@@ -157,6 +161,9 @@ struct PlannerHooksT {
             if (v.kind == VK_INS) max_len += v.len;
             if (v.kind == VK_DEL) max_len += v.len;
             if (v.kind != VK_SNV) non_snv = true;
+            // the inner loop of the walk has no window bound: a run of adjacent columns starting at the window's last base is
+            // applied past window_end, one more base each (stale columns of '-' exons and `normal` epochs sit there)
+            if (v.pos >= uint64_t(st.sso) + st.wlen) max_len += 1;
         }
         b.wins.back().need_recs = uint8_t(((NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0) | (walk_prefix << WS_PREFIX_SHIFT));  // `normal` emits every haplotype
         if (NORMAL) max_len += 1;  // the unconditional trailing base (src/normal_microphasing.rs:476)
@@ -627,44 +634,93 @@ size_t host_threads() {
 namespace {
 template <class T> void append(std::vector<T>& a, const std::vector<T>& b) { a.insert(a.end(), b.begin(), b.end()); }
 
-// Concatenate a sub-batch (genes planned by another thread) onto `b`, rebasing every absolute index.
-void merge_batch(Batch& b, Batch& s) {
-    const uint32_t gOff = uint32_t(b.genes.size()), rOff = uint32_t(b.r_pos.size()), vOff = uint32_t(b.v_pos.size());
-    const uint64_t refOff = b.ref_pool.size(), cigOff = b.cigar_pool.size(), seqOff = b.seq_pool.size(), qualOff = b.qual_pool.size();
-    const uint32_t insOff = uint32_t(b.ins_pool.size()), tOff = uint32_t(b.tx.size()), sOff = uint32_t(b.steps.size());
-    const uint32_t wOff = uint32_t(b.wins.size()), wcOff = uint32_t(b.win_cols.size()), eOff = uint32_t(b.exons.size());
-    const uint32_t strOff = uint32_t(b.str_pool.size());
-    if (refOff + s.ref_pool.size() > 0xFFFFFFF0ull) throw Error("reference bytes of one batch exceed 4 GiB: split the batch by genes");
-    if (uint64_t(sOff) + s.steps.size() > 0xFFFFFFF0ull || uint64_t(rOff) + s.r_pos.size() > 0xFFFFFFF0ull)
+// Concatenate the sub-batches (gene ranges planned by the worker threads) in gene order, rebasing every absolute index.
+// One task per array, run on the same number of threads: the copies are first-touch bound, so they are spread over the cores.
+struct PartOff { uint64_t g, r, v, ins, t, s, w, wc, e, str, ref, cig, seq, qual; };
+
+template <class T, class Fix> void cat(std::vector<T>& dst, std::vector<Batch>& parts, std::vector<T> Batch::*m, Fix fix, size_t drop_last = 0) {
+    size_t total = 0;
+    for (Batch& p : parts) total += (p.*m).size() - std::min(drop_last, (p.*m).size());
+    dst.clear();
+    dst.reserve(total + 1);
+    for (size_t t = 0; t < parts.size(); t++) {
+        std::vector<T>& src = parts[t].*m;
+        const size_t n = src.size() - std::min(drop_last, src.size());
+        for (size_t i = 0; i < n; i++) { dst.push_back(std::move(src[i])); fix(dst.back(), t); }
+        std::vector<T>().swap(src);
+    }
+}
+template <class T> void cat(std::vector<T>& dst, std::vector<Batch>& parts, std::vector<T> Batch::*m) {
+    size_t total = 0;
+    for (Batch& p : parts) total += (p.*m).size();
+    dst.clear();
+    dst.reserve(total + 1);
+    for (Batch& p : parts) { dst.insert(dst.end(), (p.*m).begin(), (p.*m).end()); std::vector<T>().swap(p.*m); }
+}
+
+void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
+    std::vector<PartOff> o(parts.size() + 1, PartOff{});
+    for (size_t t = 0; t < parts.size(); t++) {
+        const Batch& s = parts[t];
+        PartOff& n = o[t + 1];
+        const PartOff& c = o[t];
+        n.g = c.g + s.genes.size(); n.r = c.r + s.r_pos.size(); n.v = c.v + s.v_pos.size(); n.ins = c.ins + s.ins_pool.size();
+        n.t = c.t + s.tx.size(); n.s = c.s + s.steps.size(); n.w = c.w + s.wins.size(); n.wc = c.wc + s.win_cols.size();
+        n.e = c.e + s.exons.size(); n.str = c.str + s.str_pool.size(); n.ref = c.ref + s.ref_pool.size();
+        n.cig = c.cig + s.cigar_pool.size(); n.seq = c.seq + s.seq_pool.size(); n.qual = c.qual + s.qual_pool.size();
+        b.mask_words = std::max(b.mask_words, s.mask_words);
+        b.max_rows_bound = std::max(b.max_rows_bound, s.max_rows_bound);
+        b.seq_cap = std::max(b.seq_cap, s.seq_cap);
+        b.n_main_windows += s.n_main_windows;
+    }
+    const PartOff& tot = o.back();
+    if (tot.ref > 0xFFFFFFF0ull) throw Error("reference bytes of one batch exceed 4 GiB: split the batch by genes");
+    if (tot.s > 0xFFFFFFF0ull || tot.r > 0xFFFFFFF0ull || tot.w > 0xFFFFFFF0ull || tot.wc > 0xFFFFFFF0ull)
         throw Error("batch too large for 32-bit indices: split the batch by genes");
-    for (GeneHost& g : s.genes) { g.read_off += rOff; g.var_off += vOff; g.ref_off += refOff; g.tx_off += tOff; b.genes.push_back(std::move(g)); }
-    for (size_t i = 0; i + 1 < s.g_read_off.size(); i++) b.g_read_off.push_back(s.g_read_off[i] + rOff);
-    for (size_t i = 0; i + 1 < s.g_var_off.size(); i++) b.g_var_off.push_back(s.g_var_off[i] + vOff);
-    append(b.g_start, s.g_start);
-    for (uint64_t o : s.g_ref_off) b.g_ref_off.push_back(o + refOff);
-    append(b.r_pos, s.r_pos); append(b.r_end, s.r_end); append(b.r_lseq, s.r_lseq); append(b.r_ncig, s.r_ncig); append(b.r_dup, s.r_dup); append(b.r_varlo, s.r_varlo);
-    for (uint64_t o : s.r_cigoff) b.r_cigoff.push_back(o + cigOff);
-    for (uint64_t o : s.r_seqoff) b.r_seqoff.push_back(o + seqOff);
-    for (uint64_t o : s.r_qualoff) b.r_qualoff.push_back(o + qualOff);
-    append(b.cigar_pool, s.cigar_pool); append(b.seq_pool, s.seq_pool); append(b.qual_pool, s.qual_pool); append(b.r_src, s.r_src);
-    append(b.v_pos, s.v_pos); append(b.v_info, s.v_info); append(b.v_len, s.v_len); append(b.v_rev2fwd, s.v_rev2fwd);
-    for (uint32_t o : s.v_insoff) b.v_insoff.push_back(o + insOff);
-    append(b.ins_pool, s.ins_pool); append(b.ref_pool, s.ref_pool);
-    for (TxDev t : s.tx) { t.gene += gOff; t.step_off += sOff; t.id_off += strOff; b.tx.push_back(t); }
-    for (SegDev g : s.segs) { g.tx += tOff; g.step_off += sOff; b.segs.push_back(g); }
-    append(b.step_ncols, s.step_ncols); append(b.step_rlo, s.step_rlo); append(b.step_rn, s.step_rn);
-    b.seg_info.insert(b.seg_info.end(), s.seg_info.begin(), s.seg_info.end());
-    for (Step st : s.steps) { if (st.win != 0xFFFFFFFFu) st.win += wOff; st.exon += eOff; b.steps.push_back(st); }
-    b.step_aux.insert(b.step_aux.end(), s.step_aux.begin(), s.step_aux.end());
-    for (WinStatic w : s.wins) { w.tx += tOff; w.col_off += wcOff; w.ref_off += uint32_t(refOff); w.vbase += vOff; w.step += sOff; b.wins.push_back(w); }
-    append(b.win_cols, s.win_cols);
-    for (ExonPlan e : s.exons) { e.tx += tOff; b.exons.push_back(e); }
-    append(b.str_pool, s.str_pool);
-    b.mask_words = std::max(b.mask_words, s.mask_words);
-    b.max_rows_bound = std::max(b.max_rows_bound, s.max_rows_bound);
-    b.seq_cap = std::max(b.seq_cap, s.seq_cap);
-    b.n_main_windows += s.n_main_windows;
-    s = Batch();
+    using B = Batch;
+    std::vector<std::function<void()>> tasks;   // largest arrays first
+    tasks.push_back([&] { cat(b.qual_pool, parts, &B::qual_pool); });
+    tasks.push_back([&] { cat(b.steps, parts, &B::steps, [&](Step& st, size_t t) { if (st.win != 0xFFFFFFFFu) st.win += uint32_t(o[t].w); st.exon += uint32_t(o[t].e); }); });
+    tasks.push_back([&] { cat(b.seq_pool, parts, &B::seq_pool); });
+    tasks.push_back([&] { cat(b.wins, parts, &B::wins, [&](WinStatic& w, size_t t) {
+        w.tx += uint32_t(o[t].t); w.col_off += uint32_t(o[t].wc); w.ref_off += uint32_t(o[t].ref); w.vbase += uint32_t(o[t].v); w.step += uint32_t(o[t].s); }); });
+    tasks.push_back([&] { cat(b.win_cols, parts, &B::win_cols); });
+    tasks.push_back([&] { cat(b.ref_pool, parts, &B::ref_pool); });
+    tasks.push_back([&] { cat(b.r_src, parts, &B::r_src); });
+    tasks.push_back([&] { cat(b.r_cigoff, parts, &B::r_cigoff, [&](uint64_t& x, size_t t) { x += o[t].cig; }); });
+    tasks.push_back([&] { cat(b.r_seqoff, parts, &B::r_seqoff, [&](uint64_t& x, size_t t) { x += o[t].seq; }); });
+    tasks.push_back([&] { cat(b.r_qualoff, parts, &B::r_qualoff, [&](uint64_t& x, size_t t) { x += o[t].qual; }); });
+    tasks.push_back([&] { cat(b.step_rlo, parts, &B::step_rlo); });
+    tasks.push_back([&] { cat(b.cigar_pool, parts, &B::cigar_pool); });
+    tasks.push_back([&] { cat(b.r_pos, parts, &B::r_pos); });
+    tasks.push_back([&] { cat(b.r_end, parts, &B::r_end); });
+    tasks.push_back([&] { cat(b.r_lseq, parts, &B::r_lseq); });
+    tasks.push_back([&] { cat(b.r_ncig, parts, &B::r_ncig); });
+    tasks.push_back([&] { cat(b.r_dup, parts, &B::r_dup); });
+    tasks.push_back([&] { cat(b.r_varlo, parts, &B::r_varlo); });
+    tasks.push_back([&] { cat(b.step_rn, parts, &B::step_rn); });
+    tasks.push_back([&] { cat(b.step_aux, parts, &B::step_aux); });
+    tasks.push_back([&] { cat(b.step_ncols, parts, &B::step_ncols); });
+    tasks.push_back([&] { cat(b.v_pos, parts, &B::v_pos); cat(b.v_info, parts, &B::v_info); cat(b.v_len, parts, &B::v_len); cat(b.v_rev2fwd, parts, &B::v_rev2fwd);
+                          cat(b.v_insoff, parts, &B::v_insoff, [&](uint32_t& x, size_t t) { x += uint32_t(o[t].ins); }); cat(b.ins_pool, parts, &B::ins_pool); });
+    tasks.push_back([&] {
+        cat(b.genes, parts, &B::genes, [&](GeneHost& g, size_t t) { g.read_off += uint32_t(o[t].r); g.var_off += uint32_t(o[t].v); g.ref_off += o[t].ref; g.tx_off += uint32_t(o[t].t); });
+        cat(b.g_read_off, parts, &B::g_read_off, [&](uint32_t& x, size_t t) { x += uint32_t(o[t].r); }, 1);
+        cat(b.g_var_off, parts, &B::g_var_off, [&](uint32_t& x, size_t t) { x += uint32_t(o[t].v); }, 1);
+        cat(b.g_start, parts, &B::g_start);
+        cat(b.g_ref_off, parts, &B::g_ref_off, [&](uint64_t& x, size_t t) { x += o[t].ref; });
+        cat(b.tx, parts, &B::tx, [&](TxDev& x, size_t t) { x.gene += uint32_t(o[t].g); x.step_off += uint32_t(o[t].s); x.id_off += uint32_t(o[t].str); });
+        cat(b.segs, parts, &B::segs, [&](SegDev& x, size_t t) { x.tx += uint32_t(o[t].t); x.step_off += uint32_t(o[t].s); });
+        cat(b.seg_info, parts, &B::seg_info);
+        cat(b.exons, parts, &B::exons, [&](ExonPlan& e, size_t t) { e.tx += uint32_t(o[t].t); });
+        cat(b.str_pool, parts, &B::str_pool);
+    });
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < std::min(nthreads, tasks.size()); k++)
+        th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < tasks.size();) tasks[i](); });
+    for (auto& x : th) x.join();
+    parts.clear();
 }
 }  // namespace
 
@@ -681,6 +737,10 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
         cut[t] = std::min<size_t>(n_genes, size_t(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin()));
         if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     }
+    const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     std::vector<Batch> parts(nthreads);
     std::vector<std::string> errors(nthreads);
     std::vector<std::thread> th;
@@ -695,10 +755,13 @@ void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, ui
     b = Batch();
     b.window_len = window_len;
     b.normal = normal;
-    for (size_t t = 0; t < nthreads; t++) merge_batch(b, parts[t]);
+    const auto t1 = now();
+    merge_parts(b, parts, nthreads);
     b.g_read_off.push_back(uint32_t(b.r_pos.size()));
     b.g_var_off.push_back(uint32_t(b.v_pos.size()));
+    const auto t2 = now();
     finalize_segments(b);
+    if (dbg) std::fprintf(stderr, "[mp]   plan on %zu threads %.1f ms, merge %.1f ms, finalize %.1f ms\n", nthreads, ms(t0, t1), ms(t1, t2), ms(t2, now()));
 }
 
 uint64_t Batch::bytes_k1_in() const {

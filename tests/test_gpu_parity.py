@@ -194,6 +194,24 @@ def test_gpu_normal_mode_matches_oracle_on_synthetic_exome(ctx, tmp_path, seed, 
     assert exp["tsv"].count(b"\n") > 1000
 
 
+def test_gpu_normal_mode_columns_past_window_end_lengthen_the_sequence(ctx, tmp_path):
+    """Found by tools/fuzz_vs_oracle.py (seed 70098): with a variant every 1.35 nt and 3 % indels a '-' strand window keeps
+    stale columns past its end; an SNV at the window's last base starts a run of adjacent columns that the unbounded inner
+    loop of the walk (src/normal_microphasing.rs:417-475) applies past window_end, so the sequence (52 nt here) outgrows
+    window + inserted bases. The planner has to size the records for that run."""
+    import microphaser_amd as m
+    prefix = os.path.join(str(tmp_path), "on")
+    subprocess.run([ORACLE_CLI, "synth", "--mode", "normal", "--seed", "70098", "--transcripts", "16", "--depth", "20", "--spacing", "1.35",
+                    "--indel-rate", "0.03", "--genes", "9:10", "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    ds = ctx.synth(70098, 16, 20.0, 1.35, indel_rate=0.03)
+    b = ds.batch(gene_lo=9, gene_hi=10, mode=m.MODE_NORMAL)
+    b.run()
+    res = b.results()
+    assert res.fasta == open(prefix + ".fa", "rb").read()
+    assert res.tsv == open(prefix + ".tsv", "rb").read()
+    assert res.tsv.count(b"\n") > 100000
+
+
 # ------------------------------------------------------------------ the product CLI (src/cli.yaml surface): GTF on stdin, FASTA on stdout
 PRODUCT_CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microphaser_amd", "_lib", "microphaser")
 
