@@ -37,7 +37,7 @@ struct mp_batch {
     bool w_wins_known = false;
 };
 struct mp_results {
-    SomaticOutput out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty
+    PhasedStreams out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty
 };
 struct mp_filtered {
     FilterResult res;
@@ -251,17 +251,13 @@ int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
         if (!batch->ran) throw Error("mp_batch_results before mp_batch_run");
         if (ctx->last_run != batch) throw Error("mp_batch_results: another batch has been created or run on this context since this one ran - run it again");
         HostResults hr;
+        const auto t_dl = std::chrono::steady_clock::now();
         dev.download(hr);
+        if (std::getenv("MP_DEBUG"))
+            std::fprintf(stderr, "[mp]   download %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count());
         std::unique_ptr<mp_results> r(new mp_results());
-        if (batch->batch.normal) {
-            NormalOutput no;
-            consume_batch_normal(batch->batch, hr, no);
-            r->out.fasta = std::move(no.fasta);
-            r->out.tsv = std::move(no.tsv);
-            r->out.n_windows = no.n_windows;
-        } else {
-            consume_batch(batch->batch, hr, r->out);
-        }
+        if (batch->batch.normal) consume_batch_normal(batch->batch, hr, r->out);
+        else consume_batch(batch->batch, hr, r->out);
         *out = r.release();
     });
 }

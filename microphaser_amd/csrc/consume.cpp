@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <limits>
 #include <thread>
 #include <tuple>
@@ -679,17 +681,70 @@ void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1,
     }
 }
 
-void append_part(SomaticOutput& out, SomaticOutput& p) { out.normal_fasta += p.normal_fasta; }
-void append_part(NormalOutput&, NormalOutput&) {}
+const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
+const std::string* normal_stream(const NormalOutput&) { return nullptr; }
 
-// Genes are independent (no state crosses phase_gene calls), so the host walk is sharded over threads by gene range and
-// the per-range streams are concatenated in gene order; the TSV header is kept from the first range that wrote a record.
+struct CopyTask { char* dst; const char* src; size_t n; };
+
+// Concatenate the per-range streams in gene order; the TSV header is kept from the first range that wrote a record. The copies
+// (and the release of the pieces) run on all host threads.
+template <class Out>
+void assemble(std::vector<Out>& parts, PhasedStreams& out, size_t nthreads) {
+    std::vector<CopyTask> tasks;
+    constexpr size_t CHUNK = size_t(8) << 20;
+    auto plan = [&](Bytes& dst, const std::vector<std::pair<const char*, size_t>>& pieces) {
+        size_t total = 0;
+        for (const auto& pc : pieces) total += pc.second;
+        dst.n = total;
+        dst.p.reset(total ? new char[total] : nullptr);
+        size_t at = 0;
+        for (const auto& pc : pieces) {
+            for (size_t o = 0; o < pc.second; o += CHUNK) tasks.push_back({dst.p.get() + at + o, pc.first + o, std::min(CHUNK, pc.second - o)});
+            at += pc.second;
+        }
+    };
+    std::vector<std::pair<const char*, size_t>> fa, nfa, tsv;
+    bool header = false;
+    for (Out& p : parts) {
+        out.n_windows += p.n_windows;
+        fa.push_back({p.fasta.data(), p.fasta.size()});
+        if (const std::string* n = normal_stream(p)) nfa.push_back({n->data(), n->size()});
+        if (!p.tsv.empty()) {
+            const size_t skip = header ? p.tsv.find('\n') + 1 : 0;
+            tsv.push_back({p.tsv.data() + skip, p.tsv.size() - skip});
+            header = true;
+        }
+    }
+    plan(out.fasta, fa);
+    plan(out.normal_fasta, nfa);
+    plan(out.tsv, tsv);
+    std::atomic<size_t> next{0}, next_free{0};
+    auto work = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < tasks.size();) std::memcpy(tasks[i].dst, tasks[i].src, tasks[i].n);
+    };
+    std::vector<std::thread> th;
+    const size_t nt = std::max<size_t>(1, std::min(nthreads, tasks.size()));
+    for (size_t k = 1; k < nt; k++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    th.clear();
+    auto release = [&] { for (size_t i; (i = next_free.fetch_add(1)) < parts.size();) parts[i] = Out(); };
+    for (size_t k = 1; k < std::min(nthreads, parts.size()); k++) th.emplace_back(release);
+    release();
+    for (auto& x : th) x.join();
+}
+
 template <class Hooks, class Out>
-void consume_sharded(const Batch& b, const HostResults& res, Out& out) {
+void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out) {
     size_t nthreads = host_threads();
     const size_t ng = b.genes.size();
     if (nthreads > ng) nthreads = ng ? ng : 1;
-    if (nthreads <= 1) { consume_range<Hooks>(b, res, 0, ng, out); return; }
+    if (nthreads <= 1) {
+        std::vector<Out> one(1);
+        consume_range<Hooks>(b, res, 0, ng, one[0]);
+        assemble(one, out, 1);
+        return;
+    }
     // balance by planned steps
     std::vector<uint64_t> cost(ng + 1, 0);
     for (size_t g = 0; g < ng; g++) {
@@ -705,6 +760,7 @@ void consume_sharded(const Batch& b, const HostResults& res, Out& out) {
         if (cut[t] > ng) cut[t] = ng;
         if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     }
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<Out> parts(nthreads);
     std::vector<std::string> errors(nthreads);
     std::vector<std::thread> th;
@@ -716,29 +772,23 @@ void consume_sharded(const Batch& b, const HostResults& res, Out& out) {
     for (auto& x : th) x.join();
     for (size_t t = 0; t < nthreads; t++)
         if (!errors[t].empty()) throw Error(errors[t]);  // the first failing gene range in gene order, like a sequential run
-    for (size_t t = 0; t < nthreads; t++) {
-        Out& p = parts[t];
-        out.fasta += p.fasta;
-        append_part(out, p);
-        out.n_windows += p.n_windows;
-        if (!p.tsv.empty()) {
-            if (!out.tsv_header_written) { out.tsv += p.tsv; out.tsv_header_written = true; }
-            else out.tsv.append(p.tsv, p.tsv.find('\n') + 1, std::string::npos);
-        }
-        p = Out();
-    }
+    const auto t1 = std::chrono::steady_clock::now();
+    assemble(parts, out, nthreads);
+    if (std::getenv("MP_DEBUG"))
+        std::fprintf(stderr, "[mp]   consume on %zu threads %.1f ms, concatenate %.1f ms\n", nthreads, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 
 }  // namespace
 
-void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out) {
+void consume_batch(const Batch& b, const HostResults& res, PhasedStreams& out) {
     if (b.normal) throw Error("internal error: somatic consumer on a normal-mode batch");
-    consume_sharded<ConsumerHooks>(b, res, out);
+    consume_sharded<ConsumerHooks, SomaticOutput>(b, res, out);
 }
 
-void consume_batch_normal(const Batch& b, const HostResults& res, NormalOutput& out) {
+void consume_batch_normal(const Batch& b, const HostResults& res, PhasedStreams& out) {
     if (!b.normal) throw Error("internal error: normal consumer on a somatic-mode batch");
-    consume_sharded<NormalConsumerHooks>(b, res, out);
+    consume_sharded<NormalConsumerHooks, NormalOutput>(b, res, out);
 }
 
 }  // namespace mp

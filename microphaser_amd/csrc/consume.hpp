@@ -8,10 +8,10 @@ namespace mp {
 // Walk every planned transcript of the batch and emit FASTA / normal FASTA / TSV exactly as
 // microphasing::phase_gene would (reference: src/microphasing.rs:882-1941), answering every
 // print_haplotypes call from the device results.
-void consume_batch(const Batch& b, const HostResults& res, SomaticOutput& out);
+void consume_batch(const Batch& b, const HostResults& res, PhasedStreams& out);
 
 // The same for `microphaser normal` (reference: src/normal_microphasing.rs:650-1279); the batch must have been planned
 // with normal = true.
-void consume_batch_normal(const Batch& b, const HostResults& res, NormalOutput& out);
+void consume_batch_normal(const Batch& b, const HostResults& res, PhasedStreams& out);
 
 }  // namespace mp

@@ -6,6 +6,7 @@
 // and rust-bio. Reads are kept in pooled struct-of-arrays form (ReadStore) so the
 // very same pools can be uploaded to HBM unchanged.
 #pragma once
+#include <memory>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -201,6 +202,19 @@ struct NormalRecord {
 struct NormalOutput {
     std::string fasta, tsv;
     bool tsv_header_written = false;
+    uint64_t n_windows = 0;
+};
+
+// A finished output stream: one uninitialised allocation, so that the pieces written by the consumer threads are copied into it
+// (and its pages first touched) by all host threads at once - at config C the three streams are 3.5 GB of text.
+struct Bytes {
+    std::unique_ptr<char[]> p;
+    size_t n = 0;
+    const char* data() const { return p ? p.get() : ""; }
+    size_t size() const { return n; }
+};
+struct PhasedStreams {   // what mp_results holds: somatic -> three streams, normal -> fasta + tsv
+    Bytes fasta, normal_fasta, tsv;
     uint64_t n_windows = 0;
 };
 
