@@ -2,7 +2,9 @@
 
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 #include <algorithm>
@@ -17,7 +19,7 @@ namespace mp {
 namespace {
 
 struct FileBytes {
-    std::vector<uint8_t> data;
+    PodVec<uint8_t> data;   // not zero-filled before the read
     explicit FileBytes(const std::string& path) {
         FILE* f = std::fopen(path.c_str(), "rb");
         if (!f) throw Error("cannot open " + path);
@@ -36,7 +38,7 @@ struct FileBytes {
 // Streaming BGZF inflater: yields the concatenated uncompressed stream block by block.
 class BgzfReader {
   public:
-    explicit BgzfReader(const std::vector<uint8_t>& file) : f_(file) {}
+    explicit BgzfReader(const PodVec<uint8_t>& file) : f_(file) {}
     // Append the next block's payload to `out`; false at EOF.
     bool next_block(std::vector<uint8_t>& out) {
         if (off_ >= f_.size()) return false;
@@ -75,14 +77,14 @@ class BgzfReader {
     }
 
   private:
-    const std::vector<uint8_t>& f_;
+    const PodVec<uint8_t>& f_;
     size_t off_ = 0;
 };
 
 // Whole-file BGZF inflate on all host threads: BGZF blocks are independent deflate streams whose compressed and
 // uncompressed sizes are in the block itself, so one scan lays out the output and the blocks inflate in parallel
 // (the end-to-end path is ingest-bound once the kernels exist).
-std::vector<uint8_t> bgzf_inflate_all(const std::vector<uint8_t>& f) {
+PodVec<uint8_t> bgzf_inflate_all(const PodVec<uint8_t>& f) {
     struct Blk { size_t in_off; uint32_t clen, isize; size_t out_off; };
     std::vector<Blk> blks;
     size_t off = 0, total = 0;
@@ -106,7 +108,8 @@ std::vector<uint8_t> bgzf_inflate_all(const std::vector<uint8_t>& f) {
         off += bsize;
     }
     auto tA = std::chrono::steady_clock::now();
-    std::vector<uint8_t> out(total);
+    PodVec<uint8_t> out;
+    out.resize(total);   // not touched here: the inflating threads first-touch their own blocks
     auto tB = std::chrono::steady_clock::now();
     size_t nthreads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 16));
     if (const char* e = std::getenv("MP_THREADS")) nthreads = std::max<size_t>(1, size_t(std::atoi(e)));
@@ -146,12 +149,36 @@ inline uint16_t rd16(const uint8_t* p) { return uint16_t(p[0] | (p[1] << 8)); }
 
 }  // namespace
 
+namespace {
+size_t io_threads(size_t cap) {
+    size_t n = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), cap));
+    if (const char* e = std::getenv("MP_THREADS")) n = std::max<size_t>(1, size_t(std::atoi(e)));
+    return n;
+}
+template <class F> void run_threads(size_t n, F f) {
+    std::vector<std::string> errors(n);
+    std::vector<std::thread> th;
+    auto guarded = [&](size_t t) { try { f(t); } catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; } };
+    for (size_t t = 1; t < n; t++) th.emplace_back(guarded, t);
+    guarded(0);
+    for (auto& x : th) x.join();
+    for (const std::string& e : errors) if (!e.empty()) throw Error(e);
+}
+}  // namespace
+
+// BAM records -> ReadStore. One sequential hop over the record sizes finds the placed records; their fields and the cigar / base /
+// quality / name pools are then sized once and filled by all host threads (record ranges), in file order.
 void load_bam(const std::string& path, BamData& out) {
-    std::vector<uint8_t> buf;
+    const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    auto clk = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk();
+    PodVec<uint8_t> buf;
     {
         FileBytes fb(path);
         buf = bgzf_inflate_all(fb.data);
     }
+    const auto t1 = clk();
     size_t cur = 0;
     auto need = [&](size_t n) -> bool { return buf.size() - cur >= n; };
     if (!need(12)) throw Error("empty BAM " + path);
@@ -175,30 +202,80 @@ void load_bam(const std::string& path, BamData& out) {
         cur += 4;
     }
     out.reads = ReadStore();
-    std::vector<uint32_t> cig;
+    ReadStore& rs = out.reads;
+    std::vector<uint64_t> rec_at;   // buffer offset of every placed record (ref_id >= 0), file order
     while (need(4)) {
-        uint32_t bs = rd32(buf.data() + cur);
+        const uint32_t bs = rd32(buf.data() + cur);
         if (!need(4 + size_t(bs))) throw Error("truncated BAM record");
-        const uint8_t* r = buf.data() + cur + 4;
-        int32_t ref_id = int32_t(rd32(r));
-        int32_t pos = int32_t(rd32(r + 4));
-        uint8_t l_read_name = r[8];
-        uint8_t mapq = r[9];
-        uint16_t n_cig = rd16(r + 12);
-        uint16_t flag = rd16(r + 14);
-        uint32_t l_seq = rd32(r + 16);
-        const uint8_t* p = r + 32;
-        const char* name = reinterpret_cast<const char*>(p);
-        p += l_read_name;
-        cig.resize(n_cig);
-        for (uint32_t k = 0; k < n_cig; k++) cig[k] = rd32(p + 4 * k);
-        p += 4 * size_t(n_cig);
-        const uint8_t* seq4 = p;
-        p += (l_seq + 1) / 2;
-        const uint8_t* qual = p;
-        if (ref_id >= 0) out.reads.add(ref_id, pos, mapq, flag, cig.data(), n_cig, seq4, l_seq, qual, name);
+        if (bs < 32) throw Error("malformed BAM record");
+        if (int32_t(rd32(buf.data() + cur + 4)) >= 0) rec_at.push_back(cur + 4);
         cur += 4 + size_t(bs);
     }
+    const auto t2 = clk();
+    const size_t n = rec_at.size();
+    const size_t nt = std::max<size_t>(1, std::min(io_threads(32), n / 4096));
+    struct Sum { uint64_t cig = 0, seq = 0, qual = 0, name = 0; };
+    std::vector<Sum> base(nt + 1);
+    auto range = [&](size_t t) { return std::make_pair(n * t / nt, n * (t + 1) / nt); };
+    auto fields = [&](size_t i, uint32_t& l_name, uint32_t& n_cig, uint32_t& l_seq, size_t& name_len) {
+        const uint8_t* r = buf.data() + rec_at[i];
+        const uint32_t bs = rd32(r - 4);
+        l_name = r[8]; n_cig = rd16(r + 12); l_seq = rd32(r + 16);
+        if (32 + uint64_t(l_name) + 4ull * n_cig + (uint64_t(l_seq) + 1) / 2 + l_seq > bs) throw Error("malformed BAM record");
+        name_len = ::strnlen(reinterpret_cast<const char*>(r + 32), l_name);   // ReadStore keeps the name up to its first NUL
+    };
+    run_threads(nt, [&](size_t t) {
+        Sum s;
+        for (size_t i = range(t).first; i < range(t).second; i++) {
+            uint32_t l_name, n_cig, l_seq; size_t nl;
+            fields(i, l_name, n_cig, l_seq, nl);
+            s.cig += n_cig; s.seq += (l_seq + 1) / 2; s.qual += l_seq; s.name += nl + 1;
+        }
+        base[t + 1] = s;
+    });
+    for (size_t t = 0; t < nt; t++) { base[t + 1].cig += base[t].cig; base[t + 1].seq += base[t].seq; base[t + 1].qual += base[t].qual; base[t + 1].name += base[t].name; }
+    rs.tid.resize(n); rs.pos.resize(n); rs.end_pos.resize(n); rs.mapq.resize(n); rs.flag.resize(n); rs.l_seq.resize(n); rs.n_cigar.resize(n);
+    rs.cigar_off.resize(n); rs.seq_off.resize(n); rs.qual_off.resize(n); rs.qname_off.resize(n);
+    rs.cigar_pool.resize(base[nt].cig); rs.seq_pool.resize(base[nt].seq); rs.qual_pool.resize(base[nt].qual); rs.qname_pool.resize(base[nt].name);
+    run_threads(nt, [&](size_t t) {
+        Sum at = base[t];
+        for (size_t i = range(t).first; i < range(t).second; i++) {
+            uint32_t l_name, n_cig, l_seq; size_t nl;
+            fields(i, l_name, n_cig, l_seq, nl);
+            const uint8_t* r = buf.data() + rec_at[i];
+            const uint8_t* p = r + 32;
+            rs.tid[i] = int32_t(rd32(r));
+            const int64_t pos = int32_t(rd32(r + 4));
+            rs.pos[i] = pos;
+            rs.mapq[i] = r[9];
+            rs.flag[i] = rd16(r + 14);
+            rs.l_seq[i] = l_seq;
+            rs.n_cigar[i] = n_cig;
+            rs.qname_off[i] = at.name;
+            std::memcpy(rs.qname_pool.data() + at.name, p, nl);
+            rs.qname_pool[at.name + nl] = 0;
+            at.name += nl + 1;
+            p += l_name;
+            rs.cigar_off[i] = at.cig;
+            int64_t e = pos;
+            for (uint32_t k = 0; k < n_cig; k++) {
+                const uint32_t c = rd32(p + 4 * k), op = c & 0xF, l = c >> 4;
+                rs.cigar_pool[at.cig + k] = c;
+                if (op == C_M || op == C_EQ || op == C_X || op == C_D || op == C_N) e += l;
+            }
+            rs.end_pos[i] = e;
+            at.cig += n_cig;
+            p += 4 * size_t(n_cig);
+            rs.seq_off[i] = at.seq;
+            std::memcpy(rs.seq_pool.data() + at.seq, p, (l_seq + 1) / 2);
+            at.seq += (l_seq + 1) / 2;
+            p += (l_seq + 1) / 2;
+            rs.qual_off[i] = at.qual;
+            std::memcpy(rs.qual_pool.data() + at.qual, p, l_seq);
+            at.qual += l_seq;
+        }
+    });
+    if (dbg) std::fprintf(stderr, "[mp] bam: read + inflate %.0f ms, record scan %.0f ms, parse on %zu threads %.0f ms\n", ms(t0, t1), ms(t1, t2), nt, ms(t2, clk()));
     // tid_begin (file is coordinate sorted: tids ascending)
     out.tid_begin.assign(n_ref + 1, out.reads.size());
     {
@@ -374,45 +451,77 @@ std::vector<std::string> split(const std::string& s, char d) {
 }
 }  // namespace
 
+// The text is cut at line ends into one piece per host thread; the pieces are parsed concurrently and joined in file order.
 void load_vcf(const std::string& path, VcfData& out) {
-    std::ifstream in(path);
-    if (!in) throw Error("cannot open " + path);
-    std::string line;
+    FileBytes fb(path);
+    const PodVec<uint8_t>& buf = fb.data;
     out.contigs.clear();
     out.records.clear();
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '#') {
-            if (line.rfind("##contig=<", 0) == 0) {
-                size_t a = line.find("ID=");
-                if (a != std::string::npos) {
-                    size_t b = line.find_first_of(",>", a);
-                    out.contigs.push_back(line.substr(a + 3, b - a - 3));
+    const size_t nt = std::max<size_t>(1, std::min(io_threads(32), buf.size() >> 20));
+    std::vector<size_t> cut(nt + 1, buf.size());
+    cut[0] = 0;
+    for (size_t t = 1; t < nt; t++) {
+        size_t at = std::max(cut[t - 1], buf.size() * t / nt);
+        while (at < buf.size() && buf[at] != '\n') at++;
+        cut[t] = std::min(buf.size(), at + 1);
+    }
+    struct Piece {
+        std::vector<VcfRecord> records;
+        std::vector<std::pair<std::string, bool>> contigs;   // in order: every ##contig ID (true) and the first record of each contig (false)
+    };
+    std::vector<Piece> pieces(nt);
+    run_threads(nt, [&](size_t t) {
+        Piece& pc = pieces[t];
+        std::string line;
+        for (size_t at = cut[t]; at < cut[t + 1];) {
+            const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(buf.data() + at, '\n', cut[t + 1] - at));
+            const size_t end = nl ? size_t(nl - buf.data()) : cut[t + 1];
+            line.assign(reinterpret_cast<const char*>(buf.data() + at), end - at);
+            at = end + 1;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty()) continue;
+            if (line[0] == '#') {
+                if (line.rfind("##contig=<", 0) == 0) {
+                    size_t a = line.find("ID=");
+                    if (a != std::string::npos) {
+                        size_t b = line.find_first_of(",>", a);
+                        pc.contigs.emplace_back(line.substr(a + 3, b - a - 3), true);
+                    }
+                }
+                continue;
+            }
+            auto f = split(line, '\t');
+            if (f.size() < 8) throw Error("malformed VCF line: " + line);
+            VcfRecord r;
+            r.chrom = f[0];
+            r.pos = std::strtoull(f[1].c_str(), nullptr, 10) - 1;
+            r.ref = f[3];
+            r.alts = split(f[4], ',');
+            for (const auto& kv : split(f[7], ';')) {
+                if (kv == "SOMATIC") r.somatic = true;
+                else if (kv.rfind("ANN=", 0) == 0) {
+                    std::string v = kv.substr(4);
+                    size_t c = v.find(',');
+                    r.ann_first = c == std::string::npos ? v : v.substr(0, c);
+                } else if (kv.rfind("SVLEN=", 0) == 0) {
+                    r.has_svlen = true;
+                    for (const auto& x : split(kv.substr(6), ',')) r.svlen.push_back(x == "." ? INT64_MIN : std::atoll(x.c_str()));
                 }
             }
-            continue;
+            bool seen = false;
+            for (const auto& c : pc.contigs) seen |= !c.second && c.first == r.chrom;
+            if (!seen) pc.contigs.emplace_back(r.chrom, false);
+            pc.records.push_back(std::move(r));
         }
-        auto f = split(line, '\t');
-        if (f.size() < 8) throw Error("malformed VCF line: " + line);
-        VcfRecord r;
-        r.chrom = f[0];
-        r.pos = std::strtoull(f[1].c_str(), nullptr, 10) - 1;
-        r.ref = f[3];
-        r.alts = split(f[4], ',');
-        for (const auto& kv : split(f[7], ';')) {
-            if (kv == "SOMATIC") r.somatic = true;
-            else if (kv.rfind("ANN=", 0) == 0) {
-                std::string v = kv.substr(4);
-                size_t c = v.find(',');
-                r.ann_first = c == std::string::npos ? v : v.substr(0, c);
-            } else if (kv.rfind("SVLEN=", 0) == 0) {
-                r.has_svlen = true;
-                for (const auto& x : split(kv.substr(6), ',')) r.svlen.push_back(x == "." ? INT64_MIN : std::atoll(x.c_str()));
-            }
-        }
-        if (std::find(out.contigs.begin(), out.contigs.end(), r.chrom) == out.contigs.end()) out.contigs.push_back(r.chrom);
-        out.records.push_back(std::move(r));
+    });
+    size_t total = 0;
+    for (const Piece& pc : pieces) total += pc.records.size();
+    out.records.reserve(total);
+    for (Piece& pc : pieces) {
+        for (auto& c : pc.contigs)   // a contig named only by records is listed when first seen
+            if (c.second || std::find(out.contigs.begin(), out.contigs.end(), c.first) == out.contigs.end()) out.contigs.push_back(c.first);
+        for (VcfRecord& r : pc.records) out.records.push_back(std::move(r));
+        std::vector<VcfRecord>().swap(pc.records);
     }
 }
 
@@ -427,9 +536,11 @@ void VcfData::build_index() const {
     indexed = true;
 }
 
+static thread_local std::string* g_warning_sink = nullptr;   // set while genes are loaded on worker threads: warnings are printed in gene order afterwards
 static void warn_or_error(const std::string& msg, bool warning_only) {  // common.rs:62-69
-    if (warning_only) std::fprintf(stderr, "%s\n", msg.c_str());
-    else throw Error(msg);
+    if (!warning_only) throw Error(msg);
+    if (g_warning_sink) { *g_warning_sink += msg; g_warning_sink->push_back('\n'); }
+    else std::fprintf(stderr, "%s\n", msg.c_str());
 }
 
 void variants_from_record(const VcfRecord& rec, bool warning_only, std::vector<Variant>& out) {
@@ -541,9 +652,10 @@ void MemFasta::fetch(const std::string& chrom, uint64_t start, uint64_t stop, st
 }
 
 void IndexedFasta::ensure_loaded() const {
-    if (!file_.empty()) return;
-    FileBytes fb(path_);
-    file_.swap(fb.data);
+    std::call_once(once_, [&] {
+        FileBytes fb(path_);
+        file_.swap(fb.data);
+    });
 }
 
 void IndexedFasta::fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const {
@@ -693,19 +805,65 @@ void stream_gtf(std::istream& in, const std::function<void(const Gene&)>& on_gen
     if (have_gene) on_gene(gene);
 }
 
+// Pass 1 (sequential, cheap): the GTF stream and the stateful read buffer (its contents depend on the previous gene's fetch).
+// Pass 2 (all host threads): reference bases and variants of every gene, which are independent. Errors surface as in a gene-by-gene
+// run: the first failing gene in GTF order, refseq before reads before variants (:895-942); warnings are printed in gene order.
 void load_gene_inputs(std::istream& gtf, const BamData& bam, const VcfData& vcf, const RefSource& fasta,
                       bool warning_only, const std::function<void(GeneInput&)>& on_gene, bool use_three_prime_utr) {
+    const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     ReadBuffer rb(bam);
-    stream_gtf(gtf, [&](const Gene& g) {
-        if (g.biotype != "protein_coding") return;  // microphasing.rs:1964
-        GeneInput gi;
-        gi.gene = g;
-        fasta.fetch(g.chrom, g.start(), g.end() + 100, gi.refseq);  // :895-901
-        rb.fetch(g.chrom, g.start(), g.end());                      // :905
-        gi.reads.assign(rb.records().begin(), rb.records().end());
-        gene_variants(vcf, g.chrom, g.start(), g.end(), warning_only, gi.variants);  // :932-942
-        on_gene(gi);
-    }, use_three_prime_utr);
+    std::vector<GeneInput> genes;
+    struct GeneErr { std::string fasta, reads, variants, warnings; };
+    std::vector<GeneErr> errs;
+    std::string gtf_err;
+    try {
+        stream_gtf(gtf, [&](const Gene& g) {
+            if (g.biotype != "protein_coding") return;  // microphasing.rs:1964
+            genes.emplace_back();
+            errs.emplace_back();
+            GeneInput& gi = genes.back();
+            gi.gene = g;
+            try {
+                rb.fetch(g.chrom, g.start(), g.end());                      // :905
+                gi.reads.assign(rb.records().begin(), rb.records().end());
+            } catch (const std::exception& e) { errs.back().reads = e.what(); }
+        }, use_three_prime_utr);
+    } catch (const std::exception& e) { gtf_err = e.what(); if (gtf_err.empty()) gtf_err = "error"; }
+    const auto t1 = std::chrono::steady_clock::now();
+    vcf.build_index();
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t g; (g = next.fetch_add(1)) < genes.size();) {
+            GeneInput& gi = genes[g];
+            try { fasta.fetch(gi.gene.chrom, gi.gene.start(), gi.gene.end() + 100, gi.refseq); }  // :895-901
+            catch (const std::exception& e) { errs[g].fasta = e.what(); continue; }
+            if (!errs[g].reads.empty()) continue;
+            g_warning_sink = &errs[g].warnings;
+            try { gene_variants(vcf, gi.gene.chrom, gi.gene.start(), gi.gene.end(), warning_only, gi.variants); }  // :932-942
+            catch (const std::exception& e) { errs[g].variants = e.what(); }
+            g_warning_sink = nullptr;
+        }
+    };
+    size_t hw = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 32));
+    if (const char* e = std::getenv("MP_THREADS")) hw = std::max<size_t>(1, size_t(std::atoi(e)));
+    const size_t nt = std::max<size_t>(1, std::min(hw, genes.size() / 16));
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < nt; k++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    if (dbg) std::fprintf(stderr, "[mp]   gene inputs: GTF + read buffer %.0f ms, refseq + variants on %zu threads %.0f ms\n",
+                          std::chrono::duration<double, std::milli>(t1 - t0).count(), nt,
+                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    for (size_t g = 0; g < genes.size(); g++) {
+        const GeneErr& e = errs[g];
+        if (!e.fasta.empty()) throw Error(e.fasta);
+        if (!e.reads.empty()) throw Error(e.reads);
+        if (!e.warnings.empty()) std::fputs(e.warnings.c_str(), stderr);
+        if (!e.variants.empty()) throw Error(e.variants);
+        on_gene(genes[g]);
+    }
+    if (!gtf_err.empty()) throw Error(gtf_err);
 }
 
 }  // namespace mp

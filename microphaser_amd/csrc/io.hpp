@@ -5,6 +5,7 @@
 #pragma once
 #include <deque>
 #include <functional>
+#include <mutex>
 #include <istream>
 #include <map>
 #include <string>
@@ -113,7 +114,8 @@ class IndexedFasta : public RefSource {
     struct Entry { uint64_t len, offset, line_bases, line_bytes, region_start, region_len; };
     std::map<std::string, Entry> idx_;
     std::string path_;
-    mutable std::vector<uint8_t> file_;  // whole file (lazily loaded)
+    mutable PodVec<uint8_t> file_;  // whole file (lazily loaded)
+    mutable std::once_flag once_;
     void ensure_loaded() const;
 };
 

@@ -71,22 +71,33 @@ enum CigarOp : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, 
 
 // Pooled struct-of-arrays read storage. cigar words are BAM-encoded (len<<4|op),
 // seq is BAM 4-bit packed (two bases per byte, high nibble first), qual is raw phred.
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the big host arrays are sized once and then
+// filled (and their pages first touched) by all host threads, instead of being zero-filled by one.
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using PodVec = std::vector<T, DefaultInitAlloc<T>>;
+
 struct ReadStore {
-    std::vector<int32_t> tid;
-    std::vector<int64_t> pos;
-    std::vector<int64_t> end_pos;  // pos + sum(M,=,X,D,N)   (rust-htslib CigarStringView::end_pos)
-    std::vector<uint8_t> mapq;
-    std::vector<uint16_t> flag;
-    std::vector<uint32_t> l_seq;
-    std::vector<uint32_t> n_cigar;
-    std::vector<uint64_t> cigar_off;  // index into cigar_pool
-    std::vector<uint64_t> seq_off;    // byte index into seq_pool
-    std::vector<uint64_t> qual_off;   // byte index into qual_pool
-    std::vector<uint64_t> qname_off;  // byte index into qname_pool (NUL terminated)
-    std::vector<uint32_t> cigar_pool;
-    std::vector<uint8_t> seq_pool;
-    std::vector<uint8_t> qual_pool;
-    std::vector<char> qname_pool;
+    PodVec<int32_t> tid;
+    PodVec<int64_t> pos;
+    PodVec<int64_t> end_pos;  // pos + sum(M,=,X,D,N)   (rust-htslib CigarStringView::end_pos)
+    PodVec<uint8_t> mapq;
+    PodVec<uint16_t> flag;
+    PodVec<uint32_t> l_seq;
+    PodVec<uint32_t> n_cigar;
+    PodVec<uint64_t> cigar_off;  // index into cigar_pool
+    PodVec<uint64_t> seq_off;    // byte index into seq_pool
+    PodVec<uint64_t> qual_off;   // byte index into qual_pool
+    PodVec<uint64_t> qname_off;  // byte index into qname_pool (NUL terminated)
+    PodVec<uint32_t> cigar_pool;
+    PodVec<uint8_t> seq_pool;
+    PodVec<uint8_t> qual_pool;
+    PodVec<char> qname_pool;
 
     size_t size() const { return pos.size(); }
     const char* qname(size_t i) const { return &qname_pool[qname_off[i]]; }

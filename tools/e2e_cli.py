@@ -7,10 +7,11 @@ import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import microphaser_amd as m
-cfg = {"B": (1001, 1000, 30.0, 5.4), "C": (2020, 20000, 30.0, 5.4)}[sys.argv[1] if len(sys.argv) > 1 else "B"]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else cfg[1]
-out = os.path.join(ROOT, "gpurun_out", "e2e")
-os.makedirs(out, exist_ok=True)
+cfg = {"B": (1001, 1000, 30.0, 5.4), "C": (2020, 20000, 30.0, 5.4)}[sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "B"]
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(pos[1]) if len(pos) > 1 else cfg[1]
+import tempfile
+out = tempfile.mkdtemp(prefix="mp_e2e_")   # GB-sized files: not under gpurun_out/ (64 MiB copy-back limit)
 prefix = os.path.join(out, "synth")
 ctx = m.Context(-1)
 t = time.perf_counter(); ds = ctx.synth(cfg[0], n, cfg[2], cfg[3]); t_gen = time.perf_counter() - t
@@ -21,6 +22,7 @@ def run(cmd, stdout_path):
     t = time.perf_counter()
     with open(files["gtf"], "rb") as g, open(stdout_path, "wb") as o:
         r = subprocess.run(cmd, stdin=g, stdout=o, stderr=subprocess.PIPE)
+    if os.environ.get("MP_DEBUG"): sys.stderr.write(r.stderr.decode())
     dt = time.perf_counter() - t
     if r.returncode != 0: raise SystemExit(r.stderr.decode()[-2000:])
     return dt
