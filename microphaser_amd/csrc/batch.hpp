@@ -34,44 +34,44 @@ struct Batch {
     bool normal = false;                  // `microphaser normal` semantics (src/normal_microphasing.rs) instead of `somatic`
     // ---- genes
     std::vector<GeneHost> genes;
-    std::vector<uint32_t> g_read_off, g_var_off, g_start;  // per gene (+1 for the offsets)
-    std::vector<uint64_t> g_ref_off;
+    PodVec<uint32_t> g_read_off, g_var_off, g_start;  // per gene (+1 for the offsets)
+    PodVec<uint64_t> g_ref_off;
     // ---- reads (gene-major, start-sorted, mapq-filtered)
-    std::vector<uint32_t> r_pos, r_end, r_lseq, r_ncig, r_dup, r_varlo;
-    std::vector<uint64_t> r_cigoff, r_seqoff, r_qualoff;
-    std::vector<uint32_t> cigar_pool;
-    std::vector<uint8_t> seq_pool, qual_pool;
-    std::vector<size_t> r_src;            // host-only: ReadStore index of each batch read
+    PodVec<uint32_t> r_pos, r_end, r_lseq, r_ncig, r_dup, r_varlo;
+    PodVec<uint64_t> r_cigoff, r_seqoff, r_qualoff;
+    PodVec<uint32_t> cigar_pool;
+    PodVec<uint8_t> seq_pool, qual_pool;
+    PodVec<size_t> r_src;            // host-only: ReadStore index of each batch read
     // ---- variants
-    std::vector<uint32_t> v_pos, v_info, v_len, v_insoff, v_rev2fwd;
-    std::vector<uint8_t> ins_pool;
+    PodVec<uint32_t> v_pos, v_info, v_len, v_insoff, v_rev2fwd;
+    PodVec<uint8_t> ins_pool;
     // ---- refseq
-    std::vector<uint8_t> ref_pool;
+    PodVec<uint8_t> ref_pool;
     // ---- plan
-    std::vector<TxDev> tx;
-    std::vector<Step> steps;
-    std::vector<uint16_t> step_aux;       // normal mode only, one per Step: candidate key range R | 0x8000 = a new column epoch starts
-    std::vector<WinStatic> wins;
-    std::vector<WinCol> win_cols;         // column lists of the printing windows
+    PodVec<TxDev> tx;
+    PodVec<Step> steps;
+    PodVec<uint16_t> step_aux;       // normal mode only, one per Step: candidate key range R | 0x8000 = a new column epoch starts
+    PodVec<WinStatic> wins;
+    PodVec<WinCol> win_cols;         // column lists of the printing windows
     std::vector<ExonPlan> exons;
-    std::vector<uint8_t> str_pool;        // transcript ids
-    std::vector<SegDev> segs;             // independent replay units (whole exons of one transcript), see plan.hpp
-    std::vector<uint32_t> seg_order;      // launch order (longest first)
+    PodVec<uint8_t> str_pool;        // transcript ids
+    PodVec<SegDev> segs;             // independent replay units (whole exons of one transcript), see plan.hpp
+    PodVec<uint32_t> seg_order;      // launch order (longest first)
     // window-parallel replay (somatic): per-step side arrays, eligible exons, their work items
-    std::vector<uint8_t> step_ncols;      // live columns after the step's appends
-    std::vector<uint32_t> step_rlo;       // gene-relative index of the first read that can still enclose the step's window
-    std::vector<uint16_t> step_rn;        // number of reads from there up to start <= sso (saturating)
+    PodVec<uint8_t> step_ncols;      // live columns after the step's appends
+    PodVec<uint32_t> step_rlo;       // gene-relative index of the first read that can still enclose the step's window
+    PodVec<uint16_t> step_rn;        // number of reads from there up to start <= sso (saturating)
     struct SegInfo {                      // planner scratch, parallel to segs until finalize
         uint32_t n_exons = 0; bool cols_ok = true; uint32_t max_rn = 0; uint32_t read_lo = 0xFFFFFFFFu, read_hi = 0;
         uint32_t first_key_lo = 0, range = 0, tr0 = 0, f0 = 0; bool have_col = false; bool dup = false;
     };
     std::vector<SegInfo> seg_info;
-    std::vector<ExonW> exons_w;
-    std::vector<WChunk> wchunks, wchunks_m;   // single-block / multi-block window-parallel work items (kernels.hpp)
+    PodVec<ExonW> exons_w;
+    PodVec<WChunk> wchunks, wchunks_m;   // single-block / multi-block window-parallel work items (kernels.hpp)
     uint32_t rows_per_lane_w = 1;
-    std::vector<WChunk> achunks;              // admission work items: (exon, first read, count <= 64)
+    PodVec<WChunk> achunks;              // admission work items: (exon, first read, count <= 64)
     uint64_t n_adm = 0;                   // AdmEntry count (sum of ExonW::n_reads)
-    std::vector<uint64_t> v_sombits;      // bit (variant index in the batch) set <=> somatic
+    PodVec<uint64_t> v_sombits;      // bit (variant index in the batch) set <=> somatic
     // ---- sizing
     uint32_t seq_cap = 48;                // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks

@@ -35,8 +35,9 @@ void* DeviceContext::dalloc(size_t bytes) {
     return p;
 }
 
-template <class T>
-T* DeviceContext::up(const std::vector<T>& v) {
+template <class V>
+typename V::value_type* DeviceContext::up(const V& v) {
+    using T = typename V::value_type;
     T* p = static_cast<T*>(dalloc(v.size() * sizeof(T) + 64));  // +64: kernels stage pools with 16-byte loads
     allocs_.push_back(p);
     if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream_));

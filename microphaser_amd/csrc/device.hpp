@@ -55,7 +55,7 @@ class DeviceContext {
 
   private:
     void* dalloc(size_t bytes);
-    template <class T> T* up(const std::vector<T>& v);
+    template <class V> typename V::value_type* up(const V& v);
     void alloc_outputs();
     void free_outputs();
     int device_ = 0;

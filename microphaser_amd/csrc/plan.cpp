@@ -9,8 +9,10 @@
 #include <deque>
 #include <map>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <thread>
+#include <type_traits>
 
 #include "batch.hpp"
 
@@ -341,7 +343,7 @@ struct PlannerHooksT {
 static void merge_short_segments(Batch& b) {
     if (b.segs.empty()) return;
     const uint64_t target = std::max<uint64_t>(256, b.steps.size() / 16384);
-    std::vector<SegDev> out;
+    PodVec<SegDev> out;
     out.reserve(b.segs.size());
     for (const SegDev& g : b.segs) {
         if (!out.empty() && out.back().tx == g.tx && out.back().step_off + out.back().n_steps == g.step_off &&
@@ -373,7 +375,7 @@ static void validate_segments(const Batch& b) {
         if (uint64_t(e.step_off) + e.n_steps > b.steps.size() || e.tx >= b.tx.size()) throw Error("internal error: window-parallel exon outside the plan");
         covered += e.n_steps;
     }
-    for (const std::vector<WChunk>* list : {&b.wchunks, &b.wchunks_m})
+    for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m})
     for (const WChunk& c : *list)
         if (c.exon >= b.exons_w.size() || c.step_first < b.exons_w[c.exon].step_off ||
             uint64_t(c.step_first) + c.n_steps > uint64_t(b.exons_w[c.exon].step_off) + b.exons_w[c.exon].n_steps)
@@ -398,7 +400,7 @@ static void route_window_parallel(Batch& b) {
     b.wchunks_m.clear();
     b.achunks.clear();
     uint32_t max_rn_multi = 0;
-    std::vector<SegDev> keep;
+    PodVec<SegDev> keep;
     constexpr uint32_t CHUNK_STEPS = 96;
     for (size_t i = 0; i < b.segs.size(); i++) {
         const SegDev& g = b.segs[i];
@@ -638,25 +640,41 @@ template <class T> void append(std::vector<T>& a, const std::vector<T>& b) { a.i
 // One task per array, run on the same number of threads: the copies are first-touch bound, so they are spread over the cores.
 struct PartOff { uint64_t g, r, v, ins, t, s, w, wc, e, str, ref, cig, seq, qual; };
 
-template <class T, class Fix> void cat(std::vector<T>& dst, std::vector<Batch>& parts, std::vector<T> Batch::*m, Fix fix, size_t drop_last = 0) {
-    size_t total = 0;
-    for (Batch& p : parts) total += (p.*m).size() - std::min(drop_last, (p.*m).size());
-    dst.clear();
-    dst.reserve(total + 1);
-    for (size_t t = 0; t < parts.size(); t++) {
-        std::vector<T>& src = parts[t].*m;
-        const size_t n = src.size() - std::min(drop_last, src.size());
-        for (size_t i = 0; i < n; i++) { dst.push_back(std::move(src[i])); fix(dst.back(), t); }
-        std::vector<T>().swap(src);
+// One array of the merged batch: size it (PodVec: no page is touched), then one copy task per part.
+struct MergeTasks {
+    std::vector<std::function<void()>> run;
+    template <class V, class Fix> void add(V& dst, std::vector<Batch>& parts, V Batch::*m, Fix fix, size_t drop_last = 0) {
+        std::vector<size_t> at(parts.size() + 1, 0);
+        for (size_t t = 0; t < parts.size(); t++) at[t + 1] = at[t] + (parts[t].*m).size() - std::min(drop_last, (parts[t].*m).size());
+        dst.clear();
+        dst.reserve(at.back() + 1);   // +1: the offset arrays get their end sentinel appended afterwards
+        dst.resize(at.back());
+        for (size_t t = 0; t < parts.size(); t++) {
+            const size_t n = at[t + 1] - at[t], o = at[t];
+            run.push_back([&dst, &parts, m, fix, t, n, o] {
+                V& src = parts[t].*m;
+                for (size_t i = 0; i < n; i++) { dst[o + i] = std::move(src[i]); fix(dst[o + i], t); }
+                V().swap(src);
+            });
+        }
     }
-}
-template <class T> void cat(std::vector<T>& dst, std::vector<Batch>& parts, std::vector<T> Batch::*m) {
-    size_t total = 0;
-    for (Batch& p : parts) total += (p.*m).size();
-    dst.clear();
-    dst.reserve(total + 1);
-    for (Batch& p : parts) { dst.insert(dst.end(), (p.*m).begin(), (p.*m).end()); std::vector<T>().swap(p.*m); }
-}
+    template <class V> void add(V& dst, std::vector<Batch>& parts, V Batch::*m) {
+        using T = typename V::value_type;
+        static_assert(std::is_trivially_copyable<T>::value, "plain copy");
+        std::vector<size_t> at(parts.size() + 1, 0);
+        for (size_t t = 0; t < parts.size(); t++) at[t + 1] = at[t] + (parts[t].*m).size();
+        dst.clear();
+        dst.resize(at.back());
+        for (size_t t = 0; t < parts.size(); t++) {
+            const size_t o = at[t];
+            run.push_back([&dst, &parts, m, t, o] {
+                V& src = parts[t].*m;
+                if (!src.empty()) std::memcpy(static_cast<void*>(dst.data() + o), src.data(), src.size() * sizeof(T));
+                V().swap(src);
+            });
+        }
+    }
+};
 
 void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
     std::vector<PartOff> o(parts.size() + 1, PartOff{});
@@ -678,43 +696,37 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
     if (tot.s > 0xFFFFFFF0ull || tot.r > 0xFFFFFFF0ull || tot.w > 0xFFFFFFF0ull || tot.wc > 0xFFFFFFF0ull)
         throw Error("batch too large for 32-bit indices: split the batch by genes");
     using B = Batch;
-    std::vector<std::function<void()>> tasks;   // largest arrays first
-    tasks.push_back([&] { cat(b.qual_pool, parts, &B::qual_pool); });
-    tasks.push_back([&] { cat(b.steps, parts, &B::steps, [&](Step& st, size_t t) { if (st.win != 0xFFFFFFFFu) st.win += uint32_t(o[t].w); st.exon += uint32_t(o[t].e); }); });
-    tasks.push_back([&] { cat(b.seq_pool, parts, &B::seq_pool); });
-    tasks.push_back([&] { cat(b.wins, parts, &B::wins, [&](WinStatic& w, size_t t) {
-        w.tx += uint32_t(o[t].t); w.col_off += uint32_t(o[t].wc); w.ref_off += uint32_t(o[t].ref); w.vbase += uint32_t(o[t].v); w.step += uint32_t(o[t].s); }); });
-    tasks.push_back([&] { cat(b.win_cols, parts, &B::win_cols); });
-    tasks.push_back([&] { cat(b.ref_pool, parts, &B::ref_pool); });
-    tasks.push_back([&] { cat(b.r_src, parts, &B::r_src); });
-    tasks.push_back([&] { cat(b.r_cigoff, parts, &B::r_cigoff, [&](uint64_t& x, size_t t) { x += o[t].cig; }); });
-    tasks.push_back([&] { cat(b.r_seqoff, parts, &B::r_seqoff, [&](uint64_t& x, size_t t) { x += o[t].seq; }); });
-    tasks.push_back([&] { cat(b.r_qualoff, parts, &B::r_qualoff, [&](uint64_t& x, size_t t) { x += o[t].qual; }); });
-    tasks.push_back([&] { cat(b.step_rlo, parts, &B::step_rlo); });
-    tasks.push_back([&] { cat(b.cigar_pool, parts, &B::cigar_pool); });
-    tasks.push_back([&] { cat(b.r_pos, parts, &B::r_pos); });
-    tasks.push_back([&] { cat(b.r_end, parts, &B::r_end); });
-    tasks.push_back([&] { cat(b.r_lseq, parts, &B::r_lseq); });
-    tasks.push_back([&] { cat(b.r_ncig, parts, &B::r_ncig); });
-    tasks.push_back([&] { cat(b.r_dup, parts, &B::r_dup); });
-    tasks.push_back([&] { cat(b.r_varlo, parts, &B::r_varlo); });
-    tasks.push_back([&] { cat(b.step_rn, parts, &B::step_rn); });
-    tasks.push_back([&] { cat(b.step_aux, parts, &B::step_aux); });
-    tasks.push_back([&] { cat(b.step_ncols, parts, &B::step_ncols); });
-    tasks.push_back([&] { cat(b.v_pos, parts, &B::v_pos); cat(b.v_info, parts, &B::v_info); cat(b.v_len, parts, &B::v_len); cat(b.v_rev2fwd, parts, &B::v_rev2fwd);
-                          cat(b.v_insoff, parts, &B::v_insoff, [&](uint32_t& x, size_t t) { x += uint32_t(o[t].ins); }); cat(b.ins_pool, parts, &B::ins_pool); });
-    tasks.push_back([&] {
-        cat(b.genes, parts, &B::genes, [&](GeneHost& g, size_t t) { g.read_off += uint32_t(o[t].r); g.var_off += uint32_t(o[t].v); g.ref_off += o[t].ref; g.tx_off += uint32_t(o[t].t); });
-        cat(b.g_read_off, parts, &B::g_read_off, [&](uint32_t& x, size_t t) { x += uint32_t(o[t].r); }, 1);
-        cat(b.g_var_off, parts, &B::g_var_off, [&](uint32_t& x, size_t t) { x += uint32_t(o[t].v); }, 1);
-        cat(b.g_start, parts, &B::g_start);
-        cat(b.g_ref_off, parts, &B::g_ref_off, [&](uint64_t& x, size_t t) { x += o[t].ref; });
-        cat(b.tx, parts, &B::tx, [&](TxDev& x, size_t t) { x.gene += uint32_t(o[t].g); x.step_off += uint32_t(o[t].s); x.id_off += uint32_t(o[t].str); });
-        cat(b.segs, parts, &B::segs, [&](SegDev& x, size_t t) { x.tx += uint32_t(o[t].t); x.step_off += uint32_t(o[t].s); });
-        cat(b.seg_info, parts, &B::seg_info);
-        cat(b.exons, parts, &B::exons, [&](ExonPlan& e, size_t t) { e.tx += uint32_t(o[t].t); });
-        cat(b.str_pool, parts, &B::str_pool);
-    });
+    MergeTasks mt;   // largest arrays first
+    mt.add(b.qual_pool, parts, &B::qual_pool);
+    mt.add(b.steps, parts, &B::steps, [&o](Step& st, size_t t) { if (st.win != 0xFFFFFFFFu) st.win += uint32_t(o[t].w); st.exon += uint32_t(o[t].e); });
+    mt.add(b.seq_pool, parts, &B::seq_pool);
+    mt.add(b.wins, parts, &B::wins, [&o](WinStatic& w, size_t t) {
+        w.tx += uint32_t(o[t].t); w.col_off += uint32_t(o[t].wc); w.ref_off += uint32_t(o[t].ref); w.vbase += uint32_t(o[t].v); w.step += uint32_t(o[t].s); });
+    mt.add(b.win_cols, parts, &B::win_cols);
+    mt.add(b.ref_pool, parts, &B::ref_pool);
+    mt.add(b.r_src, parts, &B::r_src);
+    mt.add(b.r_cigoff, parts, &B::r_cigoff, [&o](uint64_t& x, size_t t) { x += o[t].cig; });
+    mt.add(b.r_seqoff, parts, &B::r_seqoff, [&o](uint64_t& x, size_t t) { x += o[t].seq; });
+    mt.add(b.r_qualoff, parts, &B::r_qualoff, [&o](uint64_t& x, size_t t) { x += o[t].qual; });
+    mt.add(b.step_rlo, parts, &B::step_rlo);
+    mt.add(b.cigar_pool, parts, &B::cigar_pool);
+    mt.add(b.r_pos, parts, &B::r_pos); mt.add(b.r_end, parts, &B::r_end); mt.add(b.r_lseq, parts, &B::r_lseq);
+    mt.add(b.r_ncig, parts, &B::r_ncig); mt.add(b.r_dup, parts, &B::r_dup); mt.add(b.r_varlo, parts, &B::r_varlo);
+    mt.add(b.step_rn, parts, &B::step_rn); mt.add(b.step_aux, parts, &B::step_aux); mt.add(b.step_ncols, parts, &B::step_ncols);
+    mt.add(b.v_pos, parts, &B::v_pos); mt.add(b.v_info, parts, &B::v_info); mt.add(b.v_len, parts, &B::v_len); mt.add(b.v_rev2fwd, parts, &B::v_rev2fwd);
+    mt.add(b.v_insoff, parts, &B::v_insoff, [&o](uint32_t& x, size_t t) { x += uint32_t(o[t].ins); });
+    mt.add(b.ins_pool, parts, &B::ins_pool);
+    mt.add(b.genes, parts, &B::genes, [&o](GeneHost& g, size_t t) { g.read_off += uint32_t(o[t].r); g.var_off += uint32_t(o[t].v); g.ref_off += o[t].ref; g.tx_off += uint32_t(o[t].t); });
+    mt.add(b.g_read_off, parts, &B::g_read_off, [&o](uint32_t& x, size_t t) { x += uint32_t(o[t].r); }, 1);
+    mt.add(b.g_var_off, parts, &B::g_var_off, [&o](uint32_t& x, size_t t) { x += uint32_t(o[t].v); }, 1);
+    mt.add(b.g_start, parts, &B::g_start);
+    mt.add(b.g_ref_off, parts, &B::g_ref_off, [&o](uint64_t& x, size_t t) { x += o[t].ref; });
+    mt.add(b.tx, parts, &B::tx, [&o](TxDev& x, size_t t) { x.gene += uint32_t(o[t].g); x.step_off += uint32_t(o[t].s); x.id_off += uint32_t(o[t].str); });
+    mt.add(b.segs, parts, &B::segs, [&o](SegDev& x, size_t t) { x.tx += uint32_t(o[t].t); x.step_off += uint32_t(o[t].s); });
+    mt.add(b.seg_info, parts, &B::seg_info, [](Batch::SegInfo&, size_t) {});
+    mt.add(b.exons, parts, &B::exons, [&o](ExonPlan& e, size_t t) { e.tx += uint32_t(o[t].t); });
+    mt.add(b.str_pool, parts, &B::str_pool);
+    std::vector<std::function<void()>>& tasks = mt.run;
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
     for (size_t k = 0; k < std::min(nthreads, tasks.size()); k++)
