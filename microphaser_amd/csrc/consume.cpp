@@ -44,11 +44,14 @@ std::string join_bar(const std::vector<std::string>& v) {
 }
 
 // IDRecord::update (reference: src/common.rs:376-526)
+// with_id = false leaves the id (a SHA-1 over the formatted sequence) to the caller: the splice-side merge only needs it for the
+// records it finally writes, a fraction of those it builds.
 IDRecord record_update(const IDRecord& self, const IDRecord& rec, uint64_t offset, uint64_t frame, double freq,
-                       const std::string& wt_seq, const std::string& mt_seq, uint64_t wlen) {
+                       const std::string& wt_seq, const std::string& mt_seq, uint64_t wlen, bool with_id = true) {
     IDRecord r;
-    r.id = haplotype_id(reinterpret_cast<const uint8_t*>(mt_seq.data()), mt_seq.size(), self.transcript, offset,
-                        self.strand.empty() ? '?' : self.strand[0]);
+    if (with_id)
+        r.id = haplotype_id(reinterpret_cast<const uint8_t*>(mt_seq.data()), mt_seq.size(), self.transcript, offset,
+                            self.strand.empty() ? '?' : self.strand[0]);
     auto num = [](const std::string& p) { return uint64_t(std::strtoull(p.c_str(), nullptr, 10)); };
     auto at = [](const std::vector<std::string>& v, size_t c) -> const std::string& {
         if (c >= v.size()) throw Error("reference would panic: index out of bounds (aa_change)");
@@ -270,6 +273,7 @@ struct ConsumerHooks {
             const bool emit = emit_pre && frame_frequency > 0.0;
             HapSeq hs;
             if (boundary || emit) {
+                hs.filled = true;
                 IDRecord& r = hs.record;
                 std::string sites, som_pos, som_pc, germ_pos, germ_pc;
                 uint32_t n_sites = 0, n_som_sites = 0;
@@ -345,6 +349,9 @@ struct ConsumerHooks {
         const uint64_t offset = sg.offset;
         const std::vector<HapSeq>& first_hap_vec = is_fwd ? hap_vec : prev_hap_vec;
         const std::vector<HapSeq>& sec_hap_vec = is_fwd ? prev_hap_vec : hap_vec;
+        for (const std::vector<HapSeq>* v : {&first_hap_vec, &sec_hap_vec})
+            for (const HapSeq& h : *v)
+                if (!h.filled) throw Error("internal error: splice-side merge over a window whose records were not requested from the device");
         using MKey = std::tuple<uint64_t, std::string, std::string>;
         std::map<MKey, std::tuple<std::string, IDRecord, std::string>> output_map;
         std::vector<HapSeq> new_hap_vec;
@@ -375,13 +382,15 @@ struct ConsumerHooks {
                 const double merged = std::fabs(record.freq - prev.freq) < eps ? record.freq : record.freq * prev.freq;
                 if (eg.is_short && !eg.is_last) {
                     HapSeq nh;
-                    nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_wt, window_len);
+                    nh.filled = true;
+                    nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_wt, window_len, false);   // carried, never written
                     new_hap_vec.push_back(std::move(nh));
                 }
                 for (const std::string& new_mt : new_mts) {
                     if (eg.is_short && !eg.is_last) {
                         HapSeq nh;
-                        nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_mt, window_len);
+                        nh.filled = true;
+                        nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_mt, window_len, false);
                         new_hap_vec.push_back(std::move(nh));
                         continue;
                     }
@@ -416,24 +425,29 @@ struct ConsumerHooks {
                         for (;;) {
                             if (end_offset > new_mt.size()) throw Error("reference would panic: attempt to subtract with overflow");
                             if (!(splice_offset + window_len <= uint64_t(new_mt.size() - end_offset))) break;
-                            std::string out_wt;
+                            // the two windows are compared in place; strings are only built for a window that is kept (most are not:
+                            // a merged window without a variant equals its wild type)
+                            const size_t wl_ = size_t(window_len);
+                            const char* wt_p = nullptr;
                             if (splice_offset + window_len <= uint64_t(new_wt.size())) {
-                                if (is_fwd) out_wt = new_wt.substr(size_t(splice_offset), size_t(window_len));
+                                if (is_fwd) wt_p = new_wt.data() + size_t(splice_offset);
                                 else {
                                     if (new_wt.size() < end_offset + window_len) throw Error("reference would panic: attempt to subtract with overflow");
-                                    out_wt = new_wt.substr(new_wt.size() - end_offset - size_t(window_len), size_t(window_len));
+                                    wt_p = new_wt.data() + (new_wt.size() - end_offset - wl_);
                                 }
                             }
-                            std::string out_mt = is_fwd ? new_mt.substr(size_t(splice_offset), size_t(window_len))
-                                                        : new_mt.substr(new_mt.size() - end_offset - size_t(window_len), size_t(window_len));
-                            if (out_shift > 0 && out_wt == out_mt && somatic_shift) out_wt.clear();
-                            if (out_wt == out_mt || (out_wt.empty() && frameshift == 0)) {
+                            const char* mt_p = is_fwd ? new_mt.data() + size_t(splice_offset) : new_mt.data() + (new_mt.size() - end_offset - wl_);
+                            bool same = wt_p != nullptr && std::memcmp(wt_p, mt_p, wl_) == 0;
+                            if (out_shift > 0 && same && somatic_shift) { wt_p = nullptr; same = false; }   // out_wt.clear()
+                            if (same || (wt_p == nullptr && frameshift == 0)) {
                                 if (is_fwd) splice_offset += 3; else end_offset += 3;
                                 continue;
                             }
+                            const std::string out_wt = wt_p ? std::string(wt_p, wl_) : std::string();
+                            const std::string out_mt(mt_p, wl_);
                             const uint64_t out_offset = is_fwd ? splice_offset : uint64_t(end_offset);
-                            IDRecord out_record = is_fwd ? record_update(prev, record, out_offset, frameshift, out_freq, out_wt, out_mt, window_len)
-                                                         : record_update(record, prev, out_offset, frameshift, out_freq, out_wt, out_mt, window_len);
+                            IDRecord out_record = is_fwd ? record_update(prev, record, out_offset, frameshift, out_freq, out_wt, out_mt, window_len, false)
+                                                         : record_update(record, prev, out_offset, frameshift, out_freq, out_wt, out_mt, window_len, false);
                             MKey id_tuple{out_offset, out_mt, out_wt};
                             auto fit = output_map.find(id_tuple);
                             const double old_freq = fit == output_map.end() ? 0.0 : std::get<1>(fit->second).freq;
@@ -447,11 +461,13 @@ struct ConsumerHooks {
         if (eg.is_short && !eg.is_last) {
             prev_hap_vec = std::move(new_hap_vec);
         } else {
-            for (const auto& kv : output_map) {
+            for (auto& kv : output_map) {
                 const std::string& out_mt = std::get<0>(kv.second);
-                const IDRecord& out_record = std::get<1>(kv.second);
+                IDRecord& out_record = std::get<1>(kv.second);
                 const std::string& out_wt = std::get<2>(kv.second);
                 if (out_mt != out_wt) {
+                    out_record.id = haplotype_id(reinterpret_cast<const uint8_t*>(out_mt.data()), out_mt.size(), out_record.transcript,
+                                                 std::get<0>(kv.first), out_record.strand.empty() ? '?' : out_record.strand[0]);
                     if (out_mt.size() < window_len) throw Error("reference would panic: slice index out of range");
                     write_fasta(out.fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), size_t(window_len));
                     if (!out_wt.empty()) {
@@ -475,9 +491,10 @@ struct ConsumerHooks {
 namespace {
 
 // IDRecord::update / add_freq of the normal mode (reference: src/normal_microphasing.rs:105-146, :148-179)
-NormalRecord nrecord_update(const NormalRecord& self, const NormalRecord& rec, uint64_t offset, const std::vector<uint8_t>& seq) {
+NormalRecord nrecord_update(const NormalRecord& self, const NormalRecord& rec, uint64_t offset, const std::vector<uint8_t>& seq, bool with_id = true) {
     NormalRecord r = self;
-    r.id = haplotype_id(seq.data(), seq.size(), self.transcript, offset, self.strand.empty() ? '?' : self.strand[0]);
+    if (with_id) r.id = haplotype_id(seq.data(), seq.size(), self.transcript, offset, self.strand.empty() ? '?' : self.strand[0]);
+    else r.id.clear();   // the caller sets it on the records it writes
     r.somatic_positions = self.somatic_positions + rec.somatic_positions;
     r.somatic_aa_change = self.somatic_aa_change + rec.somatic_aa_change;
     r.germline_positions = self.germline_positions + rec.germline_positions;
@@ -563,6 +580,7 @@ struct NormalConsumerHooks {
             const double freq = double(G.count) / double(nrows);  // NaN when no read covers the window
             HapSeq hs;
             if (boundary || !eg.is_short) {
+                hs.filled = true;
                 NormalRecord& r = hs.nrecord;
                 const uint64_t this_window_len = seq_len < wl ? seq_len : wl;
                 auto sl = [&](uint64_t a, uint64_t e) {
@@ -619,6 +637,9 @@ struct NormalConsumerHooks {
                       std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec) {
         const std::vector<HapSeq>& first_hap_vec = is_fwd ? hap_vec : prev_hap_vec;
         const std::vector<HapSeq>& sec_hap_vec = is_fwd ? prev_hap_vec : hap_vec;
+        for (const std::vector<HapSeq>* v : {&first_hap_vec, &sec_hap_vec})
+            for (const HapSeq& h : *v)
+                if (!h.filled) throw Error("internal error: splice-side merge over a window whose records were not requested from the device");
         using Bytes = std::vector<uint8_t>;
         std::map<std::pair<uint64_t, Bytes>, NormalRecord> output_map;
         std::vector<HapSeq> new_hap_vec;
@@ -630,7 +651,8 @@ struct NormalConsumerHooks {
                 if (eg.is_short) {
                     HapSeq nh;
                     nh.sequence = prev_sequence;
-                    nh.nrecord = nrecord_update(prev_record, hapseq.nrecord, 0, prev_sequence);
+                    nh.filled = true;
+                    nh.nrecord = nrecord_update(prev_record, hapseq.nrecord, 0, prev_sequence, false);   // carried, never written
                     new_hap_vec.push_back(std::move(nh));
                 }
                 uint64_t splice_offset = 3;
@@ -644,7 +666,7 @@ struct NormalConsumerHooks {
                     if (end_offset > prev_sequence.size()) throw Error("reference would panic: attempt to subtract with overflow (merge)");
                     if (!(splice_offset + window_len <= uint64_t(prev_sequence.size() - end_offset))) break;
                     Bytes out_seq(prev_sequence.begin() + long(splice_offset), prev_sequence.begin() + long(splice_offset + window_len));
-                    NormalRecord out_record = nrecord_update(prev_record, hapseq.nrecord, splice_offset, out_seq);
+                    NormalRecord out_record = nrecord_update(prev_record, hapseq.nrecord, splice_offset, out_seq, false);
                     auto key = std::make_pair(splice_offset, out_seq);
                     auto fit = output_map.find(key);
                     const double old_freq = fit == output_map.end() ? 0.0 : fit->second.freq;
@@ -656,8 +678,10 @@ struct NormalConsumerHooks {
         if (eg.is_short && !eg.is_last) {
             prev_hap_vec = std::move(new_hap_vec);
         } else {
-            for (const auto& kv : output_map) {
+            for (auto& kv : output_map) {
                 const Bytes& out_seq = kv.first.second;
+                NormalRecord& rec = kv.second;
+                rec.id = haplotype_id(out_seq.data(), out_seq.size(), rec.transcript, kv.first.first, rec.strand.empty() ? '?' : rec.strand[0]);
                 if (out_seq.size() < window_len) throw Error("reference would panic: slice index out of range");
                 write_fasta(out.fasta, kv.second.id, out_seq.data(), size_t(window_len));
                 write_normal_tsv_record(out, kv.second);

@@ -41,7 +41,12 @@ struct PlannerHooksT {
     uint64_t max_live = 0;
     uint64_t max_seq_len = 0;
     // windows whose haplotypes currently sit in prev_hap_vec / hap_vec (they feed the next splice-side merge)
-    uint32_t last_print_win = 0xFFFFFFFFu, held_prev = 0xFFFFFFFFu, held_hap = 0xFFFFFFFFu;
+    // Windows whose haplotypes may be in prev_hap_vec / hap_vec when a splice-side merge runs. The schedule is speculative: a shifted
+    // ORF that really stops (data dependent) no longer prints, so the vector then still holds an EARLIER window's haplotypes. A main-ORF
+    // print always happens while the walk is alive and replaces the candidates; a shifted-ORF print only adds one.
+    uint32_t last_print_win = 0xFFFFFFFFu;
+    uint64_t last_print_frame = 0;
+    std::vector<uint32_t> held_prev, held_hap;
     // segments: where the current one starts, the extreme candidate keys seen so far, prefix maximum of the read ends
     const std::vector<uint32_t>* pmax_end = nullptr;
     uint32_t seg_start = 0xFFFFFFFFu;
@@ -311,6 +316,7 @@ struct PlannerHooksT {
     std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
         ensure_window(eg, sg);
         last_print_win = b.steps[cur_step].win;
+        last_print_frame = frame;
         if (frame == 0) b.n_main_windows++;
         fsf.emplace(frame, std::make_pair(1.0, false));
         std::vector<HapSeq> v(1);
@@ -322,16 +328,21 @@ struct PlannerHooksT {
         if (seg_start != 0xFFFFFFFFu && here > seg_start) { b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, seg_init_cols}); b.seg_info.push_back(seg_info); }
     }
 
-    void routed(bool to_prev) { (to_prev ? held_prev : held_hap) = last_print_win; }
+    void routed(bool to_prev) {
+        std::vector<uint32_t>& held = to_prev ? held_prev : held_hap;
+        if (last_print_frame == 0) held.clear();
+        if (held.empty() || held.back() != last_print_win) held.push_back(last_print_win);
+    }
 
     // the merge reads the full records of both carried-over windows (:1527-1540)
     void splice_merge(const ExonGeom&, const StepGeom&, uint64_t, std::map<uint64_t, uint64_t>&, FsFreq&, std::vector<HapSeq>&,
                       std::vector<HapSeq>&) {
-        for (uint32_t wi : {held_prev, held_hap})
-            if (wi != 0xFFFFFFFFu) {
-                b.wins[wi].need_recs |= WS_CARRY;
-                b.steps[b.wins[wi].step].flags |= SF_NEED_RECS;
-            }
+        for (const std::vector<uint32_t>* held : {&held_prev, &held_hap})
+            for (uint32_t wi : *held)
+                if (wi != 0xFFFFFFFFu) {
+                    b.wins[wi].need_recs |= WS_CARRY;
+                    b.steps[b.wins[wi].step].flags |= SF_NEED_RECS;
+                }
     }
 };
 

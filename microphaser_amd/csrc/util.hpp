@@ -57,8 +57,8 @@ struct Sha1 {
         uint8_t lenb[8];
         for (int i = 0; i < 8; i++) lenb[i] = uint8_t(bits >> (56 - 8 * i));
         update(lenb, 8);
-        char out[41];
-        for (int i = 0; i < 5; i++) std::snprintf(out + 8 * i, 9, "%08x", h[i]);
+        char out[40];
+        for (int i = 0; i < 40; i++) out[i] = "0123456789abcdef"[(h[i >> 3] >> (28 - 4 * (i & 7))) & 0xF];
         return std::string(out, 40);
     }
 };
@@ -67,14 +67,17 @@ struct Sha1 {
 // (reference: src/microphasing.rs:667-675). `{:?}` of Vec<u8> is "[65, 67, ...]".
 inline std::string haplotype_id(const uint8_t* seq, size_t n, const std::string& transcript_id, uint64_t offset,
                                 char strand_initial) {
-    std::string s = "[";
-    char tmp[8];
+    std::string s;
+    s.reserve(5 * n + transcript_id.size() + 24);
+    s.push_back('[');
     for (size_t i = 0; i < n; i++) {
-        if (i) s += ", ";
-        int l = std::snprintf(tmp, sizeof tmp, "%u", unsigned(seq[i]));
-        s.append(tmp, l);
+        if (i) { s.push_back(','); s.push_back(' '); }
+        const unsigned v = seq[i];
+        if (v >= 100) s.push_back(char('0' + v / 100));
+        if (v >= 10) s.push_back(char('0' + (v / 10) % 10));
+        s.push_back(char('0' + v % 10));
     }
-    s += "]";
+    s.push_back(']');
     s += transcript_id;
     s += std::to_string(offset);
     Sha1 sh;

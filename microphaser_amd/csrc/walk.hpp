@@ -28,6 +28,7 @@ struct HapSeq {  // reference: HaplotypeSeq (microphasing.rs:141-145); record ca
     // `normal` mode (normal_microphasing.rs:182-186): the sequence bytes + its own record type
     std::vector<uint8_t> sequence;
     NormalRecord nrecord;
+    bool filled = false;   // consumer: the record was built (the planner marked the window as carried or it is emitted)
 };
 
 struct ExonGeom {

@@ -212,6 +212,24 @@ def test_gpu_normal_mode_columns_past_window_end_lengthen_the_sequence(ctx, tmp_
     assert res.tsv.count(b"\n") > 100000
 
 
+def test_gpu_merge_uses_the_window_left_by_a_stopped_shifted_orf(ctx, tmp_path):
+    """Found by tools/fuzz_vs_oracle.py (seeds 97187, 97231): the planner's schedule is speculative, a shifted ORF that really stops
+    (stop codon in its frame) prints no more, so at the next splice side hap_vec still holds an EARLIER window's haplotypes
+    (src/microphasing.rs:1445-1454, 1505-1540). Those windows need full records too, or the merge sees empty ones."""
+    prefix = os.path.join(str(tmp_path), "o")
+    args = ["--seed", "97187", "--transcripts", "16", "--depth", "30", "--spacing", "5.4", "--indel-rate", "0.03", "--multiallelic-rate", "0.08",
+            "--window-len", "33"]
+    subprocess.run([ORACLE_CLI, "synth", *args, "--genes", "12:13", "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    ds = ctx.synth(97187, 16, 30.0, 5.4, indel_rate=0.03, multiallelic_rate=0.08)
+    b = ds.batch(window_len=33, gene_lo=12, gene_hi=13)
+    b.run()
+    res = b.results()
+    assert res.tsv == open(prefix + ".tsv", "rb").read()
+    assert res.fasta == open(prefix + ".fa", "rb").read()
+    assert res.normal_fasta == open(prefix + ".normal.fa", "rb").read()
+    assert res.tsv.count(b"\n") > 300
+
+
 # ------------------------------------------------------------------ the product CLI (src/cli.yaml surface): GTF on stdin, FASTA on stdout
 PRODUCT_CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microphaser_amd", "_lib", "microphaser")
 

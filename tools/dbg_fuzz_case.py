@@ -27,4 +27,11 @@ for g in range(ds.num_genes):
     exp = {e: open(prefix + "." + e, "rb").read() for e in ("fa", "tsv")}
     if err is not None: print(g, "ENGINE-ERR", err, "oracle skipped:", st["skipped"], "oracle tsv rows", exp["tsv"].count(b"\n"))
     elif st["skipped"]: print(g, "oracle skipped the gene, engine ran")
-    else: print(g, "ok" if got == exp else "DIFF", exp["tsv"].count(b"\n"))
+    else:
+        print(g, "ok" if got == exp else "DIFF", exp["tsv"].count(b"\n"))
+        if got != exp:
+            for k in ("tsv", "fa"):
+                a, b2 = got[k].split(b"\n"), exp[k].split(b"\n")
+                for i in range(max(len(a), len(b2))):
+                    if i >= len(a) or i >= len(b2) or a[i] != b2[i]:
+                        print("  first", k, "difference at line", i); print("   engine:", a[i][:400] if i < len(a) else None); print("   oracle:", b2[i][:400] if i < len(b2) else None); break
