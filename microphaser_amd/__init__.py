@@ -174,10 +174,10 @@ class Context:
             self._check(lib().mp_filter(self._h, tsv.encode(), reference_binary.encode(), peptide_len, ctypes.byref(h)))
         return Filtered(h)
 
-    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0):
+    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0, read_len=0):
         h = ctypes.c_void_p()
-        if indel_rate or multiallelic_rate or softmask_rate:
-            cfg = SynthConfig(seed, n_transcripts, 0, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate)
+        if indel_rate or multiallelic_rate or softmask_rate or read_len:
+            cfg = SynthConfig(seed, n_transcripts, read_len, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate)
             self._check(lib().mp_dataset_synth_ex(self._h, ctypes.byref(cfg), ctypes.byref(h)))
         else:
             self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))

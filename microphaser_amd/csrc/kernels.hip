@@ -319,6 +319,25 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     }
                 }
                 if (left) sticky_err |= WD_ROW_OVERFLOW;
+                // A row that outlived its exon (a read longer than the intron) is listed again by the next exon's full-range scan.
+                // `contains` (:281-294, tested before anything else in push_read) rejects that copy for as long as the row lives,
+                // and the row leaves by the very test (start > sso) that ends the candidate: the copy is dropped here, whatever
+                // its quality state, instead of being kept pending for a retry.
+                if (any_rows_before) {
+#pragma unroll
+                    for (int rc = 0; rc < RPL; rc++) {
+                        uint64_t m = __ballot((fl[rc] & ST_MASK) == ST_PENDING);
+                        while (m) {
+                            const uint32_t l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const uint32_t myidx = rdlane(ridx[rc], l);
+                            bool is_row = false;
+#pragma unroll
+                            for (int r = 0; r < RPL; r++) is_row |= (__ballot((fl[r] & ST_MASK) == ST_ROW && ridx[r] == myidx) != 0);
+                            if (is_row && lane == l) fl[rc] = ST_EMPTY;
+                        }
+                    }
+                }
             }
             // ---- push_read (:297-343) for every pending candidate
             bool att[RPL];

@@ -230,6 +230,22 @@ def test_gpu_merge_uses_the_window_left_by_a_stopped_shifted_orf(ctx, tmp_path):
     assert res.tsv.count(b"\n") > 300
 
 
+def test_gpu_row_outliving_its_exon_is_not_admitted_twice(ctx, tmp_path):
+    """Found by tools/fuzz_vs_oracle.py (seed 200350, 250-nt reads): on the '-' strand a read longer than an intron is still a row
+    when the next exon's first window lists every read in range again; `contains` (src/microphasing.rs:281-294) must keep that
+    copy out for good - also when the row has meanwhile gone low-quality - instead of admitting it a few windows later."""
+    prefix = os.path.join(str(tmp_path), "o")
+    args = ["--seed", "200350", "--transcripts", "16", "--depth", "6", "--spacing", "1.35", "--window-len", "15", "--read-len", "250"]
+    subprocess.run([ORACLE_CLI, "synth", *args, "--genes", "1:2", "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    ds = ctx.synth(200350, 16, 6.0, 1.35, read_len=250)
+    b = ds.batch(window_len=15, gene_lo=1, gene_hi=2)
+    b.run()
+    res = b.results()
+    assert res.tsv == open(prefix + ".tsv", "rb").read()
+    assert res.fasta == open(prefix + ".fa", "rb").read()
+    assert res.tsv.count(b"\n") > 200
+
+
 # ------------------------------------------------------------------ the product CLI (src/cli.yaml surface): GTF on stdin, FASTA on stdout
 PRODUCT_CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microphaser_amd", "_lib", "microphaser")
 
