@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
 #include "../../include/microphaser_hip.h"
 
 static int fail(mp_ctx* ctx, const char* what) {
@@ -199,16 +200,37 @@ int main(int argc, char** argv) {
         return 0;
     }
     mp_results* res = nullptr;
-    if (mp_phase_dataset(ctx, ds, mode, window_len, &res) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
+    mp_batch* batch = nullptr;
+    if (mp_batch_create(ctx, ds, mode, window_len, 0, mp_dataset_num_genes(ds), &batch) != 0 || mp_batch_run(ctx, batch, nullptr) != 0 ||
+        mp_batch_results(ctx, batch, &res) != 0) {
+        int rc = fail(ctx, "microphaser");
+        mp_batch_free(batch); mp_dataset_free(ds); mp_destroy(ctx);
+        return rc;
+    }
+    // the TSV is by far the largest stream: it is written by its own thread while this one writes the two FASTA streams
+    const auto t_write = std::chrono::steady_clock::now();
+    bool tsv_ok = true;
+    std::thread tsv_writer([&] {
+        size_t tn = 0;
+        const char* tp = mp_results_tsv(res, &tn);
+        tsv_ok = write_file(tsv, tp, tn);
+    });
     size_t n = 0;
     const char* p = mp_results_fasta(res, &n);
     std::fwrite(p, 1, n, stdout);
+    std::fflush(stdout);
     p = mp_results_normal_fasta(res, &n);
-    if (!normal_mode && !write_file(normal, p, n)) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
-    p = mp_results_tsv(res, &n);
-    if (!write_file(tsv, p, n)) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
+    const bool normal_ok = normal_mode || write_file(normal, p, n);
+    tsv_writer.join();
+    if (!normal_ok) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
+    if (!tsv_ok) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
+    const auto t_free = std::chrono::steady_clock::now();
+    mp_batch_free(batch);
     mp_results_free(res);
     mp_dataset_free(ds);
     mp_destroy(ctx);
+    if (std::getenv("MP_DEBUG"))
+        std::fprintf(stderr, "[mp] write outputs %.1f ms, release %.1f ms\n", std::chrono::duration<double, std::milli>(t_free - t_write).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());
     return 0;
 }
