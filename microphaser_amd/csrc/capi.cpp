@@ -139,6 +139,7 @@ int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* c, mp_dataset** out)
         cfg.indel_rate = c->indel_rate;
         cfg.multiallelic_rate = c->multiallelic_rate;
         cfg.softmask_rate = c->softmask_rate;
+        cfg.mate_rate = c->mate_rate;
         synth_generate(cfg, d->ds);
         *out = d.release();
     });

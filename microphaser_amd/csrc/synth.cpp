@@ -249,6 +249,10 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
                     const bool tumor = rng.uni() < 0.6;
                     pr.mapq = rng.uni() < 0.01 ? 0 : 60;
                     pr.serial = read_serial++;
+                    // test-only: a mate that starts at the same position (same name, its own errors and qualities) - what `contains`
+                    // exists for (src/microphasing.rs:281-294)
+                    const bool with_mate = cfg.mate_rate > 0 && rng.uni() < cfg.mate_rate;
+                    for (int copy = 0; copy < (with_mate ? 2 : 1); copy++) {
                     std::fill(seq4.begin(), seq4.end(), 0);
                     // walk the reference from pr.pos, applying the variants this read's haplotype carries
                     auto it = std::lower_bound(vars.begin(), vars.end(), pr.pos, [](const SynVar& v, uint64_t p) { return v.pos < p; });
@@ -288,6 +292,7 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
                     stage_seq.insert(stage_seq.end(), seq4.begin(), seq4.end());
                     stage_qual.insert(stage_qual.end(), qual.begin(), qual.end());
                     creads.push_back(pr);
+                    }
                 }
             }
             std::stable_sort(creads.begin(), creads.end(), [](const PendingRead& a, const PendingRead& b2) { return a.pos < b2.pos; });

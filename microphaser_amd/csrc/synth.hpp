@@ -18,6 +18,7 @@ struct SynthConfig {
     // test-only extensions (all 0 in the benchmark workloads): fraction of variant sites that are short indels,
     // fraction of SNV sites with a second ALT allele, fraction of genes with a lower-case (soft-masked) stretch
     double indel_rate = 0.0, multiallelic_rate = 0.0, softmask_rate = 0.0;
+    double mate_rate = 0.0;    // fraction of reads followed by a second record with the same name and start
 };
 
 struct Dataset {

@@ -32,14 +32,15 @@ def make_case(k):
     n = rng.choice([8, 16]) if depth < 100 else 5
     rl = rng.choice([101, 101, 101, 76, 151, 250])   # 250-nt reads at 1.35-nt spacing span > 128 variants (four mask words)
     if rl > 101 and mode == "normal": depth = min(depth, 12)
-    return dict(seed=first + k, mode=mode, n=n, depth=depth, spacing=spacing, indel=indel, multi=multi, soft=soft, wl=wl, rl=rl)
+    mate = rng.choice([0, 0, 0.15])   # same-name records starting at the same position: the `contains` rule
+    return dict(seed=first + k, mode=mode, n=n, depth=depth, spacing=spacing, indel=indel, multi=multi, soft=soft, wl=wl, rl=rl, mate=mate)
 
 
 def run_oracle(c):
     prefix = os.path.join(tmp, "o%d" % c["seed"])
     cmd = [ORACLE_CLI, "synth", "--mode", c["mode"], "--seed", str(c["seed"]), "--transcripts", str(c["n"]), "--depth", str(c["depth"]),
            "--spacing", str(c["spacing"]), "--indel-rate", str(c["indel"]), "--multiallelic-rate", str(c["multi"]),
-           "--softmask-rate", str(c["soft"]), "--window-len", str(c["wl"]), "--read-len", str(c["rl"]), "--skip-panics", "--prefix", prefix]
+           "--softmask-rate", str(c["soft"]), "--window-len", str(c["wl"]), "--read-len", str(c["rl"]), "--mate-rate", str(c["mate"]), "--skip-panics", "--prefix", prefix]
     r = subprocess.run(cmd, capture_output=True)
     if r.returncode != 0:
         return None, "oracle failed: " + r.stderr.decode()[-300:]
@@ -54,7 +55,7 @@ def run_oracle(c):
 
 def run_engine(ctx, c, skipped):
     mode = m.MODE_SOMATIC if c["mode"] == "somatic" else m.MODE_NORMAL
-    ds = ctx.synth(c["seed"], c["n"], float(c["depth"]), c["spacing"], indel_rate=c["indel"], multiallelic_rate=c["multi"], softmask_rate=c["soft"], read_len=c["rl"])
+    ds = ctx.synth(c["seed"], c["n"], float(c["depth"]), c["spacing"], indel_rate=c["indel"], multiallelic_rate=c["multi"], softmask_rate=c["soft"], read_len=c["rl"], mate_rate=c["mate"])
     parts, windows, lo, notes = [], 0, 0, []
     for g in skipped + [ds.num_genes]:
         if g > lo:
@@ -74,7 +75,7 @@ def run_engine(ctx, c, skipped):
 
 cases = [make_case(k) for k in range(count)]
 ctx = m.Context(0)
-bad = done = 0
+bad = done = limits = 0
 t0 = time.time()
 with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 2)) as pool:
     futs = [pool.submit(run_oracle, c) for c in cases]
@@ -89,6 +90,8 @@ with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 2)) as pool:
         try:
             got, windows, notes = run_engine(ctx, c, st["skipped"])
         except m.MicrophaserError as e:
+            if "live column epochs" in str(e):   # documented loud limit of the `normal` replay: long reads x very dense variants
+                print("LIMIT", tag, str(e)[:120], flush=True); limits += 1; continue
             print("ENGINE-ERR", tag, str(e)[:200], flush=True); bad += 1; continue
         diffs = list(notes)
         if windows != st["windows"]: diffs.append("windows %d != %d" % (windows, st["windows"]))
@@ -97,5 +100,5 @@ with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 2)) as pool:
         done += 1
         if diffs: bad += 1
         print("DIFF" if diffs else "ok  ", tag, "windows=%d skipped=%d" % (windows, len(st["skipped"])), "; ".join(diffs), flush=True)
-print("cases: %d, mismatches: %d, %.0f s" % (done, bad, time.time() - t0))
+print("cases: %d, mismatches: %d, documented limits hit: %d, %.0f s" % (done, bad, limits, time.time() - t0))
 sys.exit(1 if bad else 0)
