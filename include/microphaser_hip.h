@@ -54,6 +54,7 @@ typedef struct mp_synth_config {
     double depth, var_spacing;
     double indel_rate, multiallelic_rate, softmask_rate;
     double mate_rate;            /* fraction of reads followed by a same-name record starting at the same position */
+    double isoform_rate;         /* fraction of genes with a second coding transcript (a prefix of the exons) */
 } mp_synth_config;
 int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* cfg, mp_dataset** out);
 /* Write prefix.{bam,vcf,gtf,fa,fa.fai} so that a CLI run sees the same inputs. */

@@ -32,7 +32,7 @@ class SynthConfig(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("n_transcripts", ctypes.c_uint32), ("read_len", ctypes.c_uint32),
                 ("depth", ctypes.c_double), ("var_spacing", ctypes.c_double),
                 ("indel_rate", ctypes.c_double), ("multiallelic_rate", ctypes.c_double), ("softmask_rate", ctypes.c_double),
-                ("mate_rate", ctypes.c_double)]
+                ("mate_rate", ctypes.c_double), ("isoform_rate", ctypes.c_double)]
 
 
 class RunStats(ctypes.Structure):
@@ -175,10 +175,10 @@ class Context:
             self._check(lib().mp_filter(self._h, tsv.encode(), reference_binary.encode(), peptide_len, ctypes.byref(h)))
         return Filtered(h)
 
-    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0, read_len=0, mate_rate=0.0):
+    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0, read_len=0, mate_rate=0.0, isoform_rate=0.0):
         h = ctypes.c_void_p()
-        if indel_rate or multiallelic_rate or softmask_rate or read_len or mate_rate:
-            cfg = SynthConfig(seed, n_transcripts, read_len, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate, mate_rate)
+        if indel_rate or multiallelic_rate or softmask_rate or read_len or mate_rate or isoform_rate:
+            cfg = SynthConfig(seed, n_transcripts, read_len, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate, mate_rate, isoform_rate)
             self._check(lib().mp_dataset_synth_ex(self._h, ctypes.byref(cfg), ctypes.byref(h)))
         else:
             self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))

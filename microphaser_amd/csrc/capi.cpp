@@ -140,6 +140,7 @@ int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* c, mp_dataset** out)
         cfg.multiallelic_rate = c->multiallelic_rate;
         cfg.softmask_rate = c->softmask_rate;
         cfg.mate_rate = c->mate_rate;
+        cfg.isoform_rate = c->isoform_rate;
         synth_generate(cfg, d->ds);
         *out = d.release();
     });

@@ -176,6 +176,25 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
                 consumed += ex.second - ex.first;
             }
             line("three_prime_utr", utr_lo, utr_hi, ".", attr_t);
+            // ---- test-only: a second coding transcript of the gene, its first m exons (shares the gene's reads and variants)
+            if (cfg.isoform_rate > 0 && n_exons >= 2 && rng.uni() < cfg.isoform_rate) {
+                const uint32_t m = 1 + uint32_t(rng.below(n_exons - 1));
+                char tid2[32];
+                std::snprintf(tid2, sizeof tid2, "SYNU%08u", tx_serial);
+                const std::string attr_t2 = std::string("gene_id \"") + gid + "\"; transcript_id \"" + tid2 + "\"; gene_name \"" + gname +
+                                            "\"; gene_biotype \"protein_coding\"; transcript_biotype \"protein_coding\";";
+                line("transcript", gene_start, gene_end, ".", attr_t2);
+                uint64_t used = 0;
+                for (uint32_t k = 0; k < m; k++) {
+                    const auto& ex = reverse ? gexons[n_exons - 1 - k] : gexons[k];
+                    line("CDS", ex.first, ex.second, std::to_string((3 - used % 3) % 3), attr_t2);
+                    if (k == 0) {
+                        if (!reverse) line("start_codon", ex.first, ex.first + 3, "0", attr_t2);
+                        else line("start_codon", ex.second - 3, ex.second, "0", attr_t2);
+                    }
+                    used += ex.second - ex.first;
+                }
+            }
             // ---- soft-masked stretch (test-only): case changes only
             if (cfg.softmask_rate > 0 && rng.uni() < cfg.softmask_rate) {
                 const auto& ex = gexons[rng.below(gexons.size())];

@@ -19,6 +19,7 @@ struct SynthConfig {
     // fraction of SNV sites with a second ALT allele, fraction of genes with a lower-case (soft-masked) stretch
     double indel_rate = 0.0, multiallelic_rate = 0.0, softmask_rate = 0.0;
     double mate_rate = 0.0;    // fraction of reads followed by a second record with the same name and start
+    double isoform_rate = 0.0; // fraction of genes with a second coding transcript (a prefix of the exons)
 };
 
 struct Dataset {

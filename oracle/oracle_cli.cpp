@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
                 else if (a == "--window-len") wl = std::stoull(val());
                 else if (a == "--read-len") cfg.read_len = uint32_t(std::stoul(val()));
                 else if (a == "--mate-rate") cfg.mate_rate = std::stod(val());
+                else if (a == "--isoform-rate") cfg.isoform_rate = std::stod(val());
                 else if (a == "--genes") { std::string v = val(); size_t c = v.find(':'); lo = std::stoull(v.substr(0, c)); hi = std::stoull(v.substr(c + 1)); }
                 else if (a == "--stats") stats = val();
                 else if (a == "--prefix") prefix = val();

@@ -1,5 +1,5 @@
 """Re-run one case of tools/fuzz_vs_oracle.py gene by gene and report the genes whose output differs or fails.
-  python tools/dbg_fuzz_case.py mode seed n depth spacing indel multi soft wl [read_len [mate_rate]]
+  python tools/dbg_fuzz_case.py mode seed n depth spacing indel multi soft wl [read_len [mate_rate [isoform_rate]]]
 """
 import json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,14 +9,15 @@ ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 mode, seed, n, depth, spacing, indel, multi, soft, wl = sys.argv[1:10]
 rl = sys.argv[10] if len(sys.argv) > 10 else "101"
 mate = sys.argv[11] if len(sys.argv) > 11 else "0"
+iso = sys.argv[12] if len(sys.argv) > 12 else "0"
 tmp = tempfile.mkdtemp(prefix="mpdbg")
 ctx = m.Context(0)
-ds = ctx.synth(int(seed), int(n), float(depth), float(spacing), indel_rate=float(indel), multiallelic_rate=float(multi), softmask_rate=float(soft), read_len=int(rl), mate_rate=float(mate))
+ds = ctx.synth(int(seed), int(n), float(depth), float(spacing), indel_rate=float(indel), multiallelic_rate=float(multi), softmask_rate=float(soft), read_len=int(rl), mate_rate=float(mate), isoform_rate=float(iso))
 md = m.MODE_SOMATIC if mode == "somatic" else m.MODE_NORMAL
 for g in range(ds.num_genes):
     prefix = os.path.join(tmp, "g%d" % g)
     r = subprocess.run([ORACLE_CLI, "synth", "--mode", mode, "--seed", seed, "--transcripts", n, "--depth", depth, "--spacing", spacing,
-                        "--indel-rate", indel, "--multiallelic-rate", multi, "--softmask-rate", soft, "--window-len", wl, "--read-len", rl, "--mate-rate", mate, "--skip-panics",
+                        "--indel-rate", indel, "--multiallelic-rate", multi, "--softmask-rate", soft, "--window-len", wl, "--read-len", rl, "--mate-rate", mate, "--isoform-rate", iso, "--skip-panics",
                         "--genes", "%d:%d" % (g, g + 1), "--prefix", prefix], capture_output=True)
     st = json.loads(r.stdout) if r.returncode == 0 else None
     try:

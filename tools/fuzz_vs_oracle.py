@@ -33,14 +33,15 @@ def make_case(k):
     rl = rng.choice([101, 101, 101, 76, 151, 250])   # 250-nt reads at 1.35-nt spacing span > 128 variants (four mask words)
     if rl > 101 and mode == "normal": depth = min(depth, 12)
     mate = rng.choice([0, 0, 0.15])   # same-name records starting at the same position: the `contains` rule
-    return dict(seed=first + k, mode=mode, n=n, depth=depth, spacing=spacing, indel=indel, multi=multi, soft=soft, wl=wl, rl=rl, mate=mate)
+    iso = rng.choice([0, 0, 0.5])     # genes with a second coding transcript
+    return dict(seed=first + k, mode=mode, n=n, depth=depth, spacing=spacing, indel=indel, multi=multi, soft=soft, wl=wl, rl=rl, mate=mate, iso=iso)
 
 
 def run_oracle(c):
     prefix = os.path.join(tmp, "o%d" % c["seed"])
     cmd = [ORACLE_CLI, "synth", "--mode", c["mode"], "--seed", str(c["seed"]), "--transcripts", str(c["n"]), "--depth", str(c["depth"]),
            "--spacing", str(c["spacing"]), "--indel-rate", str(c["indel"]), "--multiallelic-rate", str(c["multi"]),
-           "--softmask-rate", str(c["soft"]), "--window-len", str(c["wl"]), "--read-len", str(c["rl"]), "--mate-rate", str(c["mate"]), "--skip-panics", "--prefix", prefix]
+           "--softmask-rate", str(c["soft"]), "--window-len", str(c["wl"]), "--read-len", str(c["rl"]), "--mate-rate", str(c["mate"]), "--isoform-rate", str(c["iso"]), "--skip-panics", "--prefix", prefix]
     r = subprocess.run(cmd, capture_output=True)
     if r.returncode != 0:
         return None, "oracle failed: " + r.stderr.decode()[-300:]
@@ -55,7 +56,7 @@ def run_oracle(c):
 
 def run_engine(ctx, c, skipped):
     mode = m.MODE_SOMATIC if c["mode"] == "somatic" else m.MODE_NORMAL
-    ds = ctx.synth(c["seed"], c["n"], float(c["depth"]), c["spacing"], indel_rate=c["indel"], multiallelic_rate=c["multi"], softmask_rate=c["soft"], read_len=c["rl"], mate_rate=c["mate"])
+    ds = ctx.synth(c["seed"], c["n"], float(c["depth"]), c["spacing"], indel_rate=c["indel"], multiallelic_rate=c["multi"], softmask_rate=c["soft"], read_len=c["rl"], mate_rate=c["mate"], isoform_rate=c["iso"])
     parts, windows, lo, notes = [], 0, 0, []
     for g in skipped + [ds.num_genes]:
         if g > lo:
