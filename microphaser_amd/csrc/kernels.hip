@@ -688,6 +688,7 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
 }
 
 constexpr uint32_t K2W_ITEMS = 4;
+constexpr uint32_t K2W_HIST_BITS = 6;   // windows with at most this many columns count their haplotypes in a 64-entry LDS table
 __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
     constexpr uint32_t GROUP_CHUNK = 64, REC_CHUNK_W = 64;   // small chunks: 64 allocators share the atomics, and the unused
                                                              // tail of a wave's last chunk is all the slack K3 has to skip
@@ -700,6 +701,8 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
     const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_hi = uint64_t(part + 1) << d.rec_part_log2;
     uint64_t chunk_pos = 0, chunk_end = 0, rec_pos = 0, rec_end = 0;
     uint32_t sticky_err = 0;
+    __shared__ __attribute__((aligned(16))) uint32_t hist[256];
+    __shared__ uint2 glist[64];
     // a wave takes K2W_ITEMS consecutive work items, so that one chunk tail is shared by ~100+ windows
     for (uint32_t item = blockIdx.x * K2W_ITEMS; item < min(d.n_wchunks, (blockIdx.x + 1) * K2W_ITEMS); item++) {
     const WChunk C = d.wchunks[item];
@@ -787,23 +790,62 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
             // ---- count phase of print_haplotypes (:383-411), as in k2_window_replay<1>
             const uint32_t nrows = __popcll(__ballot(row));
             const bool has_zero = __ballot(act && hap == 0) != 0;
-            uint32_t ng = has_zero ? 0u : 1u;   // lane 0 = zero-count reference haplotype
+            uint32_t ng;
             const bool need_all = (sflags & SF_NEED_RECS) != 0;
-            uint32_t khi_s = 0, klo_s = 0, cnt_s = 0;
-            const uint32_t my_hi = uint32_t(hap >> 32), my_lo = uint32_t(hap);
-            uint64_t rem = __ballot(act);
-            while (rem) {
-                const uint32_t l = __builtin_ctzll(rem);
-                const uint32_t kh = rdlane(my_hi, l), kl = rdlane(my_lo, l);
-                const uint64_t m = __ballot(act && my_hi == kh && my_lo == kl);
-                rem &= ~m;
-                if (lane == ng) { khi_s = kh; klo_s = kl; cnt_s = uint32_t(__popcll(m)); }
-                ng++;
-            }
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < ng; j++) {
-                const uint32_t oh = rdlane(khi_s, j), ol = rdlane(klo_s, j);
-                rank += (oh < khi_s || (oh == khi_s && ol < klo_s)) ? 1u : 0u;
+            uint32_t khi_s = 0, klo_s = 0, cnt_s = 0, rank = 0;
+            bool on;
+            if (ncols <= K2W_HIST_BITS) {
+                // few columns (the common case): the key space fits the wave - one LDS counter per key, lane k then owns key k,
+                // so the groups come out counted AND in ascending key order without any search. Key 0 (the reference haplotype)
+                // is always listed, with count 0 if no row carries it (:429-431).
+                hist[lane] = 0;
+                __syncthreads();
+                if (act) atomicAdd(&hist[uint32_t(hap)], 1u);
+                __syncthreads();
+                cnt_s = hist[lane];
+                on = cnt_s != 0 || lane == 0;
+                const uint64_t pm = __ballot(on);
+                ng = uint32_t(__popcll(pm));
+                rank = lanes_below(pm, lane);
+                klo_s = lane;
+            } else if (ncols <= K2W_HIST_BITS + 2) {
+                // up to 256 keys: four counters per lane (keys 4 * lane .. 4 * lane + 3, still ascending), then the present ones are
+                // compacted through LDS so that lane i holds the i-th group (at most 64: a window has at most 63 rows here)
+                uint4* const hist4 = reinterpret_cast<uint4*>(hist);
+                hist4[lane] = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+                if (act) atomicAdd(&hist[uint32_t(hap)], 1u);
+                __syncthreads();
+                const uint4 c = hist4[lane];
+                const bool p0 = c.x != 0 || lane == 0, p1 = c.y != 0, p2 = c.z != 0, p3 = c.w != 0;
+                const uint64_t m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
+                ng = uint32_t(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                uint32_t at = lanes_below(m0, lane) + lanes_below(m1, lane) + lanes_below(m2, lane) + lanes_below(m3, lane);
+                if (p0) { glist[at] = make_uint2(4 * lane, c.x); at++; }
+                if (p1) { glist[at] = make_uint2(4 * lane + 1, c.y); at++; }
+                if (p2) { glist[at] = make_uint2(4 * lane + 2, c.z); at++; }
+                if (p3) { glist[at] = make_uint2(4 * lane + 3, c.w); }
+                __syncthreads();
+                on = lane < ng;
+                if (on) { const uint2 g2 = glist[lane]; klo_s = g2.x; cnt_s = g2.y; }
+                rank = lane;
+            } else {
+                ng = has_zero ? 0u : 1u;   // lane 0 = zero-count reference haplotype
+                const uint32_t my_hi = uint32_t(hap >> 32), my_lo = uint32_t(hap);
+                uint64_t rem = __ballot(act);
+                while (rem) {
+                    const uint32_t l = __builtin_ctzll(rem);
+                    const uint32_t kh = rdlane(my_hi, l), kl = rdlane(my_lo, l);
+                    const uint64_t m = __ballot(act && my_hi == kh && my_lo == kl);
+                    rem &= ~m;
+                    if (lane == ng) { khi_s = kh; klo_s = kl; cnt_s = uint32_t(__popcll(m)); }
+                    ng++;
+                }
+                for (uint32_t j = 0; j < ng; j++) {
+                    const uint32_t oh = rdlane(khi_s, j), ol = rdlane(klo_s, j);
+                    rank += (oh < khi_s || (oh == khi_s && ol < klo_s)) ? 1u : 0u;
+                }
+                on = lane < ng;
             }
             // group slots: exactly ng, from this wave's current chunk
             uint32_t werr = sticky_err;
@@ -819,7 +861,6 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
             if (!can_write) werr |= WD_GROUP_OVERFLOW;
             const uint64_t gbase = chunk_pos;
             {
-                const bool on = lane < ng;
                 const uint64_t key = (uint64_t(khi_s) << 32) | klo_s;
                 const bool need = on && can_write && (need_all || (key & som_mask) != 0);
                 const uint64_t nm = __ballot(need);

@@ -444,7 +444,7 @@ static void route_window_parallel(Batch& b) {
         const uint32_t ei = uint32_t(b.exons_w.size());
         b.exons_w.push_back(e);
         for (uint32_t k0 = 0; k0 < e.n_reads; k0 += 64) b.achunks.push_back(WChunk{ei, k0, std::min(64u, e.n_reads - k0), 0});
-        const bool multi = si.max_rn > 64 || b.mask_words > 1;   // needs several reads per lane / two mask words
+        const bool multi = si.max_rn > 63 || b.mask_words > 1;   // needs several reads per lane / two mask words (63: rows + the reference haplotype fit 64 lanes)
         if (multi) max_rn_multi = std::max(max_rn_multi, si.max_rn);
         // deep windows cost ~RPL x more each and there are few of them: smaller work items keep the chip full
         const uint32_t chunk = multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
