@@ -452,11 +452,188 @@ std::vector<std::string> split(const std::string& s, char d) {
 }  // namespace
 
 // The text is cut at line ends into one piece per host thread; the pieces are parsed concurrently and joined in file order.
+namespace {
+// Plain gzip (one or more members, not BGZF): sequential zlib inflate.
+PodVec<uint8_t> gunzip_all(const PodVec<uint8_t>& f) {
+    PodVec<uint8_t> out;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) throw Error("inflateInit2 failed");
+    if (f.size() > 0x7FFFFFFFull) { inflateEnd(&zs); throw Error("gzip input larger than 2 GiB is not supported: compress with bgzip"); }
+    zs.next_in = const_cast<Bytef*>(f.data());
+    zs.avail_in = uInt(f.size());
+    std::vector<uint8_t> chunk(size_t(4) << 20);
+    for (;;) {
+        zs.next_out = chunk.data();
+        zs.avail_out = uInt(chunk.size());
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
+        if (rc == Z_STREAM_END) {
+            if (zs.avail_in == 0) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); throw Error("inflateReset failed"); }   // next member
+            continue;
+        }
+        if (rc != Z_OK) { inflateEnd(&zs); throw Error("gzip inflate failed"); }
+        if (zs.avail_in == 0 && zs.avail_out != 0) { inflateEnd(&zs); throw Error("truncated gzip stream"); }
+    }
+    inflateEnd(&zs);
+    return out;
+}
+
+// BCF2 (what `bcf::Reader` reads besides VCF text; the reference's CLI help names both): typed values per the VCF/BCF
+// specification section 6. Only the fields Variant::new looks at are decoded (src/common.rs:38-147): CHROM, POS, alleles,
+// INFO/SOMATIC (flag), INFO/ANN (string), INFO/SVLEN (integers).
+struct BcfCursor {
+    const uint8_t* p; const uint8_t* end;
+    void need(size_t n) const { if (size_t(end - p) < n) throw Error("truncated BCF record"); }
+    uint8_t u8() { need(1); return *p++; }
+    uint32_t u32() { need(4); uint32_t v = rd32(p); p += 4; return v; }
+    int64_t int_of(int type) {   // one integer of the given width; missing / end-of-vector -> INT64_MIN
+        switch (type) {
+            case 1: { int8_t v = int8_t(u8()); return (v == INT8_MIN || v == INT8_MIN + 1) ? INT64_MIN : v; }
+            case 2: { need(2); int16_t v = int16_t(rd16(p)); p += 2; return (v == INT16_MIN || v == INT16_MIN + 1) ? INT64_MIN : v; }
+            case 3: { int32_t v = int32_t(u32()); return (v == INT32_MIN || v == INT32_MIN + 1) ? INT64_MIN : v; }
+            default: throw Error("malformed BCF: integer expected");
+        }
+    }
+    void descriptor(int& type, size_t& len) {   // typed-value header: low nibble type, high nibble length (15 = typed integer follows)
+        const uint8_t d = u8();
+        type = d & 0xF;
+        len = d >> 4;
+        if (len == 15) {
+            int t2; size_t l2;
+            descriptor(t2, l2);
+            const int64_t v = int_of(t2);
+            if (l2 != 1 || v < 0) throw Error("malformed BCF: bad vector length");
+            len = size_t(v);
+        }
+    }
+    static size_t width(int type) {
+        switch (type) { case 0: return 0; case 1: return 1; case 2: return 2; case 3: return 4; case 5: return 4; case 7: return 1; default: throw Error("malformed BCF: unknown value type"); }
+    }
+    std::string str() {
+        int t; size_t n;
+        descriptor(t, n);
+        if (n == 0) return std::string();
+        if (t != 7) throw Error("malformed BCF: string expected");
+        need(n);
+        std::string v(reinterpret_cast<const char*>(p), n);
+        p += n;
+        while (!v.empty() && v.back() == 0) v.pop_back();
+        return v;
+    }
+    void skip_value() { int t; size_t n; descriptor(t, n); need(n * width(t)); p += n * width(t); }
+};
+
+void load_bcf(const PodVec<uint8_t>& buf, VcfData& out) {
+    if (buf.size() < 9 || buf[3] != 2) throw Error("unsupported BCF version (BCF2 expected)");
+    const uint32_t l_text = rd32(buf.data() + 5);
+    if (buf.size() < 9 + size_t(l_text)) throw Error("truncated BCF header");
+    std::string text(reinterpret_cast<const char*>(buf.data() + 9), l_text);
+    while (!text.empty() && text.back() == 0) text.pop_back();
+    // dictionaries: strings = FILTER / INFO / FORMAT ids (PASS first unless IDX says otherwise), contigs = ##contig lines
+    std::vector<std::string> strings, contigs;
+    auto put = [](std::vector<std::string>& d, size_t idx, const std::string& v) { if (d.size() <= idx) d.resize(idx + 1); d[idx] = v; };
+    bool explicit_pass = false;
+    size_t next_str = 1, next_ctg = 0;   // implicit numbering when the header carries no IDX (0 = PASS)
+    put(strings, 0, "PASS");
+    std::map<std::string, size_t> seen;
+    size_t a = 0;
+    while (a < text.size()) {
+        size_t e = text.find('\n', a);
+        if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(a, e - a);
+        a = e + 1;
+        const bool is_ctg = line.rfind("##contig=<", 0) == 0;
+        const bool is_str = line.rfind("##INFO=<", 0) == 0 || line.rfind("##FILTER=<", 0) == 0 || line.rfind("##FORMAT=<", 0) == 0;
+        if (!is_ctg && !is_str) continue;
+        auto field = [&](const char* key) -> std::string {
+            const std::string k = std::string(key) + "=";
+            size_t q = line.find("<" + k);
+            if (q == std::string::npos) q = line.find("," + k);
+            if (q == std::string::npos) return std::string();
+            q += 1 + k.size();
+            const size_t r = line.find_first_of(",>", q);
+            return line.substr(q, r == std::string::npos ? std::string::npos : r - q);
+        };
+        const std::string id = field("ID"), idx = field("IDX");
+        if (id.empty()) continue;
+        if (is_ctg) {
+            put(contigs, idx.empty() ? next_ctg : size_t(std::strtoull(idx.c_str(), nullptr, 10)), id);
+            next_ctg = contigs.size();
+        } else {
+            if (id == "PASS") { explicit_pass = true; if (!idx.empty()) put(strings, size_t(std::strtoull(idx.c_str(), nullptr, 10)), id); continue; }
+            auto it = seen.find(id);   // one id may be declared as INFO and FORMAT: same dictionary entry
+            if (it != seen.end()) continue;
+            const size_t at = idx.empty() ? next_str : size_t(std::strtoull(idx.c_str(), nullptr, 10));
+            put(strings, at, id);
+            seen[id] = at;
+            next_str = std::max(next_str, at) + 1;
+        }
+    }
+    (void)explicit_pass;
+    out.contigs = contigs;
+    const uint8_t* p = buf.data() + 9 + l_text;
+    const uint8_t* const end = buf.data() + buf.size();
+    while (p < end) {
+        if (size_t(end - p) < 8) throw Error("truncated BCF record");
+        const uint32_t l_shared = rd32(p), l_indiv = rd32(p + 4);
+        p += 8;
+        if (size_t(end - p) < size_t(l_shared) + l_indiv) throw Error("truncated BCF record");
+        BcfCursor c{p, p + l_shared};
+        p += size_t(l_shared) + l_indiv;
+        const int32_t chrom = int32_t(c.u32());
+        const int32_t pos = int32_t(c.u32());
+        c.u32();   // rlen
+        c.u32();   // QUAL
+        const uint32_t nai = c.u32();
+        const uint32_t n_info = nai & 0xFFFF, n_allele = nai >> 16;
+        c.u32();   // n_fmt << 24 | n_sample
+        c.str();   // ID
+        if (chrom < 0 || size_t(chrom) >= contigs.size() || contigs[size_t(chrom)].empty()) throw Error("BCF record refers to a contig that is not in the header");
+        VcfRecord r;
+        r.chrom = contigs[size_t(chrom)];
+        r.pos = uint64_t(pos);
+        for (uint32_t k = 0; k < n_allele; k++) {
+            std::string al = c.str();
+            if (k == 0) r.ref = std::move(al); else r.alts.push_back(std::move(al));
+        }
+        c.skip_value();   // FILTER
+        for (uint32_t k = 0; k < n_info; k++) {
+            int kt; size_t kn;
+            c.descriptor(kt, kn);
+            if (kn != 1) throw Error("malformed BCF: INFO key");
+            const int64_t key = c.int_of(kt);
+            const std::string* name = (key >= 0 && size_t(key) < strings.size()) ? &strings[size_t(key)] : nullptr;
+            if (name && *name == "SOMATIC") { r.somatic = true; c.skip_value(); }
+            else if (name && *name == "ANN") {
+                const std::string v = c.str();
+                const size_t cm = v.find(',');
+                r.ann_first = cm == std::string::npos ? v : v.substr(0, cm);
+            } else if (name && *name == "SVLEN") {
+                int t; size_t n;
+                c.descriptor(t, n);
+                r.has_svlen = true;
+                for (size_t q = 0; q < n; q++) r.svlen.push_back(c.int_of(t));
+            } else c.skip_value();
+        }
+        out.records.push_back(std::move(r));
+    }
+}
+}  // namespace
+
 void load_vcf(const std::string& path, VcfData& out) {
     FileBytes fb(path);
-    const PodVec<uint8_t>& buf = fb.data;
     out.contigs.clear();
     out.records.clear();
+    // bcf::Reader::from_path accepts VCF text, bgzip / gzip compressed VCF and BCF (htslib detects the format from the bytes)
+    if (fb.data.size() >= 2 && fb.data[0] == 31 && fb.data[1] == 139) {
+        const bool bgzf = fb.data.size() >= 18 && (fb.data[3] & 4) && fb.data[12] == 'B' && fb.data[13] == 'C';
+        PodVec<uint8_t> plain = bgzf ? bgzf_inflate_all(fb.data) : gunzip_all(fb.data);
+        fb.data.swap(plain);
+    }
+    if (fb.data.size() >= 5 && std::memcmp(fb.data.data(), "BCF", 3) == 0) { load_bcf(fb.data, out); return; }
+    const PodVec<uint8_t>& buf = fb.data;
     const size_t nt = std::max<size_t>(1, std::min(io_threads(32), buf.size() >> 20));
     std::vector<size_t> cut(nt + 1, buf.size());
     cut[0] = 0;

@@ -26,6 +26,20 @@ def test_gpu_matches_reference_expected_output(ctx, name):
     assert res.tsv == exp["tsv"]
 
 
+def test_gpu_variants_as_bcf_and_bgzf(ctx, tmp_path):
+    """The product loader shares the format detection with the oracle CLI (tests/test_oracle_fixtures.py): BCF2 and bgzip'ed VCF in,
+    the reference's expected output out."""
+    import vcf_formats as vf
+    p = fixture_paths("test_reverse")
+    text = open(p["vcf"], "rb").read()
+    exp = read_expected(p["expected"])
+    for fn, data in (("v.bcf", vf.bgzf_bytes(vf.vcf_to_bcf(text, True))), ("v.vcf.gz", vf.bgzf_bytes(text))):
+        path = str(tmp_path / fn)
+        open(path, "wb").write(data)
+        res = ctx.load(p["bam"], path, p["fasta"], p["gtf"]).phase()
+        assert (res.fasta, res.normal_fasta, res.tsv) == (exp["fa"], exp["normal.fa"], exp["tsv"])
+
+
 def test_gpu_empty_vcf(ctx):
     p = fixture_paths("test_forward")
     res = ctx.load(p["bam"], os.path.join(GOLDEN, "test_empty", "empty_test.vcf"), p["fasta"], p["gtf"]).phase()

@@ -84,3 +84,22 @@ def test_filter_oracle_matches_reference_expected_output(built, tmp_path, name):
     assert r.stdout == open(os.path.join(exp, "tumor.%s.fa" % stem), "rb").read()
     assert (tmp_path / "o.normal.fa").read_bytes() == open(os.path.join(exp, "normal.%s.fa" % stem), "rb").read()
     assert (tmp_path / "o.tsv").read_bytes() == open(os.path.join(exp, "info.%s.tsv" % stem), "rb").read()
+
+
+@pytest.mark.parametrize("encoding", ["gzip", "bgzf", "bcf_idx", "bcf_implicit"])
+@pytest.mark.parametrize("name", ["test_reverse", "splice_forward_test"])
+def test_variants_file_may_be_gzip_bgzf_or_bcf(built, tmp_path, name, encoding):
+    """`bcf::Reader::from_path` (src/main.rs:75) takes VCF text, compressed VCF and BCF alike. The fixture VCF (multi-allelic record,
+    SOMATIC flags, ANN strings) re-encoded by tests/vcf_formats.py - an independent writer from the specification - must give the
+    reference's expected output unchanged. The reference ships no compressed / BCF fixture, so the BCF reader is pinned by this only."""
+    import vcf_formats as vf
+    p = dict(fixture_paths(name))
+    text = open(p["vcf"], "rb").read()
+    data = {"gzip": lambda: vf.gzip_bytes(text), "bgzf": lambda: vf.bgzf_bytes(text),
+            "bcf_idx": lambda: vf.bgzf_bytes(vf.vcf_to_bcf(text, True)), "bcf_implicit": lambda: vf.bgzf_bytes(vf.vcf_to_bcf(text, False))}[encoding]()
+    p["vcf"] = str(tmp_path / ("v.bcf" if encoding.startswith("bcf") else "v.vcf.gz"))
+    open(p["vcf"], "wb").write(data)
+    got = run_oracle_files(p, str(tmp_path))
+    exp = read_expected(p["expected"])
+    for ext in ("fa", "normal.fa", "tsv"):
+        assert got[ext] == exp[ext], "%s.%s differs with the variants as %s" % (name, ext, encoding)
