@@ -175,6 +175,7 @@ def main():
             "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm)},
             "hbm_resident_bytes": int(st.hbm_bytes),
             "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "d2h_consume_s": None if args.no_consume else t_consume,
+                           "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),
                            "note": "host legs of rank 0 (planner and consumer shard genes over host threads); not part of `value`"},
         }
         if world == 1 and args.cpu_sample > 0:

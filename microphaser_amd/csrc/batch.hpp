@@ -2,6 +2,7 @@
 // from the per-gene inputs phase_gene would load (reference: src/microphasing.rs:895-942).
 #pragma once
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "model.hpp"
@@ -72,6 +73,9 @@ struct Batch {
     PodVec<WChunk> achunks;              // admission work items: (exon, first read, count <= 64)
     uint64_t n_adm = 0;                   // AdmEntry count (sum of ExonW::n_reads)
     PodVec<uint64_t> v_sombits;      // bit (variant index in the batch) set <=> somatic
+    // transcripts whose speculative schedule ran into a failure: (index into tx, message); the plan stops before that step and the
+    // consumer raises the message only if the real walk reaches it
+    std::vector<std::pair<uint32_t, std::string>> tx_errors;
     // ---- sizing
     uint32_t seq_cap = 48;                // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks

@@ -142,10 +142,16 @@ struct ConsumerHooks {
     bool is_fwd;
 
     void on_exon(const ExonGeom&) {}
+    void begin_step() {}
     void routed(bool) {}
 
     void on_step(const ExonGeom&, const StepGeom& sg, const std::vector<size_t>&) {
-        if (next_step >= T.n_steps) throw Error("internal error: consumer walked past the planned schedule");
+        if (next_step >= T.n_steps) {
+            const uint32_t ti = uint32_t(&T - b.tx.data());
+            for (const auto& te : b.tx_errors)
+                if (te.first == ti) throw Error(te.second);   // the schedule stopped here for this reason, and the real walk got here
+            throw Error("internal error: consumer walked past the planned schedule");
+        }
         cur_step = T.step_off + next_step++;
         const Step& st = b.steps[cur_step];
         if (st.sso != uint32_t(sg.sso) || uint64_t(st.wlen) != sg.splice_end - sg.sso)
@@ -531,10 +537,16 @@ struct NormalConsumerHooks {
     bool is_fwd;
 
     void on_exon(const ExonGeom&) {}
+    void begin_step() {}
     void routed(bool) {}
 
     void on_step(const ExonGeom&, const StepGeom& sg, const std::vector<size_t>&) {
-        if (next_step >= T.n_steps) throw Error("internal error: consumer walked past the planned schedule");
+        if (next_step >= T.n_steps) {
+            const uint32_t ti = uint32_t(&T - b.tx.data());
+            for (const auto& te : b.tx_errors)
+                if (te.first == ti) throw Error(te.second);   // the schedule stopped here for this reason, and the real walk got here
+            throw Error("internal error: consumer walked past the planned schedule");
+        }
         cur_step = T.step_off + next_step++;
         const Step& st = b.steps[cur_step];
         if (st.sso != uint32_t(sg.sso) || uint64_t(st.wlen) != sg.splice_end - sg.sso)

@@ -69,7 +69,21 @@ struct PlannerHooksT {
 
     uint32_t tr_index(size_t fwd_idx) const { return is_fwd ? uint32_t(fwd_idx) : fwd2rev[fwd_idx]; }
 
+    // The schedule is speculative: it keeps walking where the real run may already have stopped (a stop codon ends a transcript, a
+    // shifted ORF dies). A condition under which the reference would panic - or a limit of this build - met out there must not fail
+    // the batch: the plan of the transcript is cut back to its last complete step and the message kept; the consumer raises it only
+    // if the real walk gets that far (consume.cpp on_step).
+    struct Mark { size_t steps, aux, ncols, rlo, rn, wins, win_cols; uint64_t n_main; } mark{};
+    void take_mark() { mark = Mark{b.steps.size(), b.step_aux.size(), b.step_ncols.size(), b.step_rlo.size(), b.step_rn.size(), b.wins.size(), b.win_cols.size(), b.n_main_windows}; }
+    void begin_step() { take_mark(); }
+    void rollback() {
+        b.steps.resize(mark.steps); b.step_aux.resize(mark.aux); b.step_ncols.resize(mark.ncols); b.step_rlo.resize(mark.rlo); b.step_rn.resize(mark.rn);
+        b.wins.resize(mark.wins); b.win_cols.resize(mark.win_cols); b.n_main_windows = mark.n_main;
+        if (seg_start != 0xFFFFFFFFu && seg_start > b.steps.size()) seg_start = uint32_t(b.steps.size());
+    }
+
     void on_exon(const ExonGeom& eg) {
+        take_mark();
         ExonPlan ep;
         ep.geom = eg;
         ep.tx = tx_idx;
@@ -210,7 +224,18 @@ struct PlannerHooksT {
                     rows_may_survive = seg_low_key <= sg.sso && read_lower(seg_low_key) < read_lower(sg.sso + 1);
                 }
                 if (std::getenv("MP_DEBUG_SEG")) std::fprintf(stderr, "seg? tx %u %s sso %llu end %llu cols %zu del %zu last_sso %llu low_key %llu survive %d\n", tx_idx, is_fwd ? "+" : "-", (unsigned long long)sg.sso, (unsigned long long)sg.splice_end, cols.size(), sg.deleted, (unsigned long long)seg_last_sso, (unsigned long long)seg_low_key, int(rows_may_survive));
-                if (!rows_may_survive) {
+                // A segment that starts here is given its initial deque as "the init_cols columns right before this step's first new
+                // one" (SegDev::init_cols). The deque is a run of the append sequence, but that sequence can skip variants (no window
+                // of the previous exon reached them), so the run is not always consecutive in transcription order: then the wave
+                // has to carry its real columns across this exon start - no break.
+                bool init_contiguous = true;
+                {
+                    const uint32_t x = new_cols.empty() ? col_hi : tr_index(new_cols[0]);
+                    size_t k = 0;
+                    for (uint32_t c : cols) { if (uint64_t(tr_index(c)) + cols.size() != uint64_t(x) + k) init_contiguous = false; k++; }
+                }
+                if (!rows_may_survive && !init_contiguous && std::getenv("MP_DEBUG_SEG")) std::fprintf(stderr, "seg: tx %u sso %llu keeps its segment: live columns are not consecutive\n", tx_idx, (unsigned long long)sg.sso);
+                if (!rows_may_survive && init_contiguous) {
                     seg_info.n_exons--;   // this exon's on_exon() already counted itself on the segment being closed
                     b.segs.push_back(SegDev{tx_idx, seg_start, here - seg_start, seg_init_cols});
                     b.seg_info.push_back(seg_info);
@@ -610,7 +635,12 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
             }
             auto run = [&](auto& hooks) {
                 hooks.pmax_end = &pmax_end;
-                walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks);
+                hooks.take_mark();
+                try { walk_transcript(gi.gene, t, vi, gh.max_read_len, window_len, hooks); }
+                catch (const Error& e) {
+                    hooks.rollback();
+                    b.tx_errors.emplace_back(uint32_t(b.tx.size()), std::string(e.what()));
+                }
                 hooks.finish();
                 td.n_steps = uint32_t(b.steps.size()) - td.step_off;
                 b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
@@ -737,6 +767,7 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
     mt.add(b.seg_info, parts, &B::seg_info, [](Batch::SegInfo&, size_t) {});
     mt.add(b.exons, parts, &B::exons, [&o](ExonPlan& e, size_t t) { e.tx += uint32_t(o[t].t); });
     mt.add(b.str_pool, parts, &B::str_pool);
+    mt.add(b.tx_errors, parts, &B::tx_errors, [&o](std::pair<uint32_t, std::string>& x, size_t t) { x.first += uint32_t(o[t].t); });
     std::vector<std::function<void()>>& tasks = mt.run;
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;

@@ -70,6 +70,7 @@ struct VarIndex {
 //   void on_step(const ExonGeom&, const StepGeom&, const std::vector<size_t>& new_cols_fwd_idx);
 //       called once per step after the column delta is known (columns are appended in the given order)
 //   std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom&, const StepGeom&, uint64_t frame, FsFreq, bool is_first_exon_window);
+//   void begin_step();                   // top of every window-loop iteration (the previous step is complete)
 //   void routed(bool to_prev_hap_vec);   // which carry-over vector the last print's haplotypes went to
 //   void splice_merge(const ExonGeom&, const StepGeom&, uint64_t exon_rest, std::map<uint64_t,uint64_t>& frameshifts,
 //                     FsFreq&, std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec);
@@ -123,6 +124,7 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
         bool is_first_exon_window = true;
         hooks.on_exon(eg);
         for (;;) {
+            hooks.begin_step();   // everything of the previous step (prints, merge) is done
             if (frameshifts.empty()) break;
             bool valid = is_fwd ? offset + eg.ewl <= exon.end : offset >= exon.start;
             if (!valid) break;

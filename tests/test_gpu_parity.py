@@ -110,8 +110,10 @@ def test_gpu_matches_oracle_with_indels_multiallelic_and_softmasked_reference(ct
             parts.append(dict(fasta=r.fasta, normal_fasta=r.normal_fasta, tsv=r.tsv))
             windows += r.windows
         if g < ds.num_genes:
-            with pytest.raises(m.MicrophaserError):
-                b = ds.batch(gene_lo=g, gene_hi=g + 1)
+            with pytest.raises(m.MicrophaserError):   # at plan time or - when the failing step lies in the speculative part of the
+                b = ds.batch(gene_lo=g, gene_hi=g + 1)   # schedule - when the real walk reaches it
+                b.run()
+                b.results()
                 b.run()
                 b.results()
         lo = g + 1
@@ -258,6 +260,25 @@ def test_gpu_row_outliving_its_exon_is_not_admitted_twice(ctx, tmp_path):
     assert res.tsv == open(prefix + ".tsv", "rb").read()
     assert res.fasta == open(prefix + ".fa", "rb").read()
     assert res.tsv.count(b"\n") > 200
+
+
+def test_gpu_segment_with_non_consecutive_initial_columns(ctx, tmp_path):
+    """Found by tools/fuzz_vs_oracle.py (seed 720659, gene 53): a '-' exon starts with a stale frameshift column of the previous exon
+    in the deque (src/microphasing.rs:1159) while the variants between it and the exon's first window were never appended, so the
+    live columns are not consecutive in transcription order. A replay segment starting there cannot be given its initial deque as an
+    index range; the rows pushed at that first window must still see the stale column (frame.1 != 0 keeps them out of the shifted
+    ORF's counts, :395-399)."""
+    prefix = os.path.join(str(tmp_path), "o")
+    args = ["--seed", "720659", "--transcripts", "64", "--depth", "30", "--spacing", "2.0", "--indel-rate", "0.03", "--window-len", "33",
+            "--isoform-rate", "0.5"]
+    subprocess.run([ORACLE_CLI, "synth", *args, "--genes", "53:54", "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    ds = ctx.synth(720659, 64, 30.0, 2.0, indel_rate=0.03, isoform_rate=0.5)
+    b = ds.batch(window_len=33, gene_lo=53, gene_hi=54)
+    b.run()
+    res = b.results()
+    assert res.tsv == open(prefix + ".tsv", "rb").read()
+    assert res.fasta == open(prefix + ".fa", "rb").read()
+    assert res.tsv.count(b"\n") > 500
 
 
 # ------------------------------------------------------------------ the product CLI (src/cli.yaml surface): GTF on stdin, FASTA on stdout

@@ -30,6 +30,7 @@ def make_case(k):
     soft = rng.choice([0, 0, 0.4])
     wl = rng.choice([27, 27, 27, 33, 15, 21])
     n = rng.choice([8, 16]) if depth < 100 else 5
+    if os.environ.get("FUZZ_N") and depth < 100 and mode == "somatic": n = int(os.environ["FUZZ_N"])   # more genes per batch: more planner / consumer threads
     rl = rng.choice([101, 101, 101, 76, 151, 250])   # 250-nt reads at 1.35-nt spacing span > 128 variants (four mask words)
     if rl > 101 and mode == "normal": depth = min(depth, 12)
     mate = rng.choice([0, 0, 0.15])   # same-name records starting at the same position: the `contains` rule
@@ -84,7 +85,12 @@ with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 2)) as pool:
         if time.time() - t0 > budget:
             for g in futs: g.cancel()
             break
-        st, exp = f.result()
+        while True:   # heartbeat while a slow oracle case (deep `normal` exomes take minutes) is still running
+            try: st, exp = f.result(timeout=60); break
+            except TimeoutError: print("... waiting for the oracle on seed %d" % c["seed"], flush=True)
+            except Exception as e:
+                if type(e).__name__ != "TimeoutError": raise
+                print("... waiting for the oracle on seed %d" % c["seed"], flush=True)
         tag = " ".join("%s=%s" % kv for kv in c.items())
         if st is None:
             print("ORACLE-ERR", tag, exp, flush=True); bad += 1; continue
