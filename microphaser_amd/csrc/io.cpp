@@ -111,7 +111,7 @@ PodVec<uint8_t> bgzf_inflate_all(const PodVec<uint8_t>& f) {
     PodVec<uint8_t> out;
     out.resize(total);   // not touched here: the inflating threads first-touch their own blocks
     auto tB = std::chrono::steady_clock::now();
-    size_t nthreads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 16));
+    size_t nthreads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 32));
     if (const char* e = std::getenv("MP_THREADS")) nthreads = std::max<size_t>(1, size_t(std::atoi(e)));
     nthreads = std::min(nthreads, std::max<size_t>(1, blks.size() / 16));
     std::vector<std::string> errors(nthreads);
@@ -204,11 +204,18 @@ void load_bam(const std::string& path, BamData& out) {
     out.reads = ReadStore();
     ReadStore& rs = out.reads;
     std::vector<uint64_t> rec_at;   // buffer offset of every placed record (ref_id >= 0), file order
+    rec_at.reserve(buf.size() / 160);
     while (need(4)) {
         const uint32_t bs = rd32(buf.data() + cur);
         if (!need(4 + size_t(bs))) throw Error("truncated BAM record");
         if (bs < 32) throw Error("malformed BAM record");
         if (int32_t(rd32(buf.data() + cur + 4)) >= 0) rec_at.push_back(cur + 4);
+        // the hop is a dependent-load chain (next offset = this record's size); neighbouring records have similar sizes, so the
+        // header some records ahead can be prefetched by extrapolation, which turns the chain from latency- into bandwidth-bound
+        {
+            const size_t ahead = cur + 24 * (4 + size_t(bs));
+            if (ahead + 64 < buf.size()) { __builtin_prefetch(buf.data() + ahead); __builtin_prefetch(buf.data() + ahead + 64); }
+        }
         cur += 4 + size_t(bs);
     }
     const auto t2 = clk();
