@@ -674,23 +674,46 @@ void load_vcf(const std::string& path, VcfData& out) {
                 }
                 continue;
             }
-            auto f = split(line, '\t');
-            if (f.size() < 8) throw Error("malformed VCF line: " + line);
-            VcfRecord r;
-            r.chrom = f[0];
-            r.pos = std::strtoull(f[1].c_str(), nullptr, 10) - 1;
-            r.ref = f[3];
-            r.alts = split(f[4], ',');
-            for (const auto& kv : split(f[7], ';')) {
-                if (kv == "SOMATIC") r.somatic = true;
-                else if (kv.rfind("ANN=", 0) == 0) {
-                    std::string v = kv.substr(4);
-                    size_t c = v.find(',');
-                    r.ann_first = c == std::string::npos ? v : v.substr(0, c);
-                } else if (kv.rfind("SVLEN=", 0) == 0) {
-                    r.has_svlen = true;
-                    for (const auto& x : split(kv.substr(6), ',')) r.svlen.push_back(x == "." ? INT64_MIN : std::atoll(x.c_str()));
+            // fields by position in the line (no per-field copies: the INFO column with its ANN string is most of the line)
+            const char* const lb = line.data();
+            const char* const le = lb + line.size();
+            const char* fb[8]; const char* fe[8];
+            {
+                const char* q = lb;
+                int nf = 0;
+                for (; nf < 8; nf++) {
+                    const char* t = static_cast<const char*>(std::memchr(q, '\t', size_t(le - q)));
+                    fb[nf] = q;
+                    fe[nf] = t ? t : le;
+                    if (!t) { nf++; break; }
+                    q = t + 1;
                 }
+                if (nf < 8) throw Error("malformed VCF line: " + line);
+            }
+            VcfRecord r;
+            r.chrom.assign(fb[0], fe[0]);
+            r.pos = std::strtoull(std::string(fb[1], fe[1]).c_str(), nullptr, 10) - 1;
+            r.ref.assign(fb[3], fe[3]);
+            for (const char* a = fb[4];;) {   // ALT, comma separated (an empty field is one empty allele, like split())
+                const char* c = static_cast<const char*>(std::memchr(a, ',', size_t(fe[4] - a)));
+                r.alts.emplace_back(a, c ? c : fe[4]);
+                if (!c) break;
+                a = c + 1;
+            }
+            for (const char* a = fb[7];;) {   // INFO, ';' separated
+                const char* c = static_cast<const char*>(std::memchr(a, ';', size_t(fe[7] - a)));
+                const char* e = c ? c : fe[7];
+                const size_t n = size_t(e - a);
+                if (n == 7 && std::memcmp(a, "SOMATIC", 7) == 0) r.somatic = true;
+                else if (n >= 4 && std::memcmp(a, "ANN=", 4) == 0) {
+                    const char* cm = static_cast<const char*>(std::memchr(a + 4, ',', n - 4));
+                    r.ann_first.assign(a + 4, cm ? cm : e);
+                } else if (n >= 6 && std::memcmp(a, "SVLEN=", 6) == 0) {
+                    r.has_svlen = true;
+                    for (const auto& x : split(std::string(a + 6, e), ',')) r.svlen.push_back(x == "." ? INT64_MIN : std::atoll(x.c_str()));
+                }
+                if (!c) break;
+                a = c + 1;
             }
             bool seen = false;
             for (const auto& c : pc.contigs) seen |= !c.second && c.first == r.chrom;
