@@ -205,6 +205,7 @@ struct ConsumerHooks {
             std::fclose(tf);
         }
         const char* strand = is_fwd ? "Forward" : "Reverse";
+        const std::string strand_s(strand);
         const bool has_frameshift = frame > 0;
         const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
         const uint64_t wl = eg.ewl;  // print_haplotypes' window_len parameter (:1421)
@@ -279,8 +280,6 @@ struct ConsumerHooks {
             const bool emit = emit_pre && frame_frequency > 0.0;
             HapSeq hs;
             if (boundary || emit) {
-                hs.filled = true;
-                IDRecord& r = hs.record;
                 std::string sites, som_pos, som_pc, germ_pos, germ_pc;
                 uint32_t n_sites = 0, n_som_sites = 0;
                 auto add = [](std::string& s, const std::string& x) { if (!s.empty()) s += "|"; s += x; };
@@ -304,45 +303,55 @@ struct ConsumerHooks {
                         if (!v.is_germline) n_som_sites++;
                     }
                 }
+                std::string idstr;
                 if (gs.flags & GS_ID_VALID) {
-                    char idb[20];
-                    std::snprintf(idb, sizeof idb, "%015llx%c", (unsigned long long)rec->id60, strand[0]);
-                    r.id = idb;
+                    static const char HEX[] = "0123456789abcdef";
+                    char idb[16];
+                    for (int k = 0; k < 15; k++) idb[k] = HEX[(rec->id60 >> (4 * (14 - k))) & 0xF];
+                    idb[15] = strand[0];
+                    idstr.assign(idb, 16);
                 } else {
-                    r.id = haplotype_id(rseq, seq_len, transcript.id, offset, strand[0]);
+                    idstr = haplotype_id(rseq, seq_len, transcript.id, offset, strand[0]);
                 }
-                r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
-                r.offset = splice_pos == 0 ? offset + 1 : offset + 1 + splice_gap;
-                r.frame = frame;
-                r.freq = frame_frequency;
-                r.depth = wd.nrows;
-                r.nvar = n_variants; r.nsomatic = n_somatic;
-                r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
-                r.strand = strand;
-                r.variant_sites = sites; r.somatic_positions = som_pos; r.somatic_aa_change = som_pc;
-                r.germline_positions = germ_pos; r.germline_aa_change = germ_pc;
-                r.normal_sequence = normal_peptide; r.mutant_sequence = neopeptide;
+                const uint64_t roffset = splice_pos == 0 ? offset + 1 : offset + 1 + splice_gap;
                 if (emit) {  // :839-875
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, r.id, rseq + splice_gap, seq_len - splice_gap);
+                        write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
-                        write_fasta(out.fasta, r.id, rseq, this_window_len);
+                        write_fasta(out.fasta, idstr, rseq, this_window_len);
                     }
                     if (germ_len != 0) {
                         if (splice_pos == 1) {
                             if (splice_gap > germ_len) throw Error("reference would panic: slice index out of range");
-                            write_fasta(out.normal_fasta, r.id, rgerm + splice_gap, germ_len - splice_gap);
+                            write_fasta(out.normal_fasta, idstr, rgerm + splice_gap, germ_len - splice_gap);
                         } else if (splice_pos == 0) {
                             if (this_window_len > germ_len) throw Error("reference would panic: slice index out of range");
-                            write_fasta(out.normal_fasta, r.id, rgerm, this_window_len);
+                            write_fasta(out.normal_fasta, idstr, rgerm, this_window_len);
                         }
                     }
-                    write_tsv_record(out, r);
+                    // the row is written field by field: only a window that feeds a splice-side merge needs the record itself
+                    write_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, roffset, frame, frame_frequency, wd.nrows, n_variants,
+                                     n_somatic, n_sites, n_som_sites, strand_s, sites, som_pos, som_pc, germ_pos, germ_pc, normal_peptide, neopeptide);
                 }
-                // the carried-over record holds the UNSLICED sequences (:807-832)
-                r.normal_sequence.assign(reinterpret_cast<const char*>(rgerm), germ_len);
-                r.mutant_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);
+                if (boundary) {
+                    hs.filled = true;
+                    IDRecord& r = hs.record;
+                    r.id = std::move(idstr);
+                    r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
+                    r.offset = roffset;
+                    r.frame = frame;
+                    r.freq = frame_frequency;
+                    r.depth = wd.nrows;
+                    r.nvar = n_variants; r.nsomatic = n_somatic;
+                    r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
+                    r.strand = strand_s;
+                    r.variant_sites = std::move(sites); r.somatic_positions = std::move(som_pos); r.somatic_aa_change = std::move(som_pc);
+                    r.germline_positions = std::move(germ_pos); r.germline_aa_change = std::move(germ_pc);
+                    // the carried-over record holds the UNSLICED sequences (:807-832)
+                    r.normal_sequence.assign(reinterpret_cast<const char*>(rgerm), germ_len);
+                    r.mutant_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);
+                }
             }
             if (!remove_peptide || frame == 0) haplotypes_vec.push_back(std::move(hs));  // :835-837
         }
@@ -566,6 +575,7 @@ struct NormalConsumerHooks {
         std::vector<const Variant*> variants(ncols);
         for (uint32_t j = 0; j < ncols; j++) variants[j] = &gvars[b.win_cols[ws.col_off + (is_fwd ? j : ncols - 1 - j)].f];
         const char* strand = is_fwd ? "Forward" : "Reverse";
+        const std::string strand_s(strand);
         const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
         const uint64_t wl = eg.ewl;
         const bool boundary = (ws.need_recs & WS_CARRY) != 0;
@@ -592,19 +602,23 @@ struct NormalConsumerHooks {
             const double freq = double(G.count) / double(nrows);  // NaN when no read covers the window
             HapSeq hs;
             if (boundary || !eg.is_short) {
-                hs.filled = true;
-                NormalRecord& r = hs.nrecord;
                 const uint64_t this_window_len = seq_len < wl ? seq_len : wl;
-                auto sl = [&](uint64_t a, uint64_t e) {
-                    if (a > e || e > seq_len) throw Error("reference would panic: slice index out of range");
-                    return std::string(reinterpret_cast<const char*>(rseq) + a, e - a);
-                };
-                std::string peptide = splice_pos == 1 ? sl(splice_gap, seq_len)
-                                      : splice_pos == 0 ? (insertion ? sl(0, seq_len) : sl(0, this_window_len)) : sl(0, seq_len);
+                auto check = [&](uint64_t a, uint64_t e) { if (a > e || e > seq_len) throw Error("reference would panic: slice index out of range"); };
+                uint64_t pep_lo, pep_hi;   // the peptide_sequence column: a slice of the haplotype sequence
+                if (splice_pos == 1) { pep_lo = splice_gap; pep_hi = seq_len; }
+                else if (splice_pos == 0) { pep_lo = 0; pep_hi = insertion ? seq_len : this_window_len; }
+                else { pep_lo = 0; pep_hi = seq_len; }
+                check(pep_lo, pep_hi);
                 if (!(gs.flags & GS_ID_VALID)) throw Error("internal error: haplotype id was not computed on the device");
-                char idb[20];
-                std::snprintf(idb, sizeof idb, "%015llx%c", (unsigned long long)rec->id60, strand[0]);
-                r.id = idb;
+                std::string idstr;
+                {
+                    static const char HEX[] = "0123456789abcdef";
+                    char idb[16];
+                    for (int k = 0; k < 15; k++) idb[k] = HEX[(rec->id60 >> (4 * (14 - k))) & 0xF];
+                    idb[15] = strand[0];
+                    idstr.assign(idb, 16);
+                }
+                std::string somatic_positions, somatic_aa_change, germline_positions, germline_aa_change, variant_sites;
                 auto add = [](std::string& s, const std::string& x, bool& first) { if (!first) s += "|"; s += x; first = false; };
                 bool f1 = true, f2 = true, f3 = true, f4 = true, f5 = true;
                 uint32_t n_sites = 0, n_som_sites = 0;
@@ -612,32 +626,41 @@ struct NormalConsumerHooks {
                     if (c >= rec->prof_len) break;
                     const Variant& v = *variants[c];
                     if ((rec->prof_set >> c) & 1) {
-                        if ((prof_som >> c) & 1) { add(r.somatic_positions, std::to_string(v.pos), f1); add(r.somatic_aa_change, v.prot_change, f2); }
-                        else { add(r.germline_positions, std::to_string(v.pos), f3); add(r.germline_aa_change, v.prot_change, f4); }
+                        if ((prof_som >> c) & 1) { add(somatic_positions, std::to_string(v.pos), f1); add(somatic_aa_change, v.prot_change, f2); }
+                        else { add(germline_positions, std::to_string(v.pos), f3); add(germline_aa_change, v.prot_change, f4); }
                     }
                     if (c == 0 || v.pos != variants[c - 1]->pos) {
                         n_sites++;
-                        add(r.variant_sites, std::to_string(v.pos), f5);
+                        add(variant_sites, std::to_string(v.pos), f5);
                         if (!v.is_germline) n_som_sites++;
                     }
                 }
-                r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
-                r.offset = offset; r.frame = frame; r.freq = freq; r.depth = nrows;
-                r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
-                r.strand = strand;
-                r.peptide_sequence = std::move(peptide);
                 if (!eg.is_short) {  // :629-644
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, r.id, rseq + splice_gap, seq_len - splice_gap);
+                        write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
                         if (wl > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, r.id, rseq, size_t(wl));
+                        write_fasta(out.fasta, idstr, rseq, size_t(wl));
                     }
-                    write_normal_tsv_record(out, r);
+                    write_normal_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, offset, frame, freq, nrows, rec->nvar, rec->nsom, n_sites,
+                                            n_som_sites, strand_s, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
+                                            germline_aa_change, reinterpret_cast<const char*>(rseq) + pep_lo, size_t(pep_hi - pep_lo));
                 }
-                hs.sequence.assign(rseq, rseq + seq_len);
-                r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);  // carried record: unsliced (:618-625)
+                {   // the record is kept for every window of a regular exon: `normal` merges reach further back than the planner's marks
+                    hs.filled = true;
+                    NormalRecord& r = hs.nrecord;
+                    r.id = std::move(idstr);
+                    r.somatic_positions = std::move(somatic_positions); r.somatic_aa_change = std::move(somatic_aa_change);
+                    r.germline_positions = std::move(germline_positions); r.germline_aa_change = std::move(germline_aa_change);
+                    r.variant_sites = std::move(variant_sites);
+                    r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
+                    r.offset = offset; r.frame = frame; r.freq = freq; r.depth = nrows;
+                    r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
+                    r.strand = strand_s;
+                    hs.sequence.assign(rseq, rseq + seq_len);
+                    r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);  // carried record: unsliced (:618-625)
+                }
             }
             haplotypes_vec.push_back(std::move(hs));
         }

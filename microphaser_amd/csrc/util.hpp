@@ -167,24 +167,39 @@ inline const char* idrecord_header() {
            "germline_aa_change\tnormal_sequence\tmutant_sequence\n";
 }
 
-// csv::Writer::serialize(IDRecord): header on first record only (reference: src/common.rs:350-373)
-inline void write_tsv_record(SomaticOutput& o, const IDRecord& r) {
+// csv::Writer::serialize(IDRecord): header on first record only (reference: src/common.rs:350-373). The field-wise form lets the
+// consumer write a row without building an IDRecord first (only windows that feed a splice-side merge need the record itself).
+inline void write_tsv_fields(SomaticOutput& o, const std::string& id, const std::string& transcript, const std::string& gene_id,
+                             const std::string& gene_name, const std::string& chrom, uint64_t offset, uint64_t frame, double freq, uint32_t depth,
+                             uint32_t nvar, uint32_t nsomatic, uint32_t nvariant_sites, uint32_t nsomvariant_sites, const std::string& strand,
+                             const std::string& variant_sites, const std::string& somatic_positions, const std::string& somatic_aa_change,
+                             const std::string& germline_positions, const std::string& germline_aa_change, const std::string& normal_sequence,
+                             const std::string& mutant_sequence) {
     std::string& t = o.tsv;
     if (!o.tsv_header_written) { t += idrecord_header(); o.tsv_header_written = true; }
     auto S = [&](const std::string& f) { tsv_field(t, f); t.push_back('\t'); };
-    auto U = [&](uint64_t v) { t += std::to_string(v); t.push_back('\t'); };
-    S(r.id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom);
-    U(r.offset); U(r.frame);
-    t += fmt_f64(r.freq); t.push_back('\t');
-    U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
-    S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change);
-    S(r.germline_positions); S(r.germline_aa_change); S(r.normal_sequence);
-    tsv_field(t, r.mutant_sequence);
+    auto U = [&](uint64_t v) { char b[24]; auto r = std::to_chars(b, b + sizeof b, v); t.append(b, r.ptr); t.push_back('\t'); };
+    S(id); S(transcript); S(gene_id); S(gene_name); S(chrom);
+    U(offset); U(frame);
+    t += fmt_f64(freq); t.push_back('\t');
+    U(depth); U(nvar); U(nsomatic); U(nvariant_sites); U(nsomvariant_sites);
+    S(strand); S(variant_sites); S(somatic_positions); S(somatic_aa_change);
+    S(germline_positions); S(germline_aa_change); S(normal_sequence);
+    tsv_field(t, mutant_sequence);
     t.push_back('\n');
+}
+inline void write_tsv_record(SomaticOutput& o, const IDRecord& r) {
+    write_tsv_fields(o, r.id, r.transcript, r.gene_id, r.gene_name, r.chrom, r.offset, r.frame, r.freq, r.depth, r.nvar, r.nsomatic, r.nvariant_sites,
+                     r.nsomvariant_sites, r.strand, r.variant_sites, r.somatic_positions, r.somatic_aa_change, r.germline_positions,
+                     r.germline_aa_change, r.normal_sequence, r.mutant_sequence);
 }
 
 // csv::Writer::serialize(normal_microphasing::IDRecord) (reference: src/normal_microphasing.rs:80-102)
-inline void write_normal_tsv_record(NormalOutput& o, const NormalRecord& r) {
+inline void write_normal_tsv_fields(NormalOutput& o, const std::string& id, const std::string& transcript, const std::string& gene_id,
+                                    const std::string& gene_name, const std::string& chrom, uint64_t offset, uint64_t frame, double freq, uint32_t depth,
+                                    uint32_t nvar, uint32_t nsomatic, uint32_t nvariant_sites, uint32_t nsomvariant_sites, const std::string& strand,
+                                    const std::string& variant_sites, const std::string& somatic_positions, const std::string& somatic_aa_change,
+                                    const std::string& germline_positions, const std::string& germline_aa_change, const char* peptide, size_t peptide_len) {
     std::string& t = o.tsv;
     if (!o.tsv_header_written) {
         t += "id\ttranscript\tgene_id\tgene_name\tchrom\toffset\tframe\tfreq\tdepth\tnvar\tnsomatic\tnvariant_sites\t"
@@ -193,15 +208,20 @@ inline void write_normal_tsv_record(NormalOutput& o, const NormalRecord& r) {
         o.tsv_header_written = true;
     }
     auto S = [&](const std::string& f) { tsv_field(t, f); t.push_back('\t'); };
-    auto U = [&](uint64_t v) { t += std::to_string(v); t.push_back('\t'); };
-    S(r.id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom);
-    U(r.offset); U(r.frame);
-    t += fmt_f64(r.freq); t.push_back('\t');
-    U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
-    S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change);
-    S(r.germline_positions); S(r.germline_aa_change);
-    tsv_field(t, r.peptide_sequence);
+    auto U = [&](uint64_t v) { char b[24]; auto r = std::to_chars(b, b + sizeof b, v); t.append(b, r.ptr); t.push_back('\t'); };
+    S(id); S(transcript); S(gene_id); S(gene_name); S(chrom);
+    U(offset); U(frame);
+    t += fmt_f64(freq); t.push_back('\t');
+    U(depth); U(nvar); U(nsomatic); U(nvariant_sites); U(nsomvariant_sites);
+    S(strand); S(variant_sites); S(somatic_positions); S(somatic_aa_change);
+    S(germline_positions); S(germline_aa_change);
+    tsv_field(t, std::string(peptide, peptide_len));
     t.push_back('\n');
+}
+inline void write_normal_tsv_record(NormalOutput& o, const NormalRecord& r) {
+    write_normal_tsv_fields(o, r.id, r.transcript, r.gene_id, r.gene_name, r.chrom, r.offset, r.frame, r.freq, r.depth, r.nvar, r.nsomatic, r.nvariant_sites,
+                            r.nsomvariant_sites, r.strand, r.variant_sites, r.somatic_positions, r.somatic_aa_change, r.germline_positions,
+                            r.germline_aa_change, r.peptide_sequence.data(), r.peptide_sequence.size());
 }
 
 }  // namespace mp

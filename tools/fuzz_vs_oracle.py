@@ -23,6 +23,7 @@ tmp = tempfile.mkdtemp(prefix="mpfuzz")
 
 def make_case(k):
     mode = rng.choice(["somatic", "somatic", "normal"])
+    if os.environ.get("FUZZ_MODE"): mode = os.environ["FUZZ_MODE"]
     depth = rng.choice([6, 15, 30, 30, 50, 90, 160]) if mode == "somatic" else rng.choice([6, 12, 20, 30])
     spacing = rng.choice([1.35, 2.0, 3.5, 5.4, 5.4, 9.0, 25.0])
     indel = rng.choice([0, 0, 0.03, 0.1])
@@ -79,12 +80,20 @@ cases = [make_case(k) for k in range(count)]
 ctx = m.Context(0)
 bad = done = limits = 0
 t0 = time.time()
-with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 2)) as pool:
-    futs = [pool.submit(run_oracle, c) for c in cases]
-    for c, f in zip(cases, futs):
+workers = max(2, (os.cpu_count() or 4) - 2)
+with ThreadPoolExecutor(max_workers=workers) as pool:
+    # bounded look-ahead: a finished oracle run holds its three output streams in memory until the engine has been compared with it
+    futs, nxt = {}, 0
+    def top_up(upto):
+        global nxt
+        while nxt < len(cases) and nxt < upto:
+            futs[nxt] = pool.submit(run_oracle, cases[nxt]); nxt += 1
+    for k, c in enumerate(cases):
         if time.time() - t0 > budget:
-            for g in futs: g.cancel()
+            for g in futs.values(): g.cancel()
             break
+        top_up(k + 2 * workers)
+        f = futs.pop(k)
         while True:   # heartbeat while a slow oracle case (deep `normal` exomes take minutes) is still running
             try: st, exp = f.result(timeout=60); break
             except TimeoutError: print("... waiting for the oracle on seed %d" % c["seed"], flush=True)
