@@ -740,6 +740,8 @@ void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1,
     }
 }
 
+void reserve_streams(SomaticOutput& p, size_t recs) { p.tsv.reserve(recs * 340); p.fasta.reserve(recs * 52); p.normal_fasta.reserve(recs * 52); }
+void reserve_streams(NormalOutput& p, size_t recs) { p.tsv.reserve(recs * 320); p.fasta.reserve(recs * 56); }
 const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
 const std::string* normal_stream(const NormalOutput&) { return nullptr; }
 
@@ -823,9 +825,17 @@ void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out)
     std::vector<Out> parts(nthreads);
     std::vector<std::string> errors(nthreads);
     std::vector<std::thread> th;
+    // Reserve each range's streams up front (an estimate from the records the device produced, shared out by planned steps; pages
+    // that are never written are never touched): a growing std::string re-maps its buffer again and again, and every re-map takes
+    // the process-wide mm lock that all other threads' page faults wait on.
+    const double per_step = cost[ng] ? double(res.n_recs) / double(cost[ng]) : 0.0;
     for (size_t t = 0; t < nthreads; t++)
         th.emplace_back([&, t] {
-            try { consume_range<Hooks>(b, res, cut[t], cut[t + 1], parts[t]); }
+            try {
+                const double recs = per_step * double(cost[cut[t + 1]] - cost[cut[t]]) * 1.25 + 1024;
+                reserve_streams(parts[t], size_t(recs));
+                consume_range<Hooks>(b, res, cut[t], cut[t + 1], parts[t]);
+            }
             catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
         });
     for (auto& x : th) x.join();

@@ -12,10 +12,10 @@ namespace mp {
 struct HostResults {         // device results copied back for the consumer
     // Group / record slots are global indices (allocator << log2 size) + offset (kernels.hpp NPART); only the used prefix
     // of every allocator's sub-range is copied, back to back, and the accessors translate.
-    std::vector<WinDyn> win_dyn;
-    std::vector<Group> groups;
-    std::vector<GroupSum> gsum;
-    std::vector<uint8_t> recs;   // records of rec_stride bytes (HapRecHdr + seq + germ)
+    PodVec<WinDyn> win_dyn;      // (not zero-filled before the copies from the device overwrite them)
+    PodVec<Group> groups;
+    PodVec<GroupSum> gsum;
+    PodVec<uint8_t> recs;   // records of rec_stride bytes (HapRecHdr + seq + germ)
     uint32_t seq_cap = 48, rec_stride = 128;
     uint32_t group_part_log2 = 0, rec_part_log2 = 0;
     uint64_t group_prefix[NPART + 1] = {0}, rec_prefix[NPART + 1] = {0};
