@@ -128,6 +128,9 @@ IDRecord record_add_freq(const IDRecord& self, double freq) {
     return r;
 }
 
+// MP_TRACE=<file>: one line per print_haplotypes call / merge (debugging aid, compared with the oracle's trace by tools/dbg_trace_case.py)
+static const char* trace_path() { static const char* const p = std::getenv("MP_TRACE"); return p; }
+
 struct ConsumerHooks {
     static constexpr bool kNormal = false;
     const Batch& b;
@@ -197,7 +200,7 @@ struct ConsumerHooks {
             if (zero_slot == ~0ull) throw Error("internal error: reference haplotype missing from device results");
             keys.push_back({0, 0, 0, zero_slot});
         }
-        if (const char* tr = std::getenv("MP_TRACE")) {
+        if (const char* tr = trace_path()) {
             FILE* tf = std::fopen(tr, "a");
             std::fprintf(tf, "P %s %llu f%llu depth=%u fd=%zu first=%d :", transcript.id.c_str(), (unsigned long long)sg.sso, (unsigned long long)frame, wd.nrows, frame_depth, int(is_first_exon_window));
             for (const Key& k : keys) std::fprintf(tf, " (%llu,%llu)=%zu", (unsigned long long)k.hap, (unsigned long long)k.hframe, k.count);
@@ -371,7 +374,7 @@ struct ConsumerHooks {
         std::map<MKey, std::tuple<std::string, IDRecord, std::string>> output_map;
         std::vector<HapSeq> new_hap_vec;
         const double eps = std::numeric_limits<double>::epsilon();
-        if (const char* tr = std::getenv("MP_TRACE")) {
+        if (const char* tr = trace_path()) {
             FILE* tf = std::fopen(tr, "a");
             std::fprintf(tf, "M %s %llu\n", transcript.id.c_str(), (unsigned long long)offset);
             for (const auto& h : first_hap_vec) std::fprintf(tf, "  F %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
