@@ -30,6 +30,7 @@ def make_case(k):
     multi = rng.choice([0, 0, 0.08])
     soft = rng.choice([0, 0, 0.4])
     wl = rng.choice([27, 27, 27, 33, 15, 21])
+    if os.environ.get("FUZZ_WL"): wl = int(rng.choice(os.environ["FUZZ_WL"].split(",")))   # e.g. lengths that are not multiples of 3
     n = rng.choice([8, 16]) if depth < 100 else 5
     if os.environ.get("FUZZ_N") and depth < 100 and mode == "somatic": n = int(os.environ["FUZZ_N"])   # more genes per batch: more planner / consumer threads
     rl = rng.choice([101, 101, 101, 76, 151, 250])   # 250-nt reads at 1.35-nt spacing span > 128 variants (four mask words)
