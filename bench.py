@@ -70,10 +70,17 @@ def main():
 
     import torch
     dist = None
+    # MP_BENCH_REHEARSE=1: run the N-rank code path on a box with ONE GPU (all ranks on device 0, gloo for the two reductions) -
+    # a functional rehearsal of the launch contract, never a measurement (the line says so)
+    rehearse = os.environ.get("MP_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import microphaser_amd as m
     import __graft_entry__ as entry
@@ -85,7 +92,7 @@ def main():
     seed, n_tx, depth, spacing = CONFIGS[args.config]
     if args.transcripts:
         n_tx = args.transcripts
-    ctx = m.Context(local_rank)
+    ctx = m.Context(device_index)
     t0 = time.perf_counter()
     ds = ctx.synth(seed + rank, n_tx, depth, spacing)
     t_gen = time.perf_counter() - t0
@@ -127,9 +134,10 @@ def main():
         windows = st.n_windows_planned
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cpu" if rehearse else "cuda"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wsum = torch.tensor([float(windows)], dtype=torch.float64, device="cuda")
+        wsum = torch.tensor([float(windows)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(wsum, op=dist.ReduceOp.SUM)
         elapsed_max = float(tmax.item())
         total_windows = float(wsum.item())
@@ -178,6 +186,8 @@ def main():
                            "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),
                            "note": "host legs of rank 0 (planner and consumer shard genes over host threads); not part of `value`"},
         }
+        if rehearse:
+            out["rehearsal"] = "all ranks on one GPU, gloo reductions: functional check of the N-rank path, not a measurement"
         if world == 1 and args.cpu_sample > 0:
             cb = cpu_baseline(args.config, args.cpu_sample)
             if cb:
