@@ -282,7 +282,13 @@ struct ConsumerHooks {
             }
             const bool emit = emit_pre && frame_frequency > 0.0;
             HapSeq hs;
-            if (boundary || emit) {
+            hs.win = st.win; hs.frame = frame_in;
+            // Which windows a splice-side merge will read is only known for certain while no shifted ORF exists: where one does (the planner
+            // then asks for every haplotype's record anyway, WS_ALL_IDS) the real walk can keep an older window than the speculative schedule
+            // marked - with window lengths that are not a multiple of 3 even beyond what the planner's candidate lists cover (fuzz seeds
+            // 970028, 970791). So every window of such a stretch keeps its records.
+            const bool keep_all = (ws.need_recs & WS_ALL_IDS) && rec;
+            if (boundary || emit || keep_all) {
                 std::string sites, som_pos, som_pc, germ_pos, germ_pc;
                 uint32_t n_sites = 0, n_som_sites = 0;
                 auto add = [](std::string& s, const std::string& x) { if (!s.empty()) s += "|"; s += x; };
@@ -333,11 +339,12 @@ struct ConsumerHooks {
                             write_fasta(out.normal_fasta, idstr, rgerm, this_window_len);
                         }
                     }
-                    // the row is written field by field: only a window that feeds a splice-side merge needs the record itself
+                    // the row is written field by field (no copy through the record)
                     write_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, roffset, frame, frame_frequency, wd.nrows, n_variants,
                                      n_somatic, n_sites, n_som_sites, strand_s, sites, som_pos, som_pc, germ_pos, germ_pc, normal_peptide, neopeptide);
                 }
-                if (boundary) {
+                {   // the record is kept for every window that is marked as feeding a merge OR emitted: with window lengths that are not a
+                    // multiple of 3 and indels a merge can reach a window the planner's marks miss (fuzz seeds 970028, 970791)
                     hs.filled = true;
                     IDRecord& r = hs.record;
                     r.id = std::move(idstr);
@@ -369,7 +376,15 @@ struct ConsumerHooks {
         const std::vector<HapSeq>& sec_hap_vec = is_fwd ? prev_hap_vec : hap_vec;
         for (const std::vector<HapSeq>* v : {&first_hap_vec, &sec_hap_vec})
             for (const HapSeq& h : *v)
-                if (!h.filled) throw Error("internal error: splice-side merge over a window whose records were not requested from the device");
+                if (!h.filled) {
+                    std::string where;
+                    if (h.win != 0xFFFFFFFFu) {
+                        const WinStatic& w = b.wins[h.win];
+                        where = " (window at sso " + std::to_string(w.sso) + ", printed for frame " + std::to_string(h.frame) + ", need_recs " + std::to_string(w.need_recs) +
+                                ", merge at sso " + std::to_string(sg.sso) + " of transcript " + transcript.id + (v == &hap_vec ? ", hap_vec" : ", prev_hap_vec") + ")";
+                    }
+                    throw Error("internal error: splice-side merge over a window whose records were not requested from the device" + where);
+                }
         using MKey = std::tuple<uint64_t, std::string, std::string>;
         std::map<MKey, std::tuple<std::string, IDRecord, std::string>> output_map;
         std::vector<HapSeq> new_hap_vec;

@@ -29,6 +29,8 @@ struct HapSeq {  // reference: HaplotypeSeq (microphasing.rs:141-145); record ca
     std::vector<uint8_t> sequence;
     NormalRecord nrecord;
     bool filled = false;   // consumer: the record was built (the planner marked the window as carried or it is emitted)
+    uint32_t win = 0xFFFFFFFFu;   // consumer: window the haplotype came from (diagnostics)
+    uint64_t frame = 0;
 };
 
 struct ExonGeom {

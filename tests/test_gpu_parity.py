@@ -281,6 +281,22 @@ def test_gpu_segment_with_non_consecutive_initial_columns(ctx, tmp_path):
     assert res.tsv.count(b"\n") > 500
 
 
+def test_gpu_merge_reaches_back_to_a_shifted_orf_window_with_window_length_28(ctx, tmp_path):
+    """Found by tools/fuzz_vs_oracle.py (seed 970028, -w 28, 10 % indels): the real walk's hap_vec still held the window a shifted ORF
+    printed thousands of bases earlier, which the speculative schedule had not marked for a merge. Every window of a stretch with a
+    shifted ORF keeps its records (the device has them anyway), so the merge finds them."""
+    prefix = os.path.join(str(tmp_path), "o")
+    args = ["--seed", "970028", "--transcripts", "64", "--depth", "6", "--spacing", "9.0", "--indel-rate", "0.1", "--window-len", "28"]
+    subprocess.run([ORACLE_CLI, "synth", *args, "--genes", "56:57", "--skip-panics", "--prefix", prefix], capture_output=True, check=True)
+    ds = ctx.synth(970028, 64, 6.0, 9.0, indel_rate=0.1)
+    b = ds.batch(window_len=28, gene_lo=56, gene_hi=57)
+    b.run()
+    res = b.results()
+    assert res.tsv == open(prefix + ".tsv", "rb").read()
+    assert res.fasta == open(prefix + ".fa", "rb").read()
+    assert res.tsv.count(b"\n") > 100
+
+
 # ------------------------------------------------------------------ the product CLI (src/cli.yaml surface): GTF on stdin, FASTA on stdout
 PRODUCT_CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microphaser_amd", "_lib", "microphaser")
 
