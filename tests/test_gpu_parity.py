@@ -506,3 +506,33 @@ def test_gpu_batches_of_one_context_do_not_alias(ctx):
     whole = ds.phase()
     assert r1.fasta + r2.fasta == whole.fasta
     assert r1.windows + r2.windows == whole.windows
+
+
+# ---- reference fixtures whose upstream tests are disabled (tests/lib.rs:309-320, :384-408); see conftest.py for what each one pins
+def test_gpu_normal_mode_reverse_strand_against_the_disabled_upstream_fixture(ctx):
+    import microphaser_amd as m
+    from conftest import REVERSE_GERMLINE as R, check_reverse_germline
+    d = R["dir"]
+    out = []
+    for gtf in (R["gtf"], R["last_exon_gtf"]):
+        res = ctx.load(os.path.join(d, R["bam"]), os.path.join(d, R["vcf"]), os.path.join(d, R["fasta"]), os.path.join(d, gtf)).phase(mode=m.MODE_NORMAL)
+        out.append(res.fasta)
+    check_reverse_germline(*out)
+
+
+def test_gpu_frameshift_fixture_rows_are_the_upstream_rows(ctx):
+    from conftest import check_frameshift_fixture, disabled_paths
+    p, w = disabled_paths("frameshift_test")
+    res = ctx.load(p["bam"], p["vcf"], p["fasta"], p["gtf"]).phase(window_len=w)
+    check_frameshift_fixture({"fa": res.fasta, "normal.fa": res.normal_fasta, "tsv": res.tsv})
+
+
+def test_gpu_three_way_splice_equals_the_oracle_and_reports(ctx, tmp_path, capsys):
+    """NON-GATING against the stale upstream rows (reported); gating against the oracle."""
+    from conftest import disabled_paths, run_oracle_files, stale_report
+    p, w = disabled_paths("three_way_splice")
+    res = ctx.load(p["bam"], p["vcf"], p["fasta"], p["gtf"]).phase(window_len=w)
+    exp = run_oracle_files(p, str(tmp_path), window_len=w)
+    assert (res.fasta, res.normal_fasta, res.tsv) == (exp["fa"], exp["normal.fa"], exp["tsv"])
+    with capsys.disabled():
+        print("\n[non-gating] GPU on three_way_splice (-w %d): %s" % (w, stale_report("three_way_splice", res.tsv)))

@@ -103,3 +103,39 @@ def test_variants_file_may_be_gzip_bgzf_or_bcf(built, tmp_path, name, encoding):
     exp = read_expected(p["expected"])
     for ext in ("fa", "normal.fa", "tsv"):
         assert got[ext] == exp[ext], "%s.%s differs with the variants as %s" % (name, ext, encoding)
+
+
+def run_oracle_normal(bam, vcf, fasta, gtf, tmp):
+    with open(gtf, "rb") as g:
+        r = subprocess.run([ORACLE_CLI, "normal", bam, "--variants", vcf, "--ref", fasta, "--tsv", os.path.join(tmp, "n.tsv")], stdin=g, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout
+
+
+def test_normal_oracle_reverse_strand_against_the_disabled_upstream_fixture(built, tmp_path):
+    """tests/lib.rs:309-320 (test_reverse_germline, commented out upstream): `normal` on the '-' strand. See check_reverse_germline."""
+    from conftest import REVERSE_GERMLINE as R, check_reverse_germline
+    d = R["dir"]
+    args = [os.path.join(d, R["bam"]), os.path.join(d, R["vcf"]), os.path.join(d, R["fasta"])]
+    whole = run_oracle_normal(*args, os.path.join(d, R["gtf"]), str(tmp_path))
+    tail = run_oracle_normal(*args, os.path.join(d, R["last_exon_gtf"]), str(tmp_path))
+    check_reverse_germline(whole, tail)
+
+
+def test_oracle_frameshift_fixture_rows_are_the_upstream_rows(built, tmp_path):
+    """tests/lib.rs:396-407 (frameshift_test, commented out upstream): see check_frameshift_fixture."""
+    from conftest import check_frameshift_fixture, disabled_paths
+    p, w = disabled_paths("frameshift_test")
+    check_frameshift_fixture(run_oracle_files(p, str(tmp_path), window_len=w))
+
+
+def test_oracle_on_three_way_splice_reports_only(built, tmp_path, capsys):
+    """tests/lib.rs:384-394 (three_way_splice, commented out upstream; a window that spans three exons, expectation in an older TSV
+    layout): NON-GATING - the oracle must run; the number of stale expected rows it still reproduces is reported."""
+    from conftest import disabled_paths, stale_report
+    p, w = disabled_paths("three_way_splice")
+    got = run_oracle_files(p, str(tmp_path), window_len=w)
+    rep = stale_report("three_way_splice", got["tsv"])
+    with capsys.disabled():
+        print("\n[non-gating] oracle on three_way_splice (-w %d): %s" % (w, rep))
+    assert rep["rows"] > 0
