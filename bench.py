@@ -111,12 +111,13 @@ def main():
         st = batch.run()
     sync_all()
     t0 = time.perf_counter()
-    k1 = k2s = k2a = k2w = k3 = k3b = 0.0
+    k1 = k2s = k2a = k2l = k2w = k3 = k3b = 0.0
     for _ in range(args.steps):
         st = batch.run()          # returns after the launch stream has drained (results in HBM)
         k1 += st.k1_ms
         k2s += st.k2seq_ms
         k2a += st.k2a_ms
+        k2l += st.k2l_ms
         k2w += st.k2w_ms
         k3 += st.k3_ms
         k3b += st.k3b_ms
@@ -149,7 +150,8 @@ def main():
         ms_per_step = elapsed_max / steps * 1e3
         value = total_windows * steps / elapsed_max
         kern = {"k1_pileup_bits": (k1 / steps, st.bytes_k1), "k2_window_replay": (k2s / steps, st.bytes_k2seq),
-                "k2a_admission": (k2a / steps, st.bytes_k2a), "k2w_window_rows": (k2w / steps, st.bytes_k2w),
+                "k2a_admission": (k2a / steps, st.bytes_k2a), "k2l_window_lanes": (k2l / steps, st.bytes_k2l),
+                "k2w_window_rows": (k2w / steps, st.bytes_k2w),
                 "k3_window_seq": (k3 / steps, st.bytes_k3), "k3b_haplotype_ids": (k3b / steps, st.bytes_k3b)}
         dom = max(kern, key=lambda k: kern[k][0])
         dom_ms, dom_bytes = kern[dom]
@@ -171,7 +173,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "synthetic %d-transcript exome per GPU, %gx, SNV every %g nt, 101-nt reads (SURVEY 8d config %s, seed %d+rank); "
-                                   "step = K1 + K2 (k2a admission, k2w window rows; sequential k2 replay for the segments that need it) + K3 + K3b over the HBM-resident batch" % (n_tx, depth, spacing, args.config, seed),
+                                   "step = K1 + K2 (k2a admission, k2l one lane per window, k2w one wave per window for the wide ones; sequential k2 replay for the segments that need it) + K3 + K3b over the HBM-resident batch" % (n_tx, depth, spacing, args.config, seed),
                        "windows_per_gpu": int(windows), "reads_per_gpu": int(st.n_reads), "variants_per_gpu": int(st.n_variants),
                        "transcripts_per_gpu": int(st.n_transcripts), "window_len": 27, "sharding": "genes, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -180,7 +182,8 @@ def main():
             "kernels_ms": {k: v[0] for k, v in kern.items()},
             "kernels_algorithmic_bytes": {k: int(v[1]) for k, v in kern.items()},
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),
-            "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm)},
+            "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm),
+                       "windows_lane_kernel": int(st.n_windows_lane), "windows_wave_kernel": int(st.n_windows_wave)},
             "hbm_resident_bytes": int(st.hbm_bytes),
             "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "d2h_consume_s": None if args.no_consume else t_consume,
                            "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),

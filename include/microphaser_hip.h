@@ -78,6 +78,10 @@ typedef struct mp_run_stats {
     double k2seq_ms, k2a_ms, k2w_ms;
     uint64_t bytes_k2seq, bytes_k2a, bytes_k2w;
     uint64_t n_steps_seq, n_steps_w, n_adm;    /* steps replayed sequentially / window-parallel, (exon, read) admission entries */
+    /* the window-parallel part is two kinds of launch: k2l_window_lanes (one LANE per window: windows with <= 8 variant columns,
+     * most of them) and k2w_window_rows (one WAVE per window: the rest). k2w_ms / bytes_k2w above cover the wave kernels only. */
+    double k2l_ms;
+    uint64_t bytes_k2l, n_windows_lane, n_windows_wave;
 } mp_run_stats;
 
 /* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM

@@ -230,12 +230,25 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 const uint64_t read_bytes = 20 + 16ull * b.mask_words;   // start, end, first variant, coverage, dup + the two masks
                 st->k2seq_ms = t.k2seq_ms; st->k2a_ms = t.k2a_ms; st->k2w_ms = t.k2w_ms;
                 st->n_steps_seq = seq_steps; st->n_steps_w = w_steps; st->n_adm = b.n_adm;
-                st->bytes_k2a = b.n_adm * (read_bytes + sizeof(AdmEntry)) + b.exons_w.size() * sizeof(ExonW);
-                st->bytes_k2w = w_steps * (sizeof(Step) + 7) + b.n_adm * (read_bytes + sizeof(AdmEntry)) + batch->w_wins * sizeof(WinDyn) +
-                                groups_w * (sizeof(Group) + 8);
+                // K2a writes an AdmEntry per (exon, read) and, for the lane-per-window kernel, a RowRec (16 + 8 bytes)
+                const uint64_t rowrec = b.lane_on ? sizeof(RowRecA) + 8 : 0;
+                st->bytes_k2a = b.n_adm * (read_bytes + sizeof(AdmEntry) + rowrec) + b.exons_w.size() * sizeof(ExonW);
+                // window rows: the lane kernel reads a WinW + window index per window and every RowRec once; the wave-per-window kernels
+                // read the steps of their work items and their share of the read fields / admission entries
+                uint64_t wave_steps = 0;
+                for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m}) for (const WChunk& c : *list) wave_steps += c.n_steps;
+                const double wave_share = w_steps ? double(wave_steps) / double(w_steps) : 0.0;
+                // groups are shared out by window counts (the lane kernel's windows are the narrow ones: fewer groups each, so this
+                // overstates the lane kernel's bytes a little and understates the wave kernels')
+                const uint64_t lane_wins = b.winw.size(), wave_wins = batch->w_wins - std::min<uint64_t>(batch->w_wins, lane_wins);
+                const uint64_t groups_l = batch->w_wins ? uint64_t(double(groups_w) * double(lane_wins) / double(batch->w_wins)) : 0;
+                st->k2l_ms = t.k2l_ms; st->n_windows_lane = lane_wins; st->n_windows_wave = wave_wins;
+                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * (sizeof(Group) + 8);
+                st->bytes_k2w = wave_steps * (sizeof(Step) + 7) + uint64_t(double(b.n_adm) * wave_share) * (read_bytes + sizeof(AdmEntry)) +
+                                wave_wins * sizeof(WinDyn) + (groups_w - groups_l) * (sizeof(Group) + 8);
                 st->bytes_k2seq = seq_steps * sizeof(Step) + (b.steps.empty() ? 0 : uint64_t(double(b.r_pos.size()) * double(seq_steps) / double(b.steps.size()))) * read_bytes +
                                   seq_wins * sizeof(WinDyn) + groups_seq * (sizeof(Group) + 8);
-                st->bytes_k2 = st->bytes_k2a + st->bytes_k2w + st->bytes_k2seq;
+                st->bytes_k2 = st->bytes_k2a + st->bytes_k2l + st->bytes_k2w + st->bytes_k2seq;
             }
             st->bytes_k3 = t.n_groups * (sizeof(Group) + 4 + sizeof(GroupSum)) +
                            b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols + t.n_recs * hap_rec_stride(b.seq_cap);

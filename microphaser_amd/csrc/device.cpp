@@ -108,6 +108,15 @@ void DeviceContext::upload(const Batch& b) {
     d_.n_wchunks = uint32_t(b.wchunks.size());
     d_.n_adm = b.n_adm;
     d_.adm = static_cast<AdmEntry*>(dalloc(size_t(b.n_adm + 1) * sizeof(AdmEntry))); allocs_.push_back(d_.adm);
+    d_.lane_on = b.lane_on ? 1u : 0u;
+    d_.winw = up(b.winw);
+    d_.lane_win = up(b.lane_win);
+    d_.n_lane_small = b.n_lane_small;
+    d_.n_lane_all = uint32_t(b.winw.size());
+    if (b.lane_on) {
+        d_.rr_a = static_cast<RowRecA*>(dalloc(size_t(b.n_adm + 1) * sizeof(RowRecA))); allocs_.push_back(d_.rr_a);
+        d_.rr_sup = static_cast<uint64_t*>(dalloc(size_t(b.n_adm + 1) * 8)); allocs_.push_back(d_.rr_sup);
+    }
     d_.segs = up(b.segs);
     d_.seg_order = up(b.seg_order);
     d_.n_segs = uint32_t(b.segs.size());
@@ -166,6 +175,9 @@ void DeviceContext::alloc_outputs() {
 void DeviceContext::run(RunTiming& t) {
     HIP_OK(hipSetDevice(device_));
     t = RunTiming();
+    // One pass = one stream of launches with a single host synchronisation at its end: the counts the later kernels need (used group
+    // slots, records that want an id) stay on the device (k_partition_prefix). Only then are the allocators' cursors and the error
+    // word read; an overflow grows the buffers (or the rows per lane) and runs the pass again.
     for (int attempt = 0; attempt < 8; attempt++) {
         t.attempts = uint32_t(attempt + 1);
         t.rows_per_lane = rpl_;
@@ -179,10 +191,19 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(ev_[1], stream_));
         launch_k2_window_replay(d_, rpl_, stream_);     // sequential replay of the segments that need it
         HIP_OK(hipEventRecord(ev_[5], stream_));
-        launch_k2_admission(d_, stream_);                // K2a + K2w: everything else, window-parallel
+        launch_k2_admission(d_, stream_);                // K2a + K2l + K2w: everything else, window-parallel
         HIP_OK(hipEventRecord(ev_[6], stream_));
-        launch_k2_window_rows(d_, stream_);
+        launch_k2_window_lanes(d_, stream_);             // lane per window: the narrow windows (most of them)
+        HIP_OK(hipEventRecord(ev_[7], stream_));
+        launch_k2_window_rows(d_, stream_);              // wave per window: the rest
         HIP_OK(hipEventRecord(ev_[2], stream_));
+        // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
+        launch_partition_prefix(d_, false, stream_);
+        launch_k3_window_seq(d_, group_cap_, stream_);
+        HIP_OK(hipEventRecord(ev_[3], stream_));
+        launch_partition_prefix(d_, true, stream_);
+        launch_k3b_haplotype_ids(d_, rec_cap_, stream_);
+        HIP_OK(hipEventRecord(ev_[4], stream_));
         std::vector<unsigned long long> cur(NPART * 32);
         uint32_t err = 0;
         HIP_OK(hipMemcpyAsync(cur.data(), d_.cursors, cur.size() * 8, hipMemcpyDeviceToHost, stream_));
@@ -195,54 +216,36 @@ void DeviceContext::run(RunTiming& t) {
         }
         if (err & WD_EPOCH_OVERFLOW) throw Error("normal mode: more than 128 live column epochs in one transcript (variant density too high for this build)");
         if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 512 distinct haplotypes in one window");
-        uint64_t max_g = 0, max_r = 0;
-        for (uint32_t p = 0; p < NPART; p++) { max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]); }
-        if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || max_g > (1ull << glog_) || max_r > (1ull << rlog_)) {
+        uint64_t max_g = 0, max_r = 0, max_w = 0;
+        for (uint32_t p = 0; p < NPART; p++) {
+            max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]); max_w = std::max<uint64_t>(max_w, cur[p * 32 + 24]);
+        }
+        if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || max_g > (1ull << glog_) || max_r > (1ull << rlog_) || max_w > (1ull << rlog_)) {
+            const uint32_t g0 = glog_, r0 = rlog_;
             while ((1ull << glog_) < max_g + max_g / 8) glog_++;
-            while ((1ull << rlog_) < max_r + max_r / 8) rlog_++;
-            if ((err & WD_GROUP_OVERFLOW) && max_g <= (1ull << glog_) / 2) glog_++;   // flagged without a cursor past the end: grow anyway
-            if ((err & WD_REC_OVERFLOW) && max_r <= (1ull << rlog_) / 2) rlog_++;
+            while ((1ull << rlog_) < std::max(max_r, max_w) + std::max(max_r, max_w) / 8) rlog_++;
+            if ((err & WD_GROUP_OVERFLOW) && glog_ == g0) glog_++;   // flagged without a cursor past the end: grow anyway
+            if ((err & WD_REC_OVERFLOW) && rlog_ == r0) rlog_++;     // (also: a wanted list outgrew its sub-range, or K3 found a record slot missing)
+            if (glog_ == g0 && rlog_ == r0) rlog_++;
             alloc_outputs();
             continue;
         }
-        unsigned long long prefix[NPART + 1];
-        uint64_t slots = 0, rec_slots = 0;
+        if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
+        uint64_t slots = 0, rec_slots = 0, n_want = 0;
         for (uint32_t p = 0; p < NPART; p++) {
             used_g_[p] = cur[p * 32];
             used_r_[p] = cur[p * 32 + 16];
-            prefix[p] = slots;
             slots += used_g_[p];
             rec_slots += used_r_[p];
+            n_want += cur[p * 32 + 24];
         }
-        prefix[NPART] = slots;
-        HIP_OK(hipMemcpyAsync(part_prefix_, prefix, sizeof prefix, hipMemcpyHostToDevice, stream_));
-        // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
-        uint64_t n_want = 0;
-        launch_k3_window_seq(d_, slots, stream_);
-        HIP_OK(hipEventRecord(ev_[3], stream_));
-        HIP_OK(hipMemcpyAsync(cur.data(), d_.cursors, cur.size() * 8, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipStreamSynchronize(stream_));
-        if (err & WD_REC_OVERFLOW) {   // a wanted list outgrew its sub-range (or K3 found a record slot missing): more room, again
-            rlog_++;
-            alloc_outputs();
-            continue;
-        }
-        unsigned long long wprefix[NPART + 1];
-        for (uint32_t p = 0; p < NPART; p++) { wprefix[p] = n_want; n_want += cur[p * 32 + 24]; }
-        wprefix[NPART] = n_want;
-        HIP_OK(hipMemcpyAsync(part_prefix_ + (NPART + 1), wprefix, sizeof wprefix, hipMemcpyHostToDevice, stream_));
-        launch_k3b_haplotype_ids(d_, n_want, stream_);
-        HIP_OK(hipEventRecord(ev_[4], stream_));
-        HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipStreamSynchronize(stream_));
-        if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
         HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k2seq_ms, ev_[1], ev_[5]));
         HIP_OK(hipEventElapsedTime(&t.k2a_ms, ev_[5], ev_[6]));
-        HIP_OK(hipEventElapsedTime(&t.k2w_ms, ev_[6], ev_[2]));
+        HIP_OK(hipEventElapsedTime(&t.k2l_ms, ev_[6], ev_[7]));
+        HIP_OK(hipEventElapsedTime(&t.k2w_ms, ev_[7], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         last_slots_ = slots;

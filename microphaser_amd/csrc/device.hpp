@@ -31,7 +31,7 @@ struct HostResults {         // device results copied back for the consumer
 
 struct RunTiming {
     float k1_ms = 0, k2_ms = 0, k3_ms = 0, k3b_ms = 0, total_ms = 0;
-    float k2seq_ms = 0, k2a_ms = 0, k2w_ms = 0;   // the three launches inside k2_ms: sequential replay, admission, window rows
+    float k2seq_ms = 0, k2a_ms = 0, k2l_ms = 0, k2w_ms = 0;   // the launches inside k2_ms: sequential replay, admission, lane-per-window, wave-per-window
     uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0;
     int rows_per_lane = 1;
     uint32_t attempts = 0;
@@ -60,7 +60,7 @@ class DeviceContext {
     void free_outputs();
     int device_ = 0;
     hipStream_t stream_ = nullptr;
-    hipEvent_t ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs_, out_allocs_;
     DeviceBatch d_{};
     uint64_t hbm_bytes_ = 0;

@@ -11,6 +11,9 @@
 //                         :42-76, :667-675)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace mp {
@@ -684,7 +687,211 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
             }
         }
         d.adm[uint64_t(e.adm_off) + k] = out;
+        if constexpr (W == 1) {
+            if (d.lane_on) {   // the same facts flattened for the lane-per-window kernel (plan.hpp RowRecA)
+                uint32_t bad_from = 0xFFFFFFFFu;
+                if (out.ord != 0xFFFFFFFFu) {
+                    const uint64_t dm = dirty[0];
+                    if (!is_rev) {   // transcription order = forward index: the first dirty column at or after the oldest one seen
+                        const uint32_t from = max(out.seen_lo, rvl), sh = from - rvl;
+                        const uint64_t m = sh < 64 ? dm >> sh : 0ull;
+                        if (m) bad_from = from + uint32_t(__builtin_ctzll(m));
+                    } else {         // transcription order descends in forward index: the highest dirty column at or below the oldest one seen
+                        const uint32_t f_hi = e.f0 - (out.seen_lo - e.tr0);
+                        if (f_hi >= rvl) {
+                            const uint32_t rel = f_hi - rvl;
+                            const uint64_t m = rel >= 63 ? dm : (dm & ((2ull << rel) - 1ull));
+                            if (m) bad_from = e.tr0 + (e.f0 - (rvl + 63u - uint32_t(__builtin_clzll(m))));
+                        }
+                    }
+                }
+                RowRecA a;
+                a.key = is_rev ? ~start : end;
+                a.ord = out.ord;
+                a.bad_from = bad_from;
+                a.rvl = rvl;
+                d.rr_a[uint64_t(e.adm_off) + k] = a;
+                d.rr_sup[uint64_t(e.adm_off) + k] = d.r_sup[gi];
+            }
+        }
     }
+}
+
+// ====================================================================== K2l (lane-per-window replay)
+// One lane = one printing window (plan.hpp WinW). The lane walks the window's candidate reads - consecutive RowRecs, shared
+// with the neighbouring lanes' windows, so the gathers hit L1 / L2 - and counts the haplotype words of the rows that are not
+// sticky-bad in ITS OWN column of an LDS table of 8-bit counters (table word t of lane l at hist[t * 64 + l]: every access of
+// a wave instruction falls into a different bank). Keys come out in ascending order by walking the touched table words;
+// the wave then takes one run of group slots / record slots for all its windows (prefix sums, two atomics per 64 windows),
+// so consecutive windows' groups are consecutive in memory and no slot is left unused.
+//   reference: ObservationMatrix rows and the count phase of print_haplotypes, src/microphasing.rs:220-343, :383-411
+template <int HB, int STAGE_>   // STAGE_: RowRecs staged in LDS per pass (24 bytes each); 0 = gather from memory (experiments)
+__global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t first, uint32_t count) {
+    constexpr uint32_t NW = (1u << HB) / 4;   // table words per lane (four 8-bit counters each); NW <= 64
+    constexpr uint32_t STAGE = STAGE_ ? STAGE_ : 1;
+    __shared__ uint32_t hist[NW * 64];
+    __shared__ uint4 st_a[STAGE];
+    __shared__ uint64_t st_s[STAGE];
+    const uint32_t lane = threadIdx.x;
+#pragma unroll 4
+    for (uint32_t t = 0; t < NW; t++) hist[t * 64 + lane] = 0;
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long* const gcur = d.cursors + part * 32;
+    unsigned long long* const rcur = gcur + 16;
+    const uint64_t gpart_lo = uint64_t(part) << d.group_part_log2, gpart_size = 1ull << d.group_part_log2;
+    const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_size = 1ull << d.rec_part_log2;
+    uint32_t sticky_err = 0;
+    const uint32_t n_tiles = (count + 63) / 64;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t li = tile * 64 + lane;
+        const bool valid = li < count;
+        uint32_t win = 0, rr_lo = 0, pack = 0, wkey = 0, step = 0, col_hi = 0, flo = 0;
+        uint64_t som_mask = 0;
+        if (valid) {
+            const uint4* wp = reinterpret_cast<const uint4*>(d.winw + first + li);
+            const uint4 w0 = wp[0], w1 = wp[1];
+            rr_lo = w0.x; pack = w0.y; wkey = w0.z; step = w0.w;
+            col_hi = w1.x; flo = w1.y; som_mask = (uint64_t(w1.w) << 32) | w1.z;
+            win = d.lane_win[first + li];
+        }
+        const uint32_t r_n = pack & 0x3FF, ncols = (pack >> 10) & 0x3F;
+        const bool fwd = (pack & WW_FWD) != 0, need_all = (pack & WW_NEED_ALL) != 0;
+        // ---- rows of the window, haplotypes counted as they come (branch-free body: every lane adds 0 or 1 to one counter)
+        const uint32_t cmask32 = ncols ? (0xFFFFFFFFu >> (32 - ncols)) : 0u;   // ncols <= 8: the low dword of the shifted mask is enough
+        const uint32_t rev_sh = (32u - ncols) & 31u;
+        uint32_t nrows = 0;
+        uint64_t touched = 0;   // table words this lane incremented
+        auto count_row = [&](const uint4 a, const uint64_t sup, const bool in) {
+            const bool row = in && a.y <= step && a.x >= wkey;   // inserted, and not cleaned up since (:259-278)
+            const bool act = row && col_hi <= a.z;               // not sticky-bad (:192-195)
+            const int dsh = int(flo - a.w);                      // window's lowest column relative to the mask's bit 0
+            const uint32_t right = uint32_t(sup >> (uint32_t(dsh) & 63u)), left = uint32_t(sup) << (uint32_t(-dsh) & 31u);
+            const uint32_t bits = dsh >= 0 ? (dsh < 64 ? right : 0u) : (dsh > -32 ? left : 0u);
+            const uint32_t h = (fwd ? (__brev(bits) >> rev_sh) : bits) & cmask32;
+            nrows += row ? 1u : 0u;
+            atomicAdd(&hist[(h >> 2) * 64 + lane], act ? (1u << (8 * (h & 3))) : 0u);   // the lane's own counter: a plain ds_add
+            touched |= act ? (1ull << (h >> 2)) : 0ull;
+        };
+        // The candidate ranges of a tile's windows overlap almost completely (consecutive windows of one exon): the wave stages
+        // their union in LDS, STAGE records at a time starting at the lowest range not done yet - one pass for most tiles, two
+        // or three where a tile crosses into another exon (r_n <= K2L_MAX_ROWS < STAGE: a window always fits the pass it opens).
+        auto wave_min = [](uint32_t v) {
+#pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) v = min(v, uint32_t(__shfl_xor(v, off)));
+            return rdlane(v, 0);
+        };
+        auto wave_max = [](uint32_t v) {
+#pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) v = max(v, uint32_t(__shfl_xor(v, off)));
+            return rdlane(v, 0);
+        };
+        if constexpr (STAGE_ == 0) {
+            const uint32_t rn_max = wave_max(r_n);
+            uint4 a_next = make_uint4(0, 0, 0, 0), a_next2 = a_next;
+            uint64_t s_next = 0, s_next2 = 0;
+            if (r_n) { a_next = *reinterpret_cast<const uint4*>(d.rr_a + rr_lo); s_next = d.rr_sup[rr_lo]; }
+            if (r_n > 1) { a_next2 = *reinterpret_cast<const uint4*>(d.rr_a + rr_lo + 1); s_next2 = d.rr_sup[rr_lo + 1]; }
+            for (uint32_t k = 0; k < rn_max; k++) {
+                const uint4 a = a_next;
+                const uint64_t sup = s_next;
+                a_next = a_next2; s_next = s_next2;
+                if (k + 2 < r_n) { a_next2 = *reinterpret_cast<const uint4*>(d.rr_a + rr_lo + k + 2); s_next2 = d.rr_sup[rr_lo + k + 2]; }
+                count_row(a, sup, k < r_n);
+            }
+        } else {
+        bool pending = r_n != 0;
+        while (__ballot(pending)) {
+            const uint32_t base = wave_min(pending ? rr_lo : 0xFFFFFFFFu);
+            const bool fit = pending && rr_lo - base + r_n <= STAGE;
+            const uint32_t n_stage = wave_max(fit ? rr_lo - base + r_n : 0u), rn_max = wave_max(fit ? r_n : 0u);
+            __syncthreads();   // the previous pass's reads of the stage are done
+            for (uint32_t i = lane; i < n_stage; i += 64) {
+                st_a[i] = *reinterpret_cast<const uint4*>(d.rr_a + base + i);
+                st_s[i] = d.rr_sup[base + i];
+            }
+            __syncthreads();
+            const uint32_t s_at = fit ? rr_lo - base : 0u, s_last = fit ? r_n - 1 : 0u;
+#pragma unroll 4
+            for (uint32_t k = 0; k < rn_max; k++) {
+                const uint32_t at = s_at + min(k, s_last);
+                count_row(st_a[at], st_s[at], fit && k < r_n);
+            }
+            pending = pending && !fit;
+        }
+        }
+        // ---- groups in ascending key order: key 0 (the reference haplotype) is always listed (:429-431)
+        touched |= 1ull;
+        uint32_t ng = 0, nneed = 0;
+        if (valid) {
+            uint64_t tm = touched;
+            while (tm) {
+                const uint32_t t = uint32_t(__builtin_ctzll(tm));
+                tm &= tm - 1;
+                const uint32_t x = hist[t * 64 + lane];
+#pragma unroll
+                for (uint32_t b = 0; b < 4; b++) {
+                    const uint32_t key = 4 * t + b;
+                    if (((x >> (8 * b)) & 0xFF) || key == 0) { ng++; nneed += (need_all || (uint64_t(key) & som_mask)) ? 1u : 0u; }
+                }
+            }
+        }
+        // wave-inclusive prefix sums of (ng, nneed), packed: ng <= 256 per lane -> sum <= 16384; nneed likewise
+        uint32_t scan = ng | (nneed << 16);
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(scan, off);
+            if (lane >= off) scan += up;
+        }
+        const uint32_t total = rdlane(scan, 63);
+        const uint32_t tot_g = total & 0xFFFF, tot_r = total >> 16;
+        unsigned long long gb = 0, rb = 0;
+        if (lane == 0) {
+            gb = atomicAdd(gcur, (unsigned long long)tot_g);
+            if (tot_r) rb = atomicAdd(rcur, (unsigned long long)tot_r);
+        }
+        const uint64_t gbase = (uint64_t(rdlane(uint32_t(gb >> 32), 0)) << 32) | rdlane(uint32_t(gb), 0);
+        const uint64_t rbase = (uint64_t(rdlane(uint32_t(rb >> 32), 0)) << 32) | rdlane(uint32_t(rb), 0);
+        const bool can_write = gbase + tot_g <= gpart_size;
+        const bool rec_ok = rbase + tot_r <= rpart_size;
+        uint32_t werr = 0;
+        if (!can_write) werr |= WD_GROUP_OVERFLOW;
+        if (!rec_ok) { werr |= WD_REC_OVERFLOW; }
+        sticky_err |= werr;
+        uint64_t gslot = gpart_lo + gbase + ((scan & 0xFFFF) - ng);
+        uint64_t rslot = rpart_lo + rbase + ((scan >> 16) - nneed);
+        if (valid) {
+            const uint32_t goff = uint32_t(gslot);
+            uint64_t tm = touched;
+            while (tm) {
+                const uint32_t t = uint32_t(__builtin_ctzll(tm));
+                tm &= tm - 1;
+                const uint32_t x = hist[t * 64 + lane];
+                hist[t * 64 + lane] = 0;   // ready for the next tile
+#pragma unroll
+                for (uint32_t b = 0; b < 4; b++) {
+                    const uint32_t key = 4 * t + b, cnt = (x >> (8 * b)) & 0xFF;
+                    if (cnt || key == 0) {
+                        const bool need = need_all || (uint64_t(key) & som_mask) != 0;
+                        if (can_write) {
+                            Group G; G.hap = key; G.count = cnt; G.aux = 0;
+                            d.groups[gslot] = G;
+                            d.g_win[gslot] = win;
+                            d.g_rec[gslot] = (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu;
+                        }
+                        gslot++;
+                        rslot += need ? 1u : 0u;
+                    }
+                }
+            }
+            WinDyn wd;
+            wd.group_off = goff;
+            wd.ngroups = ng;
+            wd.nrows = nrows;
+            wd.flags = WD_DONE | werr;
+            d.win_dyn[win] = wd;
+        }
+    }
+    if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
 
 constexpr uint32_t K2W_ITEMS = 4;
@@ -737,7 +944,9 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
                 w8 = uint32_t(bits); w9 = uint32_t(bits >> 32);
             }
         }
-        uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT));
+        // (the windows the lane-per-window kernel takes are not this kernel's: plan.cpp lane_window)
+        uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT) &&
+                                     !(d.lane_on && (w7 >> 16) <= K2L_MAX_COLS && (w7 & 0xFFFF) <= K2L_MAX_ROWS));
         while (printing) {
             const uint32_t i = uint32_t(__builtin_ctzll(printing));
             printing &= printing - 1;
@@ -953,7 +1162,9 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
                 w8 = uint32_t(bits); w9 = uint32_t(bits >> 32);
             }
         }
-        uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT));
+        // (the windows the lane-per-window kernel takes are not this kernel's: plan.cpp lane_window)
+        uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT) &&
+                                     !(d.lane_on && (w7 >> 16) <= K2L_MAX_COLS && (w7 & 0xFFFF) <= K2L_MAX_ROWS));
         while (printing) {
             const uint32_t i = uint32_t(__builtin_ctzll(printing));
             printing &= printing - 1;
@@ -1549,12 +1760,15 @@ __device__ __forceinline__ bool stop_codon_at(const uint8_t* s, uint32_t c, bool
 }
 
 template <int SEQ_CAP>
-__global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint64_t n_slots) {
+__global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
-    const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;   // index into the dense list of live group slots
-    const uint64_t g = slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
+    // the number of used group slots is only known on the device (k_partition_prefix after K2): a fixed grid walks them in turn
+    const uint64_t n_slots = d.part_prefix[NPART];
+    for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
+    const uint64_t li = tile * K3_THREADS + tid;   // index into the dense list of live group slots
+    const uint64_t g = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -1784,6 +1998,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
         gs.rec = recidx;
         d.gsum[g] = gs;
     }
+    }   // tiles of this wave
 }
 
 // K3 for `microphaser normal` (reference: src/normal_microphasing.rs:341-647): same slots and record layout, but the
@@ -1793,18 +2008,16 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d, uint6
 // ('+') / LAST ('-') codon of the peptide slice. germ_len is 0; the germ area's first 8 bytes hold the somatic subset of
 // the variant profile.
 template <int SEQ_CAP>
-__global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d, uint64_t n_slots) {
+__device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_slots, uint64_t g, bool valid, uint32_t& recidx) {
     constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
-    __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
-    const uint64_t li = uint64_t(blockIdx.x) * K3_THREADS + tid;
-    const uint64_t g = slot_of(d, li, uint64_t(blockIdx.x) * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
+    recidx = 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
     uint32_t* germ_dw = slot + (K3_REFCAP + SEQ_CAP) / 4;
-    const uint32_t w = li < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
-    if (w == 0xFFFFFFFFu) return;
+    const uint32_t w = valid ? d.g_win[g] : 0xFFFFFFFFu;
+    if (w == 0xFFFFFFFFu) return 0;
     const WinStatic ws = d.wins[w];
     const uint32_t vbase = ws.vbase;
     const Group G = d.groups[g];
@@ -1889,7 +2102,6 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     if (nhi - nlo >= 3) stop = is_rev ? stop_codon_at(seq, nhi - 3, false) : stop_codon_at(seq, nlo, true);
     const bool skipped = stop && ws.splice_pos != 2;   // :503-507: such a haplotype produces nothing
     uint32_t sumflags = GS_VALID | (stop ? GS_STOP : 0) | (insertion ? GS_INSERTION : 0) | (ns > uint32_t(SEQ_CAP) ? uint32_t(GS_BROKE) : 0u);
-    uint32_t recidx = 0;
     const uint32_t slot_idx = d.g_rec[g];
     if (slot_idx != 0xFFFFFFFFu) {
         uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
@@ -1908,18 +2120,30 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     } else {
         atomicOr(d.err, WD_REC_OVERFLOW);
     }
-    append_wanted(d, (sumflags & GS_ID_VALID) != 0, recidx);
     GroupSum gs;
     gs.flags = sumflags;
     gs.rec = recidx;
     d.gsum[g] = gs;
+    return sumflags;
+}
+template <int SEQ_CAP>
+__global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d) {
+    __shared__ uint32_t lds_slots[K3_THREADS * K3Cfg<SEQ_CAP>::SLOT_DW];
+    const uint64_t n_slots = d.part_prefix[NPART];
+    for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
+        const uint64_t li = tile * K3_THREADS + threadIdx.x;
+        const uint64_t g = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
+        uint32_t recidx;
+        const uint32_t sumflags = k3n_one<SEQ_CAP>(d, lds_slots, g, li < n_slots, recidx);
+        append_wanted(d, (sumflags & GS_ID_VALID) != 0, recidx);   // wave-level: every lane takes part
+    }
 }
 
 // K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
 // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
 constexpr uint32_t K3B_BUF_WORDS = 48;   // three SHA-1 blocks per thread (a 27..31-nt window + an id of <= 17 characters always fits)
 template <int SEQ_CAP>
-__global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t n_recs) {
+__global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d) {
     __shared__ uint32_t lds_blk[64 * (K3B_BUF_WORDS + 1)];   // odd stride: bank-conflict free
     __shared__ uint64_t byte_text[256];   // decimal text of a byte value followed by ", ", packed big-endian: text << 8 | length
     for (uint32_t v = threadIdx.x; v < 256; v += 64) {
@@ -1932,11 +2156,13 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
         byte_text[v] = (txt << 8) | (n + 2);
     }
     __syncthreads();
-    const uint64_t li = uint64_t(blockIdx.x) * 64 + threadIdx.x;   // index into the dense lists of records that need an id
+    const uint64_t n_recs = d.want_prefix[NPART];   // known on the device only (k_partition_prefix after K3)
+    for (uint64_t tile = blockIdx.x; tile * 64 < n_recs; tile += gridDim.x) {
+    const uint64_t li = tile * 64 + threadIdx.x;   // index into the dense lists of records that need an id
     uint32_t wp;       // li-th wanted record overall -> list wp, offset woff
     uint64_t woff;
-    locate_in_parts(d.want_prefix, li, uint64_t(blockIdx.x) * 64, li < n_recs, wp, woff);
-    if (li >= n_recs) return;
+    locate_in_parts(d.want_prefix, li, tile * 64, li < n_recs, wp, woff);
+    if (li >= n_recs) continue;
     const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + woff];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
     const uint32_t seq_len = rec[4] & 0xFF;
@@ -1991,6 +2217,25 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d, uint64_t 
     uint64_t id60 = (uint64_t(o0) << 28) | (uint64_t(o1) >> 4);
     rec[2] = uint32_t(id60);
     rec[3] = uint32_t(id60 >> 32);
+    }   // tiles of this wave
+}
+
+// The output allocators' cursors (kernels.hpp NPART) -> exclusive prefix sums, on the device: K3 / K3b walk the used slots of
+// all allocators as one dense index space without the host having to read the cursors in the middle of a pass.
+// which = 0: group slots used after K2 -> part_prefix; which = 24: lengths of K3's wanted lists -> want_prefix.
+__global__ __launch_bounds__(64) void k_partition_prefix(DeviceBatch d, uint32_t which, unsigned long long* out, uint64_t part_size) {
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long used = min((unsigned long long)d.cursors[lane * 32 + which], (unsigned long long)part_size);   // an overflowing allocator: flagged elsewhere
+    uint32_t lo = uint32_t(used), hi = uint32_t(used >> 32);
+    unsigned long long incl = used;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t ulo = __shfl_up(uint32_t(incl), off), uhi = __shfl_up(uint32_t(incl >> 32), off);
+        if (lane >= off) incl += (uint64_t(uhi) << 32) | ulo;
+    }
+    (void)lo; (void)hi;
+    out[lane] = incl - used;
+    if (lane == 63) out[NPART] = incl;
 }
 
 // ====================================================================== launchers
@@ -2069,35 +2314,71 @@ void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
     }
 }
 
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_group_slots, hipStream_t stream) {
-    if (n_group_slots == 0) return;
-    dim3 grid(uint32_t((n_group_slots + K3_THREADS - 1) / K3_THREADS)), block(K3_THREADS);
+template <int STAGE>
+static void launch_k2l(const DeviceBatch& d, hipStream_t stream) {
+    // persistent-ish grids: as many waves as the LDS admits, each takes tiles of 64 windows in turn
+    const uint32_t n_small = d.n_lane_small, n_wide = d.n_lane_all - d.n_lane_small;
+    const uint32_t lds_small = 4096 + 24 * STAGE, lds_wide = 16384 + 24 * STAGE;
+    if (n_small) {
+        const uint32_t tiles = (n_small + 63) / 64, waves = min(32u, 163840u / lds_small);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_SMALL_COLS, STAGE>), dim3(min(tiles, 256u * waves)), dim3(64), 0, stream, d, 0u, n_small);
+        HIP_CHECK_LAUNCH();
+    }
+    if (n_wide) {
+        const uint32_t tiles = (n_wide + 63) / 64, waves = min(32u, 163840u / lds_wide);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(min(tiles, 256u * waves)), dim3(64), 0, stream, d, n_small, n_wide);
+        HIP_CHECK_LAUNCH();
+    }
+}
+void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream) {
+    if (!d.lane_on) return;
+    static const int stage = [] { const char* e = std::getenv("MP_K2L_STAGE"); return e ? std::atoi(e) : 256; }();   // experiments
+    switch (stage) {
+        case 0: launch_k2l<0>(d, stream); break;
+        case 128: launch_k2l<128>(d, stream); break;
+        case 384: launch_k2l<384>(d, stream); break;
+        default: launch_k2l<256>(d, stream); break;
+    }
+}
+
+static_assert(NPART == 64, "k_partition_prefix is one wave");
+void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t stream) {
+    if (want_lists) hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 24u, const_cast<unsigned long long*>(d.want_prefix), uint64_t(1) << d.rec_part_log2);
+    else hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 0u, const_cast<unsigned long long*>(d.part_prefix), uint64_t(1) << d.group_part_log2);
+    HIP_CHECK_LAUNCH();
+}
+
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStream_t stream) {
+    if (max_group_slots == 0) return;
+    // fixed grid (the LDS admits ~16 one-wave workgroups per CU at the smallest record size); surplus waves find nothing and leave
+    const uint32_t per_cu = d.seq_cap == 48 ? 16u : d.seq_cap == 112 ? 10u : 5u;
+    dim3 grid(uint32_t(std::min<uint64_t>((max_group_slots + K3_THREADS - 1) / K3_THREADS, 256ull * per_cu))), block(K3_THREADS);
     if (d.normal) {
         switch (d.seq_cap) {
-            case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d, n_group_slots); break;
-            case 112: hipLaunchKernelGGL(k3_window_seq_normal<112>, grid, block, 0, stream, d, n_group_slots); break;
-            case 240: hipLaunchKernelGGL(k3_window_seq_normal<240>, grid, block, 0, stream, d, n_group_slots); break;
+            case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d); break;
+            case 112: hipLaunchKernelGGL(k3_window_seq_normal<112>, grid, block, 0, stream, d); break;
+            case 240: hipLaunchKernelGGL(k3_window_seq_normal<240>, grid, block, 0, stream, d); break;
             default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
         }
         HIP_CHECK_LAUNCH();
         return;
     }
     switch (d.seq_cap) {
-        case 48: hipLaunchKernelGGL(k3_window_seq<48>, grid, block, 0, stream, d, n_group_slots); break;
-        case 112: hipLaunchKernelGGL(k3_window_seq<112>, grid, block, 0, stream, d, n_group_slots); break;
-        case 240: hipLaunchKernelGGL(k3_window_seq<240>, grid, block, 0, stream, d, n_group_slots); break;
+        case 48: hipLaunchKernelGGL(k3_window_seq<48>, grid, block, 0, stream, d); break;
+        case 112: hipLaunchKernelGGL(k3_window_seq<112>, grid, block, 0, stream, d); break;
+        case 240: hipLaunchKernelGGL(k3_window_seq<240>, grid, block, 0, stream, d); break;
         default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
     HIP_CHECK_LAUNCH();
 }
 
-void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream) {
-    if (n_recs == 0) return;
-    dim3 grid(uint32_t((n_recs + 63) / 64)), block(64);
+void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {
+    if (max_recs == 0) return;
+    dim3 grid(uint32_t(std::min<uint64_t>((max_recs + 63) / 64, 256ull * 10))), block(64);
     switch (d.seq_cap) {
-        case 48: hipLaunchKernelGGL(k3b_haplotype_ids<48>, grid, block, 0, stream, d, n_recs); break;
-        case 112: hipLaunchKernelGGL(k3b_haplotype_ids<112>, grid, block, 0, stream, d, n_recs); break;
-        case 240: hipLaunchKernelGGL(k3b_haplotype_ids<240>, grid, block, 0, stream, d, n_recs); break;
+        case 48: hipLaunchKernelGGL(k3b_haplotype_ids<48>, grid, block, 0, stream, d); break;
+        case 112: hipLaunchKernelGGL(k3b_haplotype_ids<112>, grid, block, 0, stream, d); break;
+        case 240: hipLaunchKernelGGL(k3b_haplotype_ids<240>, grid, block, 0, stream, d); break;
         default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
     HIP_CHECK_LAUNCH();

@@ -40,6 +40,12 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint16_t* step_rn;
     const uint64_t* v_sombits;      // bit (var_off + f) set <=> that variant is somatic
     AdmEntry* adm;                  // K2a output
+    // lane-per-window replay (plan.hpp WinW): K2a also writes a RowRec per (exon, read); k2l_window_lanes takes the listed windows
+    RowRecA* rr_a;
+    uint64_t* rr_sup;
+    const WinW* winw;
+    const uint32_t* lane_win;
+    uint32_t n_lane_small, n_lane_all, lane_on, lane_pad_;
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
     uint32_t n_exons_w, n_wchunks, n_wchunks_m, n_achunks;
     uint32_t rows_per_lane_w;       // RPL of k2w_window_rows_multi: 64 * RPL >= candidate reads of any of its windows
@@ -78,7 +84,11 @@ void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
 void launch_k2_admission(const DeviceBatch& d, hipStream_t stream);     // K2a over the ExonW part of the plan
 void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream);   // K2w, after K2a
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t n_live_groups, hipStream_t stream);
-void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t n_recs, hipStream_t stream);
+void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream);  // K2l, after K2a: the windows of winw
+// K3 / K3b read the number of used group slots / wanted records from the device (launch_partition_prefix first); the host only
+// passes an upper bound that sizes the fixed grid.
+void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t stream);
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStream_t stream);
+void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream);
 
 }  // namespace mp

@@ -422,6 +422,78 @@ static void validate_segments(const Batch& b) {
     if (b.normal && b.step_aux.size() != b.steps.size()) throw Error("internal error: step_aux out of step with the plan");
 }
 
+// Lane-per-window replay (plan.hpp WinW): flatten every eligible printing window of the window-parallel exons, small windows
+// (<= K2L_SMALL_COLS columns) first; the wave-per-window kernels keep only the work items that still hold one of their windows.
+static bool lane_window(const Batch& b, uint32_t si) {
+    return b.lane_on && (b.steps[si].flags & SF_PRINT) && b.step_ncols[si] <= K2L_MAX_COLS && b.step_rn[si] <= K2L_MAX_ROWS;
+}
+static void route_lane_windows(Batch& b) {
+    b.winw.clear();
+    b.lane_win.clear();
+    b.n_lane_small = 0;
+    if (!b.lane_on) return;
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>(host_threads(), b.exons_w.size() / 64 + 1));
+    struct Part { PodVec<WinW> w[2]; PodVec<uint32_t> id[2]; };
+    std::vector<Part> parts(nthreads);
+    auto work = [&](size_t t) {
+        Part& P = parts[t];
+        const size_t e0 = b.exons_w.size() * t / nthreads, e1 = b.exons_w.size() * (t + 1) / nthreads;
+        for (size_t ei = e0; ei < e1; ei++) {
+            const ExonW& e = b.exons_w[ei];
+            const bool rev = e.strand != 0;
+            for (uint32_t k = 0; k < e.n_steps; k++) {
+                const uint32_t si = e.step_off + k;
+                if (!lane_window(b, si)) continue;
+                const Step& st = b.steps[si];
+                const uint32_t nc = b.step_ncols[si], rn = b.step_rn[si];
+                WinW w{};
+                w.rr_lo = rn ? e.adm_off + (b.step_rlo[si] - e.read_lo) : 0;
+                w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u);
+                w.wkey = rev ? ~st.sso : st.sso + uint32_t(st.wlen);
+                w.step = si;
+                w.col_hi = st.col_hi;
+                uint64_t som = 0;
+                if (nc) {   // forward indices of the live columns: transcription order [col_hi - nc, col_hi)
+                    w.flo = rev ? e.f0 - (st.col_hi - 1 - e.tr0) : st.col_hi - nc;
+                    const uint64_t gv = uint64_t(e.vbase) + w.flo;
+                    const uint64_t x0 = b.v_sombits[gv >> 6], x1 = b.v_sombits[(gv >> 6) + 1];
+                    const uint32_t sh = uint32_t(gv & 63);
+                    som = (sh ? ((x0 >> sh) | (x1 << (64 - sh))) : x0) & (~0ull >> (64 - nc));
+                    if (!rev) {   // haplotype bit order on '+': newest column (highest position) = bit 0
+                        uint64_t r = 0;
+                        for (uint32_t c = 0; c < nc; c++) if ((som >> c) & 1) r |= 1ull << (nc - 1 - c);
+                        som = r;
+                    }
+                }
+                w.som_lo = uint32_t(som); w.som_hi = uint32_t(som >> 32);
+                const int cls = nc <= K2L_SMALL_COLS ? 0 : 1;
+                P.w[cls].push_back(w);
+                P.id[cls].push_back(st.win);
+            }
+        }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthreads; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    size_t n[2] = {0, 0};
+    for (const Part& P : parts) { n[0] += P.w[0].size(); n[1] += P.w[1].size(); }
+    b.winw.resize(n[0] + n[1]);
+    b.lane_win.resize(n[0] + n[1]);
+    b.n_lane_small = uint32_t(n[0]);
+    size_t at[2] = {0, n[0]};
+    for (const Part& P : parts)
+        for (int c = 0; c < 2; c++) {
+            if (!P.w[c].empty()) {
+                std::memcpy(static_cast<void*>(b.winw.data() + at[c]), P.w[c].data(), P.w[c].size() * sizeof(WinW));
+                std::memcpy(b.lane_win.data() + at[c], P.id[c].data(), P.id[c].size() * 4);
+            }
+            at[c] += P.w[c].size();
+        }
+}
+
 // Decide which single-exon segments go to the window-parallel replay (plan.hpp ExonW) and cut them into work items.
 static void route_window_parallel(Batch& b) {
     // packed somatic flags of all variants (K2w derives a window's somatic-column mask from it)
@@ -433,6 +505,7 @@ static void route_window_parallel(Batch& b) {
     b.n_adm = 0;
     if (b.seg_info.size() != b.segs.size()) throw Error("internal error: segment info out of step");
     const bool enabled = !b.normal && b.mask_words <= 2 && !std::getenv("MP_SEQUENTIAL_REPLAY");
+    b.lane_on = enabled && b.mask_words == 1 && !std::getenv("MP_NO_LANE_KERNEL");
     b.wchunks_m.clear();
     b.achunks.clear();
     uint32_t max_rn_multi = 0;
@@ -473,13 +546,19 @@ static void route_window_parallel(Batch& b) {
         if (multi) max_rn_multi = std::max(max_rn_multi, si.max_rn);
         // deep windows cost ~RPL x more each and there are few of them: smaller work items keep the chip full
         const uint32_t chunk = multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
-        for (uint32_t s0 = 0; s0 < g.n_steps; s0 += chunk)
-            (multi ? b.wchunks_m : b.wchunks).push_back(WChunk{ei, g.step_off + s0, std::min(chunk, g.n_steps - s0), 0});
+        for (uint32_t s0 = 0; s0 < g.n_steps; s0 += chunk) {
+            const uint32_t n = std::min(chunk, g.n_steps - s0);
+            bool mine = !b.lane_on;   // a printing window the lane kernel does not take
+            for (uint32_t k = 0; k < n && !mine; k++)
+                mine = (b.steps[g.step_off + s0 + k].flags & SF_PRINT) && !lane_window(b, g.step_off + s0 + k);
+            if (mine) (multi ? b.wchunks_m : b.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0});
+        }
     }
     b.rows_per_lane_w = 1;
     while (64u * b.rows_per_lane_w < max_rn_multi) b.rows_per_lane_w *= 2;
     b.segs.swap(keep);
     b.seg_info.clear();
+    route_lane_windows(b);
 }
 
 static void finalize_segments(Batch& b) {

@@ -73,6 +73,34 @@ struct AdmEntry {                   // K2a output per (ExonW, read)
     uint32_t seen_lo;               // transcription-order index of the oldest column the row has seen (deque at that push)
 };
 
+// Lane-per-window replay (K2l): a printing window of a window-parallel exon with at most K2L_MAX_COLS columns and at most
+// K2L_MAX_ROWS candidate reads (one mask word per read) is one LANE's work: the lane walks the window's candidate reads
+// (RowRec, written by K2a per (exon, read)), derives row / bad / haplotype with three compares and two shifts and counts the
+// haplotypes in its own column of an LDS table of 8-bit counters indexed by the haplotype word - no ballots, no readlanes, no
+// barriers. Everything a lane needs is flattened into its WinW by the planner.
+constexpr uint32_t K2L_MAX_COLS = 8;
+constexpr uint32_t K2L_SMALL_COLS = 6;    // windows with <= 6 columns: 64 counters per lane (4 KB of LDS per wave); 7-8: 256 (16 KB)
+constexpr uint32_t K2L_MAX_ROWS = 255;    // 8-bit counters
+struct WinW {
+    uint32_t rr_lo;      // RowRec index of the window's first candidate read
+    uint32_t pack;       // r_n (bits 0-9) | ncols (10-15) | WW_FWD | WW_NEED_ALL
+    uint32_t wkey;       // a read is a row iff RowRec.key >= wkey: '+' splice_end vs end, '-' ~sso vs ~start (:259-278, :312-315)
+    uint32_t step;       // ... and it was inserted at or before this step (RowRec.ord <= step)
+    uint32_t col_hi;     // the row is not sticky-bad iff col_hi <= RowRec.bad_from
+    uint32_t flo;        // gene-relative forward index of the window's lowest-position column
+    uint32_t som_lo, som_hi;   // somatic columns of the window in haplotype bit order
+};
+static_assert(sizeof(WinW) == 32, "WinW layout");
+enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17 };
+struct RowRecA {         // K2a output per (ExonW, read), first half (the second is the 64-bit support mask)
+    uint32_t key;        // '+': end_pos, '-': ~start
+    uint32_t ord;        // AdmEntry::ord
+    uint32_t bad_from;   // transcription-order index of the first column, among those the row sees after its insertion, on which it has a
+                         // low-quality / start-loss bit (0xFFFFFFFF: none): the row is bad from the step that appends it (:157-197)
+    uint32_t rvl;        // r_varlo: forward index of the variant bit 0 of the masks belongs to
+};
+static_assert(sizeof(RowRecA) == 16, "RowRecA layout");
+
 // Step.flags
 enum : uint8_t {
     SF_PRINT = 1,        // print_haplotypes may be called at this step (superset)

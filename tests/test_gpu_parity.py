@@ -536,3 +536,22 @@ def test_gpu_three_way_splice_equals_the_oracle_and_reports(ctx, tmp_path, capsy
     assert (res.fasta, res.normal_fasta, res.tsv) == (exp["fa"], exp["normal.fa"], exp["tsv"])
     with capsys.disabled():
         print("\n[non-gating] GPU on three_way_splice (-w %d): %s" % (w, stale_report("three_way_splice", res.tsv)))
+
+
+def test_gpu_lane_per_window_and_wave_per_window_replay_agree(ctx, monkeypatch):
+    """K2l (lane per window: RowRecs + per-lane LDS counters) against K2w (wave per window) on the same exome: the default plan
+    sends the windows with <= 8 columns to K2l, MP_NO_LANE_KERNEL=1 sends everything to K2w. Shallow and deep (rows spread over
+    more than 64 reads: the multi-block wave kernel keeps the wide windows, the lane kernel takes the narrow ones)."""
+    for seed, n, depth, spacing in ((4243, 50, 30.0, 5.4), (4244, 30, 45.0, 2.5), (4245, 8, 150.0, 9.0)):
+        ds = ctx.synth(seed, n, depth, spacing)
+        monkeypatch.delenv("MP_NO_LANE_KERNEL", raising=False)
+        b = ds.batch()
+        b.run()
+        lanes = b.results()
+        monkeypatch.setenv("MP_NO_LANE_KERNEL", "1")
+        b2 = ds.batch()
+        b2.run()
+        waves = b2.results()
+        assert (lanes.fasta, lanes.normal_fasta, lanes.tsv, lanes.windows) == (waves.fasta, waves.normal_fasta, waves.tsv, waves.windows)
+        assert lanes.tsv.count(b"\n") > 200
+    monkeypatch.delenv("MP_NO_LANE_KERNEL", raising=False)
