@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -1114,9 +1115,26 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
 // K2w for deeper data: RPL reads per lane (a block of 64 * RPL consecutive reads) and W mask words per read. Same row
 // derivation as k2w_window_rows; the haplotypes are counted by repeated minimum extraction (bitwise descent with ballots),
 // which yields them in ascending order, 64 at a time.
+// Bitonic sort of n (a power of two, >= 64) keys in LDS by ONE wave, ascending.
+template <class K>
+__device__ __forceinline__ void bitonic_sort_wave(K* keys, uint32_t n, uint32_t lane) {
+    for (uint32_t k = 2; k <= n; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < n / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i + j;
+                const K a = keys[i], b = keys[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+}
+
 template <int RPL, int W>
 __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
     constexpr uint32_t CAP = 64u * RPL;
+    __shared__ uint64_t sk[CAP];              // the window's haplotype words, sorted
+    __shared__ uint16_t starts[CAP + 2];      // first entry of every run of equal words
     constexpr uint32_t GROUP_CHUNK = 64u * RPL + 64u, REC_CHUNK_W = 64;
     const uint32_t lane = threadIdx.x;
     const uint32_t part = blockIdx.x & (NPART - 1);
@@ -1267,43 +1285,54 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
                     d.g_rec[gi] = rec;
                 }
             };
-            uint32_t ng = has_zero ? 0u : 1u;   // lane 0 stages the zero-count reference group
-            uint32_t sg_hi = 0, sg_lo = 0, sg_cnt = 0;
-            for (;;) {
-                bool c[RPL];
-                bool any_c = false;
-#pragma unroll
-                for (int k = 0; k < RPL; k++) { c[k] = act[k]; any_c |= c[k]; }
-                if (!__ballot(any_c)) break;
-                for (int bit = int(ncols) - 1; bit >= 0; bit--) {
-                    const uint64_t mk = 1ull << bit;
-                    bool z = false;
-#pragma unroll
-                    for (int k = 0; k < RPL; k++) z |= c[k] && !(hap[k] & mk);
-                    if (__ballot(z)) {
-#pragma unroll
-                        for (int k = 0; k < RPL; k++) c[k] = c[k] && !(hap[k] & mk);
-                    }
-                }
-                uint32_t cnt = 0, khi = 0, klo = 0;
-                bool have_key = false;
+            // ---- count phase of print_haplotypes (:383-411): the haplotype words of the rows that are not bad are compacted into
+            // LDS, sorted (bitonic, one wave, 32-bit keys when the window has at most 32 columns) and run-length counted - ascending
+            // key order falls out. (The reference's BTreeMap does the same in O(R log H); repeated minimum extraction over the
+            // lanes cost O(H x ncols x RPL) ballots and was 98 % of this kernel at 500x.)
+            const uint32_t lead = has_zero ? 0u : 1u;   // the zero-count reference group goes first (:429-431)
+            uint32_t ng = 0;
+            auto count_sorted = [&](auto* keys) {
+                using K = typename std::remove_pointer<decltype(keys)>::type;
+                uint32_t n_act = 0;
 #pragma unroll
                 for (int k = 0; k < RPL; k++) {
-                    const uint64_t m = __ballot(c[k]);
-                    cnt += __popcll(m);
-                    if (m && !have_key) {
-                        const uint32_t l = __builtin_ctzll(m);
-                        khi = rdlane(uint32_t(hap[k] >> 32), l);
-                        klo = rdlane(uint32_t(hap[k]), l);
-                        have_key = true;
-                    }
-                    if (c[k]) act[k] = false;
+                    const uint64_t m = __ballot(act[k]);
+                    if (act[k]) keys[n_act + lanes_below(m, lane)] = K(hap[k]);
+                    n_act += __popcll(m);
                 }
-                if (lane == (ng & 63)) { sg_hi = khi; sg_lo = klo; sg_cnt = cnt; }
-                ng++;
-                if ((ng & 63) == 0) emit(true, gbase + ng - 64 + lane, sg_hi, sg_lo, sg_cnt);
-            }
-            if (ng & 63) emit(lane < (ng & 63), gbase + (ng & ~63u) + lane, sg_hi, sg_lo, sg_cnt);
+                uint32_t N = 64;
+                while (N < n_act) N <<= 1;
+                for (uint32_t i = n_act + lane; i < N; i += 64) keys[i] = K(~K(0));   // padding sorts to the end (never a key: see below)
+                __syncthreads();
+                bitonic_sort_wave<K>(keys, N, lane);
+                // group starts -> starts[0 .. n_groups], in order
+                uint32_t n_groups = 0;
+                for (uint32_t i0 = 0; i0 < n_act; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool is_start = i < n_act && (i == 0 || keys[i] != keys[i - 1]);
+                    const uint64_t m = __ballot(is_start);
+                    if (is_start) starts[n_groups + lanes_below(m, lane)] = uint16_t(i);
+                    n_groups += __popcll(m);
+                }
+                if (lane == 0) starts[n_groups] = uint16_t(n_act);
+                __syncthreads();
+                ng = n_groups + lead;
+                for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+                    const uint32_t g = g0 + lane;
+                    const bool on = g < ng;
+                    uint32_t kh = 0, kl = 0, cnt = 0;
+                    if (on && g >= lead) {
+                        const uint32_t a0 = starts[g - lead], a1 = starts[g - lead + 1];
+                        const uint64_t key = keys[a0];
+                        kh = uint32_t(key >> 32); kl = uint32_t(key); cnt = a1 - a0;
+                    }
+                    emit(on, gbase + g, kh, kl, cnt);
+                }
+            };
+            // 32-bit keys while the all-ones padding cannot be a haplotype word (at most 31 columns); a word has at most 63 bits
+            if (ncols < 32) count_sorted(reinterpret_cast<uint32_t*>(sk));
+            else count_sorted(sk);
+            __syncthreads();   // sk / starts are reused by the next window
             if (lane == 0) {
                 WinDyn wd;
                 wd.group_off = uint32_t(gbase);
