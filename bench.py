@@ -6,14 +6,21 @@
 
 Metric (BASELINE.json): peptide-windows/s, `somatic`, 9-mer (27 nt), on the synthetic 20k-transcript
 whole exome (30x, ~5 variant sites per window). A "step" is one pass of the
-hot path (K1 pileup bits -> K2 window replay -> K3 window sequences) over the batch, with the packed
-inputs already resident in HBM and the results left in HBM. Genes are independent units: every rank
-phases its own 20k-transcript exome (seed 2020 + rank) with no data-path collective -> weak scaling.
+hot path (K1 pileup bits -> K2 window replay -> K3 window sequences -> K3b ids) over the batch, with
+the packed inputs already resident in HBM and the results left in HBM.
+
+Multi-GPU (BASELINE.json configs[2]: ONE 20k-transcript exome sharded across the GPUs): genes are
+independent units, so every rank takes the genes a cost-weighted partition gives it (longest
+processing time first on CDS_nt x depth), generates only those (the generator draws
+every gene from its own random stream, so the N ranks hold disjoint parts of the SAME exome) and
+phases them with no data-path collective. value = windows of the whole exome / slowest rank's
+time -> "scaling": "strong". N=1 runs the same exome on one GPU.
 
 The JSON line also carries
-  roofline      - the dominant kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak
-  cpu_baseline  - the CPU oracle (single thread, like the reference) on a bounded sample of the workload
-  end_to_end    - plan+pack, H2D, D2H+consume wall times of this rank (host side, outside `value`)
+  roofline                 - the dominant kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline             - the CPU oracle (single thread, like the reference) on a bounded sample of the workload
+  cpu_baseline_all_cores   - the same oracle with the sample's genes sharded over all host cores
+  end_to_end               - plan+pack+H2D, pass, D2H+consume wall times of rank 0 and the in-memory end-to-end rate
 """
 import argparse
 import json
@@ -34,19 +41,43 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(cfg_name, sample_transcripts):
+def effective_cores():
+    """Host cores this process may use: the affinity mask, capped by the cgroup CPU quota (a GPU box gives one GPU's job a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name, sample_transcripts, threads=1):
+    """The CPU oracle on a bounded sample of the workload (same generator, seed and parameters, fewer transcripts)."""
     seed, _n, depth, spacing = CONFIGS[cfg_name]
     cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
     r = subprocess.run([cli, "synth", "--seed", str(seed), "--transcripts", str(sample_transcripts), "--depth", str(depth),
-                        "--spacing", str(spacing)], capture_output=True, text=True)
+                        "--spacing", str(spacing), "--gene-streams", "--threads", str(threads)], capture_output=True, text=True)
     if r.returncode != 0:
         return None
     st = json.loads(r.stdout)
     return {
-        "value": st["windows"] / st["phase_seconds"], "unit": "peptide-windows/s", "cores": 1, "kind": "port",
-        "sample": "%d-transcript exome from the same generator and parameters (seed %d, %gx, spacing %g nt): %d windows in %.2f s; "
-                  "phasing only, inputs in memory; the Rust reference cannot be built here, the CPU oracle (C++ -O2, "
-                  "single thread like the reference) stands in" % (sample_transcripts, seed, depth, spacing, st["windows"], st["phase_seconds"]),
+        "value": st["windows"] / st["phase_seconds"], "unit": "peptide-windows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+        "sample": "%d-transcript exome from the same generator and parameters (seed %d, %gx, spacing %g nt): %d windows in %.2f s on %d thread(s); "
+                  "phasing only, inputs in memory (ingest excluded); the Rust reference cannot be built here, the CPU oracle (C++ -O2) stands in - "
+                  "single-threaded like the reference, or with the genes sharded over the host threads"
+                  % (sample_transcripts, seed, depth, spacing, st["windows"], st["phase_seconds"], threads),
     }
 
 
@@ -57,7 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C", choices=sorted(CONFIGS))
     ap.add_argument("--transcripts", type=int, default=0, help="override the transcript count (debugging)")
-    ap.add_argument("--cpu-sample", type=int, default=1000, help="transcripts in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="transcripts in the single-thread CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-all", type=int, default=4000, help="transcripts in the all-cores CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-consume", action="store_true", help="skip the end-to-end D2H + consumer leg")
     args = ap.parse_args()
 
@@ -92,12 +124,23 @@ def main():
     seed, n_tx, depth, spacing = CONFIGS[args.config]
     if args.transcripts:
         n_tx = args.transcripts
+    n_cores = effective_cores()
+    if world > 1:   # the ranks of one node share its host cores (planner / consumer threads)
+        os.environ.setdefault("MP_THREADS", str(max(1, n_cores // world)))
     ctx = m.Context(device_index)
     t0 = time.perf_counter()
-    ds = ctx.synth(seed + rank, n_tx, depth, spacing)
+    # one exome for all ranks: cost-weighted partition of its genes, every rank materialises only its own
+    my_genes = None
+    if world > 1:
+        from microphaser_amd.shard import lpt_partition
+        costs = ctx.synth_gene_costs(seed, n_tx, depth, spacing)
+        parts = lpt_partition(costs, world)
+        my_genes = parts[rank]
+        my_cost, total_cost = sum(costs[g] for g in my_genes), sum(costs)
+    ds = ctx.synth(seed, n_tx, depth, spacing, gene_streams=True, keep=my_genes)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    batch = ds.batch(window_len=27)   # plan + pack + H2D: inputs are resident in HBM from here on
+    batch = ds.batch(window_len=27)   # plan + pack + H2D of this rank's genes: inputs are resident in HBM from here on
     t_plan = time.perf_counter() - t0
 
     def sync_all():
@@ -157,44 +200,65 @@ def main():
         dom_ms, dom_bytes = kern[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes of this very command, so
-        # they come from the committed summary of those passes (tools/pmc_traffic.py), only when it is for this workload
-        traffic, traffic_src = None, None
+        # they come from the committed summary of those passes (tools/pmc_summary.py), only when it is for this workload
+        traffic, traffic_src, traffic_note = None, None, None
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_config%s.json" % args.config)), reverse=True):
             try:
                 pt = json.load(open(path))
             except (OSError, ValueError):
                 continue
-            if pt.get("config") == args.config and not args.transcripts and dom in pt.get("kernels", {}):
-                traffic, traffic_src = pt["kernels"][dom]["hbm_bytes"], os.path.relpath(path, ROOT)
+            hit = [k for k in pt if k.split("<")[0] == dom]
+            if hit and not args.transcripts and world == 1 and "fetch_bytes_raw" in pt[hit[0]]:
+                e = pt[hit[0]]
+                traffic = e["fetch_bytes_raw"] + e.get("write_bytes", 0.0)
+                traffic_src = os.path.relpath(path, ROOT)
+                traffic_note = ("FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch; with the gfx950 correction for wide streaming reads "
+                                "(FETCH_SIZE counts them at half, MI355X_MICROARCH.md HBM section) the read side is at most %.3g bytes" % e.get("fetch_bytes_x2", 0.0))
                 break
+        t_pass = elapsed_max / steps
         out = {
             "metric": "peptide-windows/s (somatic, 9-mer)", "value": value, "unit": "peptide-windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "synthetic %d-transcript exome per GPU, %gx, SNV every %g nt, 101-nt reads (SURVEY 8d config %s, seed %d+rank); "
-                                   "step = K1 + K2 (k2a admission, k2l one lane per window, k2w one wave per window for the wide ones; sequential k2 replay for the segments that need it) + K3 + K3b over the HBM-resident batch" % (n_tx, depth, spacing, args.config, seed),
-                       "windows_per_gpu": int(windows), "reads_per_gpu": int(st.n_reads), "variants_per_gpu": int(st.n_variants),
-                       "transcripts_per_gpu": int(st.n_transcripts), "window_len": 27, "sharding": "genes, no collective"},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "ONE synthetic %d-transcript exome, %gx, SNV every %g nt, 101-nt reads (SURVEY 8d config %s, seed %d, per-gene random streams)%s; "
+                                   "step = K1 + K2 (k2a admission, k2l one lane per window, k2w one wave per window for the wide ones; sequential k2 replay for the "
+                                   "segments that need it) + K3 + K3b over the HBM-resident batch"
+                                   % (n_tx, depth, spacing, args.config, seed,
+                                      "" if world == 1 else ", its genes dealt to the %d GPUs by estimated cost (LPT on CDS nt x depth)" % world),
+                       "windows_total": int(total_windows), "windows_rank0": int(windows), "reads_rank0": int(st.n_reads), "variants_rank0": int(st.n_variants),
+                       "transcripts_rank0": int(st.n_transcripts), "window_len": 27, "sharding": "genes (LPT on cost), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms,
+                         "limiter": "instruction issue / latency, not HBM (integer and bitset work: see DESIGN.md section 4 and profiles/)"},
             "kernels_ms": {k: v[0] for k, v in kern.items()},
             "kernels_algorithmic_bytes": {k: int(v[1]) for k, v in kern.items()},
+            "kernels_hbm_frac": {k: (v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else 0.0) for k, v in kern.items()},
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),
             "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm),
                        "windows_lane_kernel": int(st.n_windows_lane), "windows_wave_kernel": int(st.n_windows_wave)},
             "hbm_resident_bytes": int(st.hbm_bytes),
-            "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "d2h_consume_s": None if args.no_consume else t_consume,
+            "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "pass_s": t_pass, "d2h_consume_s": None if args.no_consume else t_consume,
+                           "windows_per_s": None if args.no_consume else windows / (t_plan + t_pass + t_consume),
+                           "host_threads": int(os.environ.get("MP_THREADS", "0")) or min(32, n_cores),
                            "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 1),
-                           "note": "host legs of rank 0 (planner and consumer shard genes over host threads); not part of `value`"},
+                           "note": "rank 0, in memory: decoded inputs -> plan + pack + H2D -> one pass -> D2H + consumer (FASTA / TSV text); "
+                                   "windows_per_s is this rank's windows over the sum of the three legs; not part of `value`"},
         }
+        if world > 1:
+            out["partition"] = {"rank0_cost_share": my_cost / total_cost, "ideal_share": 1.0 / world}
         if rehearse:
             out["rehearsal"] = "all ranks on one GPU, gloo reductions: functional check of the N-rank path, not a measurement"
         if world == 1 and args.cpu_sample > 0:
             cb = cpu_baseline(args.config, args.cpu_sample)
             if cb:
                 out["cpu_baseline"] = cb
+                out["vs_cpu_baseline"] = value / cb["value"]
+        if world == 1 and args.cpu_sample_all > 0 and n_cores > 1:
+            cb = cpu_baseline(args.config, args.cpu_sample_all, threads=n_cores)
+            if cb:
+                out["cpu_baseline_all_cores"] = cb
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

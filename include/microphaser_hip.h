@@ -55,11 +55,74 @@ typedef struct mp_synth_config {
     double indel_rate, multiallelic_rate, softmask_rate;
     double mate_rate;            /* fraction of reads followed by a same-name record starting at the same position */
     double isoform_rate;         /* fraction of genes with a second coding transcript (a prefix of the exons) */
+    /* Sharded generation (one exome over several GPUs, every rank materialises only its genes): with gene_streams != 0 every
+     * gene draws from its own random stream (seed, gene ordinal); gene_keep (NULL = all) holds one flag per transcript. */
+    uint32_t gene_streams, pad_;
+    const uint8_t* gene_keep;
 } mp_synth_config;
 int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* cfg, mp_dataset** out);
+/* Work estimate of every gene of the data set cfg describes (gene_streams != 0), without generating it: sum over its exons of
+ * (exon length + read length), i.e. proportional to CDS_nt x depth. costs holds cfg->n_transcripts entries. */
+int mp_synth_gene_costs(mp_ctx* ctx, const mp_synth_config* cfg, uint64_t* costs);
 /* Write prefix.{bam,vcf,gtf,fa,fa.fai} so that a CLI run sees the same inputs. */
 int mp_dataset_write(mp_ctx* ctx, const mp_dataset* ds, const char* prefix);
+/* ---- The phase_gene seam itself (reference: src/microphasing.rs:882-893, called per protein-coding gene from :1963-1979;
+ * normal twin src/normal_microphasing.rs:650-660): the host keeps its own readers (rust-htslib RecordBuffers, bio FASTA / GFF)
+ * and hands over, for a batch of genes, exactly what phase_gene works on - the Gene model as `phase` has built it, the bytes of
+ * refseq, the records read_buffer.iter() yields after fetch (BEFORE the mapq filter, :909-920) and the Variants of variant_tree
+ * (after Variant::new and the same-position overwrite, :932-942). Struct-of-arrays with CSR offsets; the caller owns everything
+ * for the duration of the call (the data set copies what it keeps). Positions are 0-based, intervals half-open. */
+typedef struct mp_gene_batch {
+    uint32_t n_genes;
+    uint32_t pad_;
+    /* genes (src/common.rs:224-253) */
+    const char* const* gene_id;      /* [n_genes] */
+    const char* const* gene_name;
+    const char* const* chrom;
+    const uint64_t* gene_start;      /* gene.start() / gene.end() */
+    const uint64_t* gene_end;
+    const uint64_t* ref_off;         /* [n_genes + 1] into refseq: gene g owns bytes of [gene.start, gene.end + 100), case preserved (:895-901) */
+    const uint8_t* refseq;
+    /* transcripts of gene g: [tx_off[g], tx_off[g + 1])  (src/common.rs:271-291; all of them, coding or not) */
+    const uint32_t* tx_off;          /* [n_genes + 1] */
+    const char* const* tx_id;        /* [n_tx] */
+    const uint8_t* tx_strand;        /* 0 forward, 1 reverse */
+    const uint32_t* exon_off;        /* [n_tx + 1]; exons in the order Transcript.exons holds them */
+    const uint64_t* exon_start;      /* Interval { start, end, frame }  (src/common.rs:293-338) */
+    const uint64_t* exon_end;
+    const uint64_t* exon_frame;
+    /* reads of gene g: [read_off[g], read_off[g + 1]) of the read arrays, in the order the buffer yields them */
+    const uint64_t* read_off;        /* [n_genes + 1] */
+    const int64_t* r_pos;            /* [n_reads] bam::Record::pos() */
+    const uint8_t* r_mapq;
+    const uint16_t* r_flag;
+    const uint64_t* r_cigar_off;     /* [n_reads + 1] into cigar: BAM-encoded ops (len << 4 | op, op in MIDNSHP=X) */
+    const uint32_t* cigar;
+    const uint64_t* r_seq_off;       /* [n_reads + 1] in BASES: read r has l_seq = r_seq_off[r + 1] - r_seq_off[r] */
+    const uint8_t* seq;              /* one byte per base: what bam::Record::seq().as_bytes() returns (upper-case "=ACMGRSVTWYHKDBN") */
+    const uint8_t* qual;             /* one byte per base, same offsets (bam::Record::qual()) */
+    const uint64_t* r_qname_hash;    /* any hash of qname(): `contains` (:281-294) only compares names for equality */
+    /* variants of gene g: [var_off[g], var_off[g + 1]), ascending position, ALT order within a position (src/common.rs:38-59) */
+    const uint64_t* var_off;         /* [n_genes + 1] */
+    const uint64_t* v_pos;
+    const uint8_t* v_kind;           /* 0 SNV, 1 Insertion, 2 Deletion */
+    const uint8_t* v_alt;            /* SNV: the alt base as written in the VCF */
+    const uint64_t* v_len;           /* indel length (Variant::Insertion/Deletion len) */
+    const uint8_t* v_is_germline;
+    const uint64_t* v_seq_off;       /* [n_vars + 1] into v_seq: insertion = whole ALT incl. the anchor base; empty otherwise */
+    const char* v_seq;
+    const char* const* v_prot_change;/* [n_vars] (may be "") */
+} mp_gene_batch;
+int mp_dataset_from_arrays(mp_ctx* ctx, const mp_gene_batch* genes, mp_dataset** out);
+/* The same view of a loaded / synthetic data set (what a host would have handed over); owned by the library until freed.
+ * mode selects the gene model (`normal` ignores three_prime_utr records, src/normal_microphasing.rs:1319-1433). */
+int mp_dataset_to_arrays(mp_ctx* ctx, const mp_dataset* ds, int mode, mp_gene_batch** out);
+void mp_gene_batch_free(mp_gene_batch* b);
+
 uint32_t mp_dataset_num_genes(const mp_dataset* ds);   /* protein-coding genes, GTF order */
+/* Work estimate per gene for sharding genes over GPUs (cost ~ sum of CDS_nt x depth): coding nucleotides x mean read
+ * depth of the gene's records. costs holds mp_dataset_num_genes entries. */
+int mp_dataset_gene_costs(mp_ctx* ctx, const mp_dataset* ds, uint64_t* costs);
 uint64_t mp_dataset_num_reads(const mp_dataset* ds);
 void mp_dataset_free(mp_dataset* ds);
 
@@ -89,6 +152,10 @@ typedef struct mp_run_stats {
  * src/microphasing.rs:905-1342). */
 int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, uint32_t gene_lo, uint32_t gene_hi,
                     mp_batch** out);
+/* The same for an arbitrary, strictly ascending list of genes: a shard of a cost-balanced partition (genes are independent
+ * units, src/microphasing.rs:895-942). The results list these genes in the given order. */
+int mp_batch_create_genes(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, const uint32_t* genes, uint32_t n_genes,
+                          mp_batch** out);
 /* One pass of the hot path over the resident batch: read pileup -> haplotype bitsets,
  * sliding-window haplotype counting, window sequences (replaces ObservationMatrix::{cleanup_reads,
  * shrink_left, push_read, extend_right} and the count + sequence phases of print_haplotypes,
@@ -108,6 +175,10 @@ const char* mp_results_fasta(const mp_results* r, size_t* len);         /* stdou
 const char* mp_results_normal_fasta(const mp_results* r, size_t* len);  /* --normal-output     */
 const char* mp_results_tsv(const mp_results* r, size_t* len);           /* --tsv               */
 uint64_t mp_results_windows(const mp_results* r);  /* main-ORF print_haplotypes calls actually made */
+/* Byte offsets of the batch's genes in a stream (which: 0 stdout FASTA, 1 normal FASTA, 2 TSV): n_genes + 1 values, gene k owns
+ * [off[k], off[k + 1]); off[0] is the length of the TSV header line (0 for the FASTA streams, and for an empty TSV). With them a
+ * host merges the shards of several GPUs back into GTF order - the reference's output order. */
+const uint64_t* mp_results_gene_offsets(const mp_results* r, int which, size_t* n_plus_1);
 void mp_results_free(mp_results* r);
 
 /* `microphaser build_reference` (reference: peptides::build, src/peptides.rs:148-186 <- run_build, src/main.rs:146-169):
@@ -116,12 +187,20 @@ void mp_results_free(mp_results* r);
  * GPU. peptide_len <= 12. */
 typedef struct mp_peptides mp_peptides;
 int mp_build_reference(mp_ctx* ctx, const char* fasta_path, uint32_t peptide_len, mp_peptides** out);
+int mp_build_reference_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, uint32_t peptide_len, mp_peptides** out);   /* the FASTA's bytes */
 const char* mp_peptides_fasta(const mp_peptides* p, size_t* len);     /* stdout of build_reference            */
 const char* mp_peptides_binary(const mp_peptides* p, size_t* len);    /* --output: bincode HashSet<Vec<u8>>   */
 const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n);    /* sorted distinct keys (5 bits/residue): the unit
                                                                          exchanged in the multi-GPU peptidome union */
 uint64_t mp_peptides_count(const mp_peptides* p);                     /* translated windows                   */
 void mp_peptides_free(mp_peptides* p);
+/* to_protein (reference: src/peptides.rs:128-146) for n windows of 3 * peptide_len nucleotides laid out back to back in nt;
+ * reverse[i] != 0: reverse complement first (ids that do not end in 'F', :161-164). aa gets n * peptide_len residues (stop = 'X'),
+ * keys (may be NULL) the 5-bit-per-residue keys. Runs on the GPU. */
+int mp_translate(mp_ctx* ctx, const uint8_t* nt, const uint8_t* reverse, uint64_t n, uint32_t peptide_len, uint8_t* aa, uint64_t* keys);
+/* The exchange step of a multi-GPU build_reference: the union of sorted distinct key arrays (one per rank, as
+ * all-gathered) -> one peptidome with the same accessors (its FASTA stream is empty). Host-side merge of sorted runs; no GPU needed. */
+int mp_peptides_union(mp_ctx* ctx, const uint64_t* const* keys, const uint64_t* counts, uint32_t n_arrays, uint32_t peptide_len, mp_peptides** out);
 
 /* `microphaser filter` (reference: peptides::filter, src/peptides.rs:221-709 <- run_filtering, src/main.rs:170-214,
  * src/filter_cli.yaml): translate the mutant / normal windows of a `somatic` info.tsv, drop self-similar, repeated and

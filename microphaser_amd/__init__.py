@@ -32,7 +32,91 @@ class SynthConfig(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("n_transcripts", ctypes.c_uint32), ("read_len", ctypes.c_uint32),
                 ("depth", ctypes.c_double), ("var_spacing", ctypes.c_double),
                 ("indel_rate", ctypes.c_double), ("multiallelic_rate", ctypes.c_double), ("softmask_rate", ctypes.c_double),
-                ("mate_rate", ctypes.c_double), ("isoform_rate", ctypes.c_double)]
+                ("mate_rate", ctypes.c_double), ("isoform_rate", ctypes.c_double),
+                ("gene_streams", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("gene_keep", ctypes.c_void_p)]
+
+
+class GeneBatch(ctypes.Structure):
+    """include/microphaser_hip.h mp_gene_batch: the phase_gene-level inputs of a batch of genes as struct-of-arrays."""
+    _P = ctypes.c_void_p
+    _fields_ = [("n_genes", ctypes.c_uint32), ("pad_", ctypes.c_uint32)] + [(n, ctypes.c_void_p) for n in (
+        "gene_id", "gene_name", "chrom", "gene_start", "gene_end", "ref_off", "refseq",
+        "tx_off", "tx_id", "tx_strand", "exon_off", "exon_start", "exon_end", "exon_frame",
+        "read_off", "r_pos", "r_mapq", "r_flag", "r_cigar_off", "cigar", "r_seq_off", "seq", "qual", "r_qname_hash",
+        "var_off", "v_pos", "v_kind", "v_alt", "v_len", "v_is_germline", "v_seq_off", "v_seq", "v_prot_change")]
+
+
+# (field, numpy dtype, which count gives its length) of the plain arrays of a GeneBatch; strings are handled apart
+_GB_ARRAYS = [
+    ("gene_start", "u8", "g"), ("gene_end", "u8", "g"), ("ref_off", "u8", "g+1"), ("refseq", "u1", "ref"),
+    ("tx_off", "u4", "g+1"), ("tx_strand", "u1", "t"), ("exon_off", "u4", "t+1"), ("exon_start", "u8", "e"), ("exon_end", "u8", "e"), ("exon_frame", "u8", "e"),
+    ("read_off", "u8", "g+1"), ("r_pos", "i8", "r"), ("r_mapq", "u1", "r"), ("r_flag", "u2", "r"), ("r_cigar_off", "u8", "r+1"), ("cigar", "u4", "cig"),
+    ("r_seq_off", "u8", "r+1"), ("seq", "u1", "b"), ("qual", "u1", "b"), ("r_qname_hash", "u8", "r"),
+    ("var_off", "u8", "g+1"), ("v_pos", "u8", "v"), ("v_kind", "u1", "v"), ("v_alt", "u1", "v"), ("v_len", "u8", "v"), ("v_is_germline", "u1", "v"),
+    ("v_seq_off", "u8", "v+1"), ("v_seq", "u1", "vs"),
+]
+_GB_STRINGS = [("gene_id", "g"), ("gene_name", "g"), ("chrom", "g"), ("tx_id", "t"), ("v_prot_change", "v")]
+
+
+def gene_batch_to_python(gb):
+    """Copy an mp_gene_batch (ctypes GeneBatch) into host-owned numpy arrays / lists of bytes: dict field -> value."""
+    import numpy as np
+
+    def arr(ptr, dtype, n):
+        if not n:
+            return np.zeros(0, dtype=dtype)
+        nbytes = n * np.dtype(dtype).itemsize
+        return np.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=dtype).copy()
+
+    g = gb.n_genes
+    out = {"n_genes": g}
+    counts = {"g": g, "g+1": g + 1}
+    for name in ("ref_off", "tx_off", "read_off", "var_off"):
+        dt = "u4" if name == "tx_off" else "u8"
+        out[name] = arr(getattr(gb, name), dt, g + 1)
+    counts["ref"] = int(out["ref_off"][-1]) if g else 0
+    counts["t"] = int(out["tx_off"][-1]) if g else 0
+    counts["t+1"] = counts["t"] + 1
+    counts["r"] = int(out["read_off"][-1]) if g else 0
+    counts["r+1"] = counts["r"] + 1
+    counts["v"] = int(out["var_off"][-1]) if g else 0
+    counts["v+1"] = counts["v"] + 1
+    out["exon_off"] = arr(gb.exon_off, "u4", counts["t+1"])
+    counts["e"] = int(out["exon_off"][-1])
+    out["r_cigar_off"] = arr(gb.r_cigar_off, "u8", counts["r+1"])
+    counts["cig"] = int(out["r_cigar_off"][-1])
+    out["r_seq_off"] = arr(gb.r_seq_off, "u8", counts["r+1"])
+    counts["b"] = int(out["r_seq_off"][-1])
+    out["v_seq_off"] = arr(gb.v_seq_off, "u8", counts["v+1"])
+    counts["vs"] = int(out["v_seq_off"][-1])
+    for name, dt, cnt in _GB_ARRAYS:
+        if name not in out:
+            out[name] = arr(getattr(gb, name), dt, counts[cnt])
+    for name, cnt in _GB_STRINGS:
+        n = counts[cnt]
+        ptrs = (ctypes.c_char_p * n).from_address(getattr(gb, name)) if n else []
+        out[name] = [bytes(x) if x is not None else b"" for x in ptrs]
+    return out
+
+
+def gene_batch_from_python(d):
+    """The inverse: a ctypes GeneBatch whose pointers refer to the arrays of `d` (returned too: keep them alive during the call)."""
+    import numpy as np
+    gb = GeneBatch()
+    gb.n_genes = d["n_genes"]
+    keep = []
+    for name, dt, _cnt in _GB_ARRAYS:
+        a = np.ascontiguousarray(d[name], dtype=dt)
+        if a.size == 0:
+            a = np.zeros(1, dtype=dt)
+        keep.append(a)
+        setattr(gb, name, a.ctypes.data)
+    for name, _cnt in _GB_STRINGS:
+        lst = d[name]
+        arr = (ctypes.c_char_p * max(1, len(lst)))(*lst)
+        keep.append(arr)
+        setattr(gb, name, ctypes.cast(arr, ctypes.c_void_p).value)
+    return gb, keep
 
 
 class RunStats(ctypes.Structure):
@@ -75,6 +159,15 @@ def lib():
         "mp_dataset_load": (i32, [vp, cp, cp, cp, cp, i32, pp]),
         "mp_dataset_synth": (i32, [vp, u64, u32, dbl, dbl, pp]),
         "mp_dataset_synth_ex": (i32, [vp, ctypes.POINTER(SynthConfig), pp]),
+        "mp_synth_gene_costs": (i32, [vp, ctypes.POINTER(SynthConfig), ctypes.POINTER(u64)]),
+        "mp_dataset_from_arrays": (i32, [vp, ctypes.POINTER(GeneBatch), pp]),
+        "mp_dataset_to_arrays": (i32, [vp, vp, i32, ctypes.POINTER(ctypes.POINTER(GeneBatch))]),
+        "mp_gene_batch_free": (None, [ctypes.POINTER(GeneBatch)]),
+        "mp_dataset_gene_costs": (i32, [vp, vp, ctypes.POINTER(u64)]),
+        "mp_batch_create_genes": (i32, [vp, vp, i32, u64, ctypes.POINTER(u32), u32, pp]),
+        "mp_results_gene_offsets": (vp, [vp, i32, ctypes.POINTER(ctypes.c_size_t)]),
+        "mp_translate": (i32, [vp, cp, cp, u64, u32, vp, vp]),
+        "mp_peptides_union": (i32, [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), u32, u32, pp]),
         "mp_dataset_write": (i32, [vp, vp, cp]),
         "mp_dataset_num_genes": (u32, [vp]),
         "mp_dataset_num_reads": (u64, [vp]),
@@ -90,6 +183,7 @@ def lib():
         "mp_results_windows": (u64, [vp]),
         "mp_results_free": (None, [vp]),
         "mp_build_reference": (i32, [vp, cp, u32, pp]),
+        "mp_build_reference_buffer": (i32, [vp, cp, ctypes.c_size_t, u32, pp]),
         "mp_peptides_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_peptides_binary": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_peptides_keys": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
@@ -121,6 +215,8 @@ C_ABI_SYMBOLS = [
     "mp_build_reference", "mp_peptides_fasta", "mp_peptides_binary", "mp_peptides_keys", "mp_peptides_count", "mp_peptides_free",
     "mp_filter", "mp_filter_buffers", "mp_filtered_fasta", "mp_filtered_normal_fasta", "mp_filtered_tsv", "mp_filtered_removed_tsv",
     "mp_filtered_removed_fasta", "mp_filtered_count", "mp_filtered_free",
+    "mp_synth_gene_costs", "mp_dataset_from_arrays", "mp_dataset_to_arrays", "mp_gene_batch_free", "mp_dataset_gene_costs",
+    "mp_batch_create_genes", "mp_results_gene_offsets", "mp_translate", "mp_peptides_union", "mp_build_reference_buffer",
 ]
 
 
@@ -164,7 +260,10 @@ class Context:
     def build_reference(self, fasta_path, peptide_len=9):
         """`microphaser build_reference`: translation + peptide de-duplication on the GPU."""
         h = ctypes.c_void_p()
-        self._check(lib().mp_build_reference(self._h, fasta_path.encode(), peptide_len, ctypes.byref(h)))
+        if isinstance(fasta_path, bytes):   # the FASTA's bytes instead of a path
+            self._check(lib().mp_build_reference_buffer(self._h, fasta_path, len(fasta_path), peptide_len, ctypes.byref(h)))
+        else:
+            self._check(lib().mp_build_reference(self._h, fasta_path.encode(), peptide_len, ctypes.byref(h)))
         return Peptides(h)
 
     def filter(self, tsv, reference_binary, peptide_len=9):
@@ -176,14 +275,58 @@ class Context:
             self._check(lib().mp_filter(self._h, tsv.encode(), reference_binary.encode(), peptide_len, ctypes.byref(h)))
         return Filtered(h)
 
-    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0, read_len=0, mate_rate=0.0, isoform_rate=0.0):
+    def synth(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, indel_rate=0.0, multiallelic_rate=0.0, softmask_rate=0.0, read_len=0, mate_rate=0.0,
+              isoform_rate=0.0, gene_streams=False, keep=None):
+        """Deterministic synthetic exome. gene_streams: every gene has its own random stream, so that `keep` (an iterable of gene
+        ordinals, None = all) materialises a subset of the SAME exome - what a rank of a multi-GPU run does."""
         h = ctypes.c_void_p()
-        if indel_rate or multiallelic_rate or softmask_rate or read_len or mate_rate or isoform_rate:
-            cfg = SynthConfig(seed, n_transcripts, read_len, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate, mate_rate, isoform_rate)
+        if indel_rate or multiallelic_rate or softmask_rate or read_len or mate_rate or isoform_rate or gene_streams or keep is not None:
+            cfg = SynthConfig(seed, n_transcripts, read_len, depth, var_spacing, indel_rate, multiallelic_rate, softmask_rate, mate_rate, isoform_rate,
+                              1 if (gene_streams or keep is not None) else 0, 0, None)
+            mask = None
+            if keep is not None:
+                mask = (ctypes.c_uint8 * n_transcripts)()
+                for g in keep:
+                    mask[g] = 1
+                cfg.gene_keep = ctypes.cast(mask, ctypes.c_void_p)
             self._check(lib().mp_dataset_synth_ex(self._h, ctypes.byref(cfg), ctypes.byref(h)))
         else:
             self._check(lib().mp_dataset_synth(self._h, seed, n_transcripts, depth, var_spacing, ctypes.byref(h)))
         return Dataset(self, h)
+
+    def from_arrays(self, arrays):
+        """A data set from decoded records (the phase_gene seam, mp_dataset_from_arrays): `arrays` as gene_batch_to_python returns it."""
+        gb, keep = gene_batch_from_python(arrays)
+        h = ctypes.c_void_p()
+        self._check(lib().mp_dataset_from_arrays(self._h, ctypes.byref(gb), ctypes.byref(h)))
+        del keep
+        return Dataset(self, h)
+
+    def translate(self, nt, reverse, peptide_len):
+        """to_protein on the GPU for len(reverse) windows of 3 * peptide_len nucleotides: (amino acids bytes, list of keys)."""
+        n = len(reverse)
+        assert len(nt) == n * 3 * peptide_len
+        aa = ctypes.create_string_buffer(max(1, n * peptide_len))
+        keys = (ctypes.c_uint64 * max(1, n))()
+        self._check(lib().mp_translate(self._h, bytes(nt), bytes(bytearray(reverse)), n, peptide_len, ctypes.cast(aa, ctypes.c_void_p), ctypes.cast(keys, ctypes.c_void_p)))
+        return aa.raw[:n * peptide_len], list(keys)[:n]
+
+    def peptides_union(self, key_arrays, peptide_len):
+        """Union of sorted distinct key arrays (one per rank) -> Peptides (keys, binary)."""
+        import numpy as np
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in key_arrays]
+        ptrs = (ctypes.c_void_p * max(1, len(arrs)))(*[a.ctypes.data if a.size else None for a in arrs])
+        counts = (ctypes.c_uint64 * max(1, len(arrs)))(*[a.size for a in arrs])
+        h = ctypes.c_void_p()
+        self._check(lib().mp_peptides_union(self._h, ptrs, counts, len(arrs), peptide_len, ctypes.byref(h)))
+        return Peptides(h)
+
+    def synth_gene_costs(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, read_len=0):
+        """Work estimate per gene (CDS nt + one read length per exon, i.e. ~ reads and windows) of the gene_streams exome, without generating it."""
+        cfg = SynthConfig(seed, n_transcripts, read_len, depth, var_spacing, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 0, None)
+        out = (ctypes.c_uint64 * n_transcripts)()
+        self._check(lib().mp_synth_gene_costs(self._h, ctypes.byref(cfg), out))
+        return list(out)
 
 
 def _bytes_at(p, n):
@@ -266,6 +409,30 @@ class Dataset:
         self.ctx._check(lib().mp_batch_create(self.ctx._h, self._h, mode, window_len, gene_lo, hi, ctypes.byref(h)))
         return Batch(self.ctx, h, self)
 
+    def batch_genes(self, genes, window_len=27, mode=MODE_SOMATIC):
+        """Plan + pack an arbitrary ascending list of genes (a shard of a cost-balanced partition)."""
+        genes = list(genes)
+        arr = (ctypes.c_uint32 * max(1, len(genes)))(*genes)
+        h = ctypes.c_void_p()
+        self.ctx._check(lib().mp_batch_create_genes(self.ctx._h, self._h, mode, window_len, arr, len(genes), ctypes.byref(h)))
+        return Batch(self.ctx, h, self)
+
+    def gene_costs(self):
+        """Work estimate per gene (coding nt x read depth), for sharding genes over GPUs."""
+        n = self.num_genes
+        out = (ctypes.c_uint64 * max(1, n))()
+        self.ctx._check(lib().mp_dataset_gene_costs(self.ctx._h, self._h, out))
+        return list(out)[:n]
+
+    def to_arrays(self, mode=MODE_SOMATIC):
+        """The phase_gene-level inputs of every gene as host-owned arrays (gene_batch_to_python of mp_dataset_to_arrays)."""
+        p = ctypes.POINTER(GeneBatch)()
+        self.ctx._check(lib().mp_dataset_to_arrays(self.ctx._h, self._h, mode, ctypes.byref(p)))
+        try:
+            return gene_batch_to_python(p.contents)
+        finally:
+            lib().mp_gene_batch_free(p)
+
     def phase(self, window_len=27, mode=MODE_SOMATIC):
         """`microphaser somatic` on this data set: returns Results (fasta, normal_fasta, tsv)."""
         h = ctypes.c_void_p()
@@ -330,6 +497,12 @@ class Results:
         n = ctypes.c_size_t()
         getattr(lib(), "mp_results_" + name)(self._h, ctypes.byref(n))
         return n.value
+
+    def gene_offsets(self, which):
+        """Byte offsets of the batch's genes in a stream (0 fasta, 1 normal fasta, 2 tsv): n_genes + 1 values."""
+        n = ctypes.c_size_t()
+        p = lib().mp_results_gene_offsets(self._h, which, ctypes.byref(n))
+        return list((ctypes.c_uint64 * n.value).from_address(p)) if n.value else []
 
     @property
     def fasta(self):

@@ -91,8 +91,13 @@ struct Batch {
     uint64_t bytes_k1_out() const;
 };
 
-// Build the batch + plan for a list of loaded genes, for `somatic` (normal = false) or `normal` mode.
-void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& reads, uint64_t window_len, bool normal, Batch& out);
+// Build the batch + plan for a list of loaded genes (any subset, in output order), for `somatic` (normal = false) or `normal` mode.
+void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore& reads, uint64_t window_len, bool normal, Batch& out);
+inline void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& reads, uint64_t window_len, bool normal, Batch& out) {
+    std::vector<const GeneInput*> ptrs(n_genes);
+    for (size_t g = 0; g < n_genes; g++) ptrs[g] = genes + g;
+    build_batch(ptrs.data(), n_genes, reads, window_len, normal, out);
+}
 inline void build_batch(const std::vector<GeneInput>& genes, const ReadStore& reads, uint64_t window_len, bool normal, Batch& out) {
     build_batch(genes.data(), genes.size(), reads, window_len, normal, out);
 }

@@ -18,54 +18,8 @@
 
 using namespace mp;
 
-struct mp_ctx {
-    std::unique_ptr<DeviceContext> dev;
-    const void* resident = nullptr;   // the batch whose buffers the device context currently holds (one at a time)
-    const void* last_run = nullptr;   // the batch the device results belong to
-    std::string err;
-};
-struct mp_dataset {
-    Dataset ds;
-};
-struct mp_batch {
-    Batch batch;                   // GeneHost::input points into the data set, which must outlive the batch
-    const ReadStore* reads = nullptr;
-    bool uploaded = false, ran = false;
-    RunTiming timing;
-    uint64_t sum_wlen = 0, sum_cols = 0;  // cached for the byte accounting
-    uint64_t w_steps = 0, w_wins = 0;     // steps / printing steps replayed window-parallel
-    bool w_wins_known = false;
-};
-struct mp_results {
-    PhasedStreams out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty
-};
-struct mp_filtered {
-    FilterResult res;
-};
-struct mp_peptides {
-    PeptideResult res;
-    std::string bin;
-};
+#include "capi_types.hpp"
 
-namespace {
-template <class F>
-int guarded(mp_ctx* ctx, F&& f) {
-    try {
-        f();
-        return 0;
-    } catch (const std::exception& e) {
-        if (ctx) ctx->err = e.what();
-        return 1;
-    } catch (...) {
-        if (ctx) ctx->err = "unknown error";
-        return 1;
-    }
-}
-DeviceContext& need_device(mp_ctx* ctx) {
-    if (!ctx->dev) throw Error("this context has no GPU (created with device -1): the phasing kernels need an MI355X, there is no CPU fallback");
-    return *ctx->dev;
-}
-}  // namespace
 
 namespace {
 // MP_DEBUG=1: wall time of every C-ABI call that does real work (where an end-to-end run spends its time)
@@ -127,22 +81,37 @@ int mp_dataset_synth(mp_ctx* ctx, uint64_t seed, uint32_t n_transcripts, double 
     });
 }
 
+static SynthConfig synth_config_of(const mp_synth_config* c) {
+    SynthConfig cfg;
+    cfg.seed = c->seed;
+    cfg.n_transcripts = c->n_transcripts;
+    if (c->read_len) cfg.read_len = c->read_len;
+    cfg.depth = c->depth;
+    cfg.var_spacing = c->var_spacing;
+    cfg.indel_rate = c->indel_rate;
+    cfg.multiallelic_rate = c->multiallelic_rate;
+    cfg.softmask_rate = c->softmask_rate;
+    cfg.mate_rate = c->mate_rate;
+    cfg.isoform_rate = c->isoform_rate;
+    cfg.gene_streams = c->gene_streams != 0;
+    if (c->gene_keep) cfg.keep.assign(c->gene_keep, c->gene_keep + c->n_transcripts);
+    return cfg;
+}
+
 int mp_dataset_synth_ex(mp_ctx* ctx, const mp_synth_config* c, mp_dataset** out) {
     return guarded(ctx, [&] {
         std::unique_ptr<mp_dataset> d(new mp_dataset());
-        SynthConfig cfg;
-        cfg.seed = c->seed;
-        cfg.n_transcripts = c->n_transcripts;
-        if (c->read_len) cfg.read_len = c->read_len;
-        cfg.depth = c->depth;
-        cfg.var_spacing = c->var_spacing;
-        cfg.indel_rate = c->indel_rate;
-        cfg.multiallelic_rate = c->multiallelic_rate;
-        cfg.softmask_rate = c->softmask_rate;
-        cfg.mate_rate = c->mate_rate;
-        cfg.isoform_rate = c->isoform_rate;
-        synth_generate(cfg, d->ds);
+        synth_generate(synth_config_of(c), d->ds);
         *out = d.release();
+    });
+}
+
+int mp_synth_gene_costs(mp_ctx* ctx, const mp_synth_config* c, uint64_t* costs) {
+    return guarded(ctx, [&] {
+        SynthConfig cfg = synth_config_of(c);
+        cfg.keep.clear();
+        const std::vector<uint64_t> v = synth_gene_costs(cfg);
+        std::copy(v.begin(), v.end(), costs);
     });
 }
 
@@ -180,10 +149,11 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
                          (unsigned long long)wsteps, b->batch.wchunks.size(), (unsigned long long)b->batch.n_adm);
         }
         if (ctx->dev) {
+            ctx->resident = nullptr;   // an upload that throws leaves nothing resident (the device context frees what it had allocated)
+            ctx->last_run = nullptr;
             ctx->dev->upload(b->batch);
             b->uploaded = true;
             ctx->resident = b.get();
-            ctx->last_run = nullptr;
         }
         *out = b.release();
     });
@@ -194,11 +164,20 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         if (!batch->uploaded || ctx->resident != batch) {   // another batch was made resident in between: bring this one back
+            ctx->resident = nullptr;
+            ctx->last_run = nullptr;
             dev.upload(batch->batch);
             batch->uploaded = true;
             ctx->resident = batch;
         }
-        dev.run(batch->timing);
+        try { dev.run(batch->timing); }
+        catch (...) {   // a failed pass may have re-sized or released buffers: nothing counts as resident, the next run uploads again
+            ctx->resident = nullptr;
+            ctx->last_run = nullptr;
+            batch->uploaded = false;
+            dev.free_batch();
+            throw;
+        }
         batch->ran = true;
         ctx->last_run = batch;
         if (st) {
@@ -303,6 +282,15 @@ int mp_build_reference(mp_ctx* ctx, const char* fasta_path, uint32_t peptide_len
         ss << in.rdbuf();
         std::unique_ptr<mp_peptides> p(new mp_peptides());
         build_reference_device(dev.device(), ss.str(), peptide_len, p->res);
+        p->bin = p->res.binary();
+        *out = p.release();
+    });
+}
+int mp_build_reference_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, uint32_t peptide_len, mp_peptides** out) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        std::unique_ptr<mp_peptides> p(new mp_peptides());
+        build_reference_device(dev.device(), std::string(fasta_text, len), peptide_len, p->res);
         p->bin = p->res.binary();
         *out = p.release();
     });

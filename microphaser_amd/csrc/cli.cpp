@@ -4,10 +4,13 @@
 //              [-n/--normal-output normal.fasta] [-w/--window-len 27] [-u] [-v]  < GTF  > FASTA
 // exit status 1 on error, message on stderr (src/main.rs:260-265).
 // Extra (not in the reference): --device N, or --devices a,b,... = genes sharded over several GPUs from this one process
-// (one context + host thread per GPU, contiguous gene ranges, outputs concatenated in gene order: byte-identical to one GPU).
+// (one context + host thread per GPU; the genes are dealt to the GPUs by estimated cost - longest processing time first on
+// coding nt x depth - and the shards' outputs are merged back into GTF order: byte-identical to one GPU).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,12 +23,16 @@ static int fail(mp_ctx* ctx, const char* what) {
     return 1;
 }
 
+// Every write is checked: a full disk or a closed pipe must end in exit status 1, not in a truncated file
+// (the reference propagates writer errors to main, src/main.rs:260-265).
 static bool write_file(const std::string& path, const char* data, size_t n) {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return false;
-    std::fwrite(data, 1, n, f);
-    std::fclose(f);
-    return true;
+    const bool ok = std::fwrite(data, 1, n, f) == n;
+    return (std::fclose(f) == 0) && ok;
+}
+static bool write_stdout(const char* data, size_t n) {
+    return std::fwrite(data, 1, n, stdout) == n && std::fflush(stdout) == 0;
 }
 
 int main(int argc, char** argv) {
@@ -61,7 +68,7 @@ int main(int argc, char** argv) {
         if (mp_build_reference(ctx, ref.c_str(), peptide_len, &pep) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
         size_t n = 0;
         const char* p = mp_peptides_fasta(pep, &n);
-        std::fwrite(p, 1, n, stdout);
+        if (!write_stdout(p, n)) { std::fprintf(stderr, "cannot write the translated FASTA to stdout\n"); return 1; }
         p = mp_peptides_binary(pep, &n);
         if (!write_file(outp, p, n)) { std::fprintf(stderr, "cannot write %s\n", outp.c_str()); return 1; }
         mp_peptides_free(pep);
@@ -98,7 +105,7 @@ int main(int argc, char** argv) {
         if (mp_filter(ctx, tsv.c_str(), ref.c_str(), peptide_len, &f) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
         size_t n = 0;
         const char* p = mp_filtered_fasta(f, &n);
-        std::fwrite(p, 1, n, stdout);
+        if (!write_stdout(p, n)) { std::fprintf(stderr, "cannot write the filtered FASTA to stdout\n"); return 1; }
         p = mp_filtered_normal_fasta(f, &n);
         if (!write_file(normo, p, n)) { std::fprintf(stderr, "cannot write %s\n", normo.c_str()); return 1; }
         p = mp_filtered_tsv(f, &n);
@@ -155,7 +162,8 @@ int main(int argc, char** argv) {
     if (mp_dataset_load(ctx, bam.c_str(), vcf.c_str(), ref.c_str(), nullptr, warn_only, &ds) != 0) { int rc = fail(ctx, "microphaser"); mp_destroy(ctx); return rc; }
     const int mode = normal_mode ? MP_MODE_NORMAL : MP_MODE_SOMATIC;
     if (devices.size() > 1) {
-        // genes are independent units (src/microphasing.rs:895-942): contiguous gene ranges, one context + thread per GPU
+        // genes are independent units (src/microphasing.rs:895-942): a cost-weighted deal of the genes (greedy longest
+        // processing time first on coding nt x depth), one context + thread per GPU, outputs merged back into GTF order
         const uint32_t ng = mp_dataset_num_genes(ds);
         const size_t nd = devices.size();
         {   // the data set builds its `normal` gene view lazily: do it once here, the shards then only read
@@ -163,41 +171,73 @@ int main(int argc, char** argv) {
             if (mp_batch_create(ctx, ds, mode, window_len, 0, 0, &warm) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
             mp_batch_free(warm);
         }
+        std::vector<uint64_t> cost(ng ? ng : 1);
+        if (mp_dataset_gene_costs(ctx, ds, cost.data()) != 0) { int rc = fail(ctx, "microphaser"); mp_dataset_free(ds); mp_destroy(ctx); return rc; }
+        std::vector<std::vector<uint32_t>> deal(nd);
+        {
+            std::vector<uint32_t> order(ng);
+            for (uint32_t g = 0; g < ng; g++) order[g] = g;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            typedef std::pair<uint64_t, size_t> Load;   // (load, device slot): the least loaded first, ties by slot
+            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
+            for (size_t k = 0; k < nd; k++) pq.push(Load(0, k));
+            for (uint32_t g : order) { Load l = pq.top(); pq.pop(); deal[l.second].push_back(g); pq.push(Load(l.first + cost[g], l.second)); }
+            for (auto& v : deal) std::sort(v.begin(), v.end());
+        }
         struct Shard { mp_ctx* ctx = nullptr; mp_results* res = nullptr; std::string err; };
         std::vector<Shard> shards(nd);
         std::vector<std::thread> th;
         for (size_t k = 0; k < nd; k++)
             th.emplace_back([&, k] {
                 Shard& sh = shards[k];
-                const uint32_t lo = uint32_t(uint64_t(ng) * k / nd), hi = uint32_t(uint64_t(ng) * (k + 1) / nd);
                 mp_batch* b = nullptr;
-                if (mp_create(devices[k], &sh.ctx) != 0 || mp_batch_create(sh.ctx, ds, mode, window_len, lo, hi, &b) != 0 ||
+                if (mp_create(devices[k], &sh.ctx) != 0 || mp_batch_create_genes(sh.ctx, ds, mode, window_len, deal[k].data(), uint32_t(deal[k].size()), &b) != 0 ||
                     mp_batch_run(sh.ctx, b, nullptr) != 0 || mp_batch_results(sh.ctx, b, &sh.res) != 0)
                     sh.err = sh.ctx ? mp_last_error(sh.ctx) : "mp_create failed";
                 if (b) mp_batch_free(b);
             });
         for (auto& t : th) t.join();
-        for (size_t k = 0; k < nd; k++)   // the first failing gene range in gene order, like a sequential run
-            if (!shards[k].err.empty()) { std::fprintf(stderr, "microphaser: %s\n", shards[k].err.c_str()); return 1; }
-        std::string fa, nfa, tsvs;
-        for (size_t k = 0; k < nd; k++) {
-            size_t n = 0;
-            const char* p = mp_results_fasta(shards[k].res, &n); fa.append(p, n);
-            p = mp_results_normal_fasta(shards[k].res, &n); nfa.append(p, n);
-            p = mp_results_tsv(shards[k].res, &n);
-            if (n) {   // the header is the first line of every non-empty shard: keep the first one only
-                if (tsvs.empty()) tsvs.append(p, n);
-                else { const char* nl = static_cast<const char*>(std::memchr(p, '\n', n)); if (nl) tsvs.append(nl + 1, size_t(p + n - (nl + 1))); }
-            }
-            mp_results_free(shards[k].res);
-            mp_destroy(shards[k].ctx);
+        auto release = [&] {
+            for (Shard& sh : shards) { if (sh.res) mp_results_free(sh.res); if (sh.ctx) mp_destroy(sh.ctx); sh.res = nullptr; sh.ctx = nullptr; }
+            mp_dataset_free(ds);
+            mp_destroy(ctx);
+        };
+        {   // the error of the first gene (in GTF order) whose shard failed, like a sequential run
+            size_t bad = nd;
+            for (size_t k = 0; k < nd; k++)
+                if (!shards[k].err.empty() && (bad == nd || (!deal[k].empty() && (deal[bad].empty() || deal[k][0] < deal[bad][0])))) bad = k;
+            if (bad != nd) { std::fprintf(stderr, "microphaser: %s\n", shards[bad].err.c_str()); release(); return 1; }
         }
-        std::fwrite(fa.data(), 1, fa.size(), stdout);
-        if (!normal_mode && !write_file(normal, nfa.data(), nfa.size())) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
-        if (!write_file(tsv, tsvs.data(), tsvs.size())) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
-        mp_dataset_free(ds);
-        mp_destroy(ctx);
-        return 0;
+        // merge by gene ordinal with the per-gene offsets of every shard; the TSV header line is kept once
+        std::vector<std::pair<uint32_t, uint32_t>> where(ng);   // gene -> (shard, index in the shard)
+        for (size_t k = 0; k < nd; k++) for (size_t i = 0; i < deal[k].size(); i++) where[deal[k][i]] = {uint32_t(k), uint32_t(i)};
+        std::string streams[3];
+        for (int which = 0; which < 3; which++) {
+            std::vector<const char*> base(nd);
+            std::vector<const uint64_t*> off(nd);
+            for (size_t k = 0; k < nd; k++) {
+                size_t n = 0, no = 0;
+                base[k] = which == 0 ? mp_results_fasta(shards[k].res, &n) : which == 1 ? mp_results_normal_fasta(shards[k].res, &n) : mp_results_tsv(shards[k].res, &n);
+                off[k] = mp_results_gene_offsets(shards[k].res, which, &no);
+                if (which == 2 && n && streams[2].empty() && no) streams[2].assign(base[k], size_t(off[k][0]));   // the header
+                if (no != deal[k].size() + 1) off[k] = nullptr;   // (an empty stream)
+            }
+            for (uint32_t g = 0; g < ng; g++) {
+                const auto w = where[g];
+                if (off[w.first]) streams[which].append(base[w.first] + off[w.first][w.second], size_t(off[w.first][w.second + 1] - off[w.first][w.second]));
+            }
+        }
+        {   // a TSV that is nothing but its header cannot happen (the header comes with the first record); keep it empty if no shard wrote
+            bool any = false;
+            for (size_t k = 0; k < nd; k++) { size_t n = 0; mp_results_tsv(shards[k].res, &n); any = any || n; }
+            if (!any) streams[2].clear();
+        }
+        int rc = 0;
+        if (!write_stdout(streams[0].data(), streams[0].size())) { std::fprintf(stderr, "cannot write the FASTA records to stdout\n"); rc = 1; }
+        if (!rc && !normal_mode && !write_file(normal, streams[1].data(), streams[1].size())) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); rc = 1; }
+        if (!rc && !write_file(tsv, streams[2].data(), streams[2].size())) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); rc = 1; }
+        release();
+        return rc;
     }
     mp_results* res = nullptr;
     mp_batch* batch = nullptr;
@@ -217,11 +257,11 @@ int main(int argc, char** argv) {
     });
     size_t n = 0;
     const char* p = mp_results_fasta(res, &n);
-    std::fwrite(p, 1, n, stdout);
-    std::fflush(stdout);
+    const bool stdout_ok = write_stdout(p, n);
     p = mp_results_normal_fasta(res, &n);
     const bool normal_ok = normal_mode || write_file(normal, p, n);
     tsv_writer.join();
+    if (!stdout_ok) { std::fprintf(stderr, "cannot write the FASTA records to stdout\n"); return 1; }
     if (!normal_ok) { std::fprintf(stderr, "cannot write %s\n", normal.c_str()); return 1; }
     if (!tsv_ok) { std::fprintf(stderr, "cannot write %s\n", tsv.c_str()); return 1; }
     const auto t_free = std::chrono::steady_clock::now();

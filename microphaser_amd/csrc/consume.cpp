@@ -743,6 +743,11 @@ struct NormalConsumerHooks {
     }
 };
 
+void reserve_streams(SomaticOutput& p, size_t recs) { p.tsv.reserve(recs * 340); p.fasta.reserve(recs * 52); p.normal_fasta.reserve(recs * 52); }
+void reserve_streams(NormalOutput& p, size_t recs) { p.tsv.reserve(recs * 320); p.fasta.reserve(recs * 56); }
+const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
+const std::string* normal_stream(const NormalOutput&) { return nullptr; }
+
 template <class Hooks, class Out>
 void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1, Out& out) {
     for (size_t g = g0; g < g1; g++) {
@@ -755,13 +760,11 @@ void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1,
             Hooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
             walk_transcript(gi.gene, t, vi, gh.max_read_len, b.window_len, hooks);
         }
+        const std::string* nf = normal_stream(out);
+        out.gene_ends.push_back(GeneEnds{out.fasta.size(), nf ? nf->size() : 0, out.tsv.size()});
     }
 }
 
-void reserve_streams(SomaticOutput& p, size_t recs) { p.tsv.reserve(recs * 340); p.fasta.reserve(recs * 52); p.normal_fasta.reserve(recs * 52); }
-void reserve_streams(NormalOutput& p, size_t recs) { p.tsv.reserve(recs * 320); p.fasta.reserve(recs * 56); }
-const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
-const std::string* normal_stream(const NormalOutput&) { return nullptr; }
 
 struct CopyTask { char* dst; const char* src; size_t n; };
 
@@ -784,16 +787,31 @@ void assemble(std::vector<Out>& parts, PhasedStreams& out, size_t nthreads) {
     };
     std::vector<std::pair<const char*, size_t>> fa, nfa, tsv;
     bool header = false;
+    uint64_t fa_at = 0, nfa_at = 0, tsv_at = 0, header_len = 0;
+    for (int k = 0; k < 3; k++) out.gene_off[k].assign(1, 0);
     for (Out& p : parts) {
         out.n_windows += p.n_windows;
         fa.push_back({p.fasta.data(), p.fasta.size()});
-        if (const std::string* n = normal_stream(p)) nfa.push_back({n->data(), n->size()});
+        const std::string* n = normal_stream(p);
+        if (n) nfa.push_back({n->data(), n->size()});
+        size_t skip = 0;
         if (!p.tsv.empty()) {
-            const size_t skip = header ? p.tsv.find('\n') + 1 : 0;
+            const size_t hl = p.tsv.find('\n') + 1;
+            skip = header ? hl : 0;
+            if (!header) header_len = hl;
             tsv.push_back({p.tsv.data() + skip, p.tsv.size() - skip});
             header = true;
         }
+        for (const GeneEnds& ge : p.gene_ends) {   // this range's genes, in the merged streams
+            out.gene_off[0].push_back(fa_at + ge.fasta);
+            out.gene_off[1].push_back(nfa_at + ge.normal_fasta);
+            out.gene_off[2].push_back(tsv_at + (ge.tsv > skip ? ge.tsv - skip : 0));
+        }
+        fa_at += p.fasta.size();
+        if (n) nfa_at += n->size();
+        tsv_at += p.tsv.size() - skip;
     }
+    for (uint64_t& o : out.gene_off[2]) o = std::max(o, header_len);   // the header line belongs to no gene
     plan(out.fasta, fa);
     plan(out.normal_fasta, nfa);
     plan(out.tsv, tsv);

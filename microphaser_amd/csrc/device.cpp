@@ -30,6 +30,8 @@ DeviceContext::~DeviceContext() {
 
 void* DeviceContext::dalloc(size_t bytes) {
     void* p = nullptr;
+    if (const char* lim = std::getenv("MP_TEST_ALLOC_LIMIT"))   // tests: allocations above this many bytes fail like an exhausted HBM
+        if (bytes > std::strtoull(lim, nullptr, 10)) throw_hip(hipErrorOutOfMemory, __FILE__, __LINE__);
     HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
     hbm_bytes_ += bytes;
     return p;
@@ -45,19 +47,28 @@ typename V::value_type* DeviceContext::up(const V& v) {
 }
 
 void DeviceContext::free_outputs() {
-    for (void* p : out_allocs_) hipFree(p);
+    for (void* p : out_allocs_) (void)hipFree(p);
     out_allocs_.clear();
+    hbm_bytes_ -= out_bytes_;
+    out_bytes_ = 0;
+    d_.groups = nullptr; d_.g_win = nullptr; d_.g_rec = nullptr; d_.gsum = nullptr; d_.recs = nullptr; d_.want_recs = nullptr;
 }
 
 void DeviceContext::free_batch() {
     free_outputs();
-    for (void* p : allocs_) hipFree(p);
+    for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
     hbm_bytes_ = 0;
+    out_bytes_ = 0;
     std::memset(&d_, 0, sizeof d_);
 }
 
 void DeviceContext::upload(const Batch& b) {
+    try { upload_impl(b); }
+    catch (...) { free_batch(); throw; }   // never leave a half-uploaded batch behind (dangling or null pointers in d_)
+}
+
+void DeviceContext::upload_impl(const Batch& b) {
     HIP_OK(hipSetDevice(device_));
     free_batch();
     std::vector<uint32_t> r_gene(b.r_pos.size());
@@ -155,11 +166,12 @@ void DeviceContext::upload(const Batch& b) {
 }
 
 void DeviceContext::alloc_outputs() {
+    if ((uint64_t(NPART) << glog_) > 0x7FFFFFFFull || (uint64_t(NPART) << rlog_) > 0x7FFFFFFFull)
+        throw Error("result buffers exceed 2^31 slots: split the batch by genes");   // (checked before anything is released)
     free_outputs();
     group_cap_ = uint64_t(NPART) << glog_;
     rec_cap_ = uint64_t(NPART) << rlog_;
-    if (group_cap_ > 0x7FFFFFFFull || rec_cap_ > 0x7FFFFFFFull) throw Error("result buffers exceed 2^31 slots: split the batch by genes");
-    auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); return p; };
+    auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); out_bytes_ += bytes; return p; };
     d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
     d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));

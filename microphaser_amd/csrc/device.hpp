@@ -56,6 +56,7 @@ class DeviceContext {
   private:
     void* dalloc(size_t bytes);
     template <class V> typename V::value_type* up(const V& v);
+    void upload_impl(const Batch& b);
     void alloc_outputs();
     void free_outputs();
     int device_ = 0;
@@ -63,7 +64,7 @@ class DeviceContext {
     hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs_, out_allocs_;
     DeviceBatch d_{};
-    uint64_t hbm_bytes_ = 0;
+    uint64_t hbm_bytes_ = 0, out_bytes_ = 0;   // device memory held by the batch; the result buffers' share (re-sized on overflow)
     uint64_t group_cap_ = 0, rec_cap_ = 0;          // NPART << log2
     uint32_t glog_ = 12, rlog_ = 12;                // log2 of one allocator's sub-range
     uint64_t used_g_[NPART] = {0}, used_r_[NPART] = {0};   // slots used by each allocator in the last run()

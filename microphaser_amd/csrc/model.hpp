@@ -195,10 +195,12 @@ struct IDRecord {
 };
 
 // The three output streams of `microphaser somatic` (stdout FASTA, --normal-output FASTA, --tsv).
+struct GeneEnds { uint64_t fasta, normal_fasta, tsv; };   // sizes of the three streams after a gene has been written
 struct SomaticOutput {
     std::string fasta, normal_fasta, tsv;
     bool tsv_header_written = false;
     uint64_t n_windows = 0;  // main-ORF print_haplotypes invocations (the benchmark unit)
+    std::vector<GeneEnds> gene_ends;   // filled by the device consumer only (one entry per gene of its range)
 };
 
 // `microphaser normal`: its own record type with a single peptide_sequence column
@@ -214,6 +216,7 @@ struct NormalOutput {
     std::string fasta, tsv;
     bool tsv_header_written = false;
     uint64_t n_windows = 0;
+    std::vector<GeneEnds> gene_ends;
 };
 
 // A finished output stream: one uninitialised allocation, so that the pieces written by the consumer threads are copied into it
@@ -227,6 +230,9 @@ struct Bytes {
 struct PhasedStreams {   // what mp_results holds: somatic -> three streams, normal -> fasta + tsv
     Bytes fasta, normal_fasta, tsv;
     uint64_t n_windows = 0;
+    // byte offsets of the batch's genes in each stream (n_genes + 1 entries; [0] = length of the TSV header line for the TSV):
+    // what a host needs to merge the shards of several GPUs back into GTF order
+    std::vector<uint64_t> gene_off[3];
 };
 
 }  // namespace mp

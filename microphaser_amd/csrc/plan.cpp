@@ -570,7 +570,7 @@ static void finalize_segments(Batch& b) {
     validate_segments(b);
 }
 
-static void build_batch_range(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b, bool finalize) {
+static void build_batch_range(const GeneInput* const* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b, bool finalize) {
     const uint8_t mapq_min = normal ? 0 : 5;  // src/microphasing.rs:910 vs src/normal_microphasing.rs:676-684
     b = Batch();
     b.window_len = window_len;
@@ -580,7 +580,7 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
     std::vector<uint32_t> pmax_end;
     {   // reserve the big pools once
         size_t nr = 0, nref = 0, nv = 0;
-        for (size_t g = 0; g < n_genes; g++) { nr += genes[g].reads.size(); nref += genes[g].refseq.size(); nv += genes[g].variants.size(); }
+        for (size_t g = 0; g < n_genes; g++) { nr += genes[g]->reads.size(); nref += genes[g]->refseq.size(); nv += genes[g]->variants.size(); }
         for (auto* v : {&b.r_pos, &b.r_end, &b.r_lseq, &b.r_ncig, &b.r_dup}) v->reserve(nr);
         for (auto* v : {&b.r_cigoff, &b.r_seqoff, &b.r_qualoff}) v->reserve(nr);
         b.r_src.reserve(nr);
@@ -593,7 +593,7 @@ static void build_batch_range(const GeneInput* genes, size_t n_genes, const Read
         b.wins.reserve(nref / 3);
     }
     for (size_t gi_ = 0; gi_ < n_genes; gi_++) {
-        const GeneInput& gi = genes[gi_];
+        const GeneInput& gi = *genes[gi_];
         GeneHost& gh = b.genes[gi_];
         gh.input = &gi;
         if (gi.gene.end() + 100 > 0xFFFFFFF0ull) throw Error("coordinate exceeds 32 bits");
@@ -858,11 +858,11 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
 }  // namespace
 
 // Genes are independent: plan gene ranges on worker threads, then concatenate the sub-batches in gene order.
-void build_batch(const GeneInput* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
+void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
     size_t nthreads = std::min(host_threads(), std::max<size_t>(1, n_genes / 8));
     if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, normal, b, true); return; }
     std::vector<uint64_t> cost(n_genes + 1, 0);
-    for (size_t g = 0; g < n_genes; g++) cost[g + 1] = cost[g] + genes[g].reads.size() + genes[g].refseq.size() / 8 + 1;
+    for (size_t g = 0; g < n_genes; g++) cost[g + 1] = cost[g] + genes[g]->reads.size() + genes[g]->refseq.size() / 8 + 1;
     std::vector<size_t> cut(nthreads + 1, n_genes);
     cut[0] = 0;
     for (size_t t = 1; t < nthreads; t++) {

@@ -67,9 +67,32 @@ struct SynVar {
 
 }  // namespace
 
-void synth_generate(const SynthConfig& cfg, Dataset& ds) {
+namespace {
+uint64_t stream_seed(uint64_t seed, uint64_t stream) {   // splitmix64 of (seed, stream): independent per-gene streams
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (stream + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+}  // namespace
+
+static void synth_generate_impl(const SynthConfig& cfg, Dataset& ds, std::vector<uint64_t>* costs_only);
+
+void synth_generate(const SynthConfig& cfg, Dataset& ds) { synth_generate_impl(cfg, ds, nullptr); }
+
+std::vector<uint64_t> synth_gene_costs(const SynthConfig& cfg) {
+    if (!cfg.gene_streams) throw Error("synth_gene_costs needs gene_streams");
+    std::vector<uint64_t> costs;
+    Dataset scratch;
+    synth_generate_impl(cfg, scratch, &costs);
+    return costs;
+}
+
+static void synth_generate_impl(const SynthConfig& cfg, Dataset& ds, std::vector<uint64_t>* costs_only) {
     ds = Dataset();
     Rng rng(cfg.seed);
+    if (!cfg.keep.empty() && (!cfg.gene_streams || cfg.keep.size() != cfg.n_transcripts))
+        throw Error("synthetic data set: a gene selection needs gene_streams and one flag per transcript");
     const uint32_t n_contigs = 4;
     const uint32_t L = cfg.read_len;
     ds.contig_names.resize(n_contigs);
@@ -85,7 +108,9 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
     std::vector<PendingRead> creads;              //  so sorting the reads of one gene keeps the BAM coordinate-sorted)
     {
         // rough totals, to avoid re-growing multi-GB pools
-        double reads_est = double(cfg.n_transcripts) * cfg.depth * 2750.0 / double(L) * 1.15;
+        uint64_t n_kept = cfg.n_transcripts;
+        if (!cfg.keep.empty()) { n_kept = 0; for (uint8_t k : cfg.keep) n_kept += k ? 1 : 0; }
+        double reads_est = costs_only ? 0.0 : double(n_kept) * cfg.depth * 2750.0 / double(L) * 1.15;
         rs.pos.reserve(size_t(reads_est)); rs.end_pos.reserve(size_t(reads_est)); rs.tid.reserve(size_t(reads_est));
         rs.mapq.reserve(size_t(reads_est)); rs.flag.reserve(size_t(reads_est)); rs.l_seq.reserve(size_t(reads_est));
         rs.n_cigar.reserve(size_t(reads_est)); rs.cigar_off.reserve(size_t(reads_est)); rs.seq_off.reserve(size_t(reads_est));
@@ -98,10 +123,12 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
     for (uint32_t c = 0; c < n_contigs; c++) {
         std::string& contig = ds.contig_seq[c];
         contig.assign(2000, 'N');
+        if (cfg.gene_streams) rng = Rng(stream_seed(cfg.seed, 0xC0000000ull + c));
         for (char& ch : contig) ch = BASES[rng.below(4)];
         ds.bam.tid_begin.push_back(rs.size());
         for (uint32_t gi = 0; gi < per_contig && tx_serial < cfg.n_transcripts; gi++, tx_serial++) {
             const bool reverse = (tx_serial & 1) != 0;
+            if (cfg.gene_streams) { rng = Rng(stream_seed(cfg.seed, tx_serial)); read_serial = uint64_t(tx_serial) << 24; }
             // ---- exon structure
             uint32_t n_exons = std::min<uint32_t>(30, std::max<uint32_t>(1, 1 + rng.poisson(8.0)));
             std::vector<uint64_t> elen(n_exons);
@@ -133,6 +160,16 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
             }
             if (!reverse) { stop_lo = cur; utr_lo = cur + 3; utr_hi = utr_lo + utr; cur = utr_hi; }
             const uint64_t gene_end = cur + margin;
+            if (costs_only) {
+                uint64_t cost = 0;
+                for (const auto& ex : gexons) cost += (ex.second - ex.first) + L;
+                costs_only->push_back(cost);
+            }
+            if (costs_only || (!cfg.keep.empty() && !cfg.keep[tx_serial])) {   // only the coordinates of this gene are needed
+                if (costs_only) contig.resize(gene_end + 2000);                // (sizes only; never read)
+                else contig.resize(gene_end + 2000, 'N');
+                continue;
+            }
             // ---- reference bases
             contig.resize(gene_end + 2000);
             for (uint64_t p = gene_start; p < gene_end + 2000; p++) contig[p] = BASES[rng.below(4)];
@@ -327,6 +364,7 @@ void synth_generate(const SynthConfig& cfg, Dataset& ds) {
         }
         ds.bam.ref_lens.push_back(int64_t(contig.size()));
     }
+    if (costs_only) return;
     ds.bam.tid_begin.push_back(rs.size());
     ds.vcf.contigs = ds.contig_names;
     ds.gtf = gtf.str();

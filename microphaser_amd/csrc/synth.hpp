@@ -20,6 +20,12 @@ struct SynthConfig {
     double indel_rate = 0.0, multiallelic_rate = 0.0, softmask_rate = 0.0;
     double mate_rate = 0.0;    // fraction of reads followed by a second record with the same name and start
     double isoform_rate = 0.0; // fraction of genes with a second coding transcript (a prefix of the exons)
+    // Sharded generation (multi-GPU runs: one exome, every rank materialises only its own genes). With gene_streams every gene
+    // draws from its own random stream seeded by (seed, gene ordinal), so a gene's reads / variants / reference bases do not depend
+    // on which other genes are generated; `keep` (empty = all, else one flag per transcript) selects the genes to materialise -
+    // the others only reserve their coordinates (their stretch of the contig is left 'N', no GTF / VCF / BAM records).
+    bool gene_streams = false;
+    std::vector<uint8_t> keep;
 };
 
 struct Dataset {
@@ -36,6 +42,9 @@ struct Dataset {
 };
 
 void synth_generate(const SynthConfig& cfg, Dataset& ds);
+// Work estimate per gene of the data set `cfg` describes, without generating it: sum over exons of (exon length + one read length)
+// - proportional to the gene's reads and windows at the configured depth (cost ~ CDS_nt x depth). gene_streams only.
+std::vector<uint64_t> synth_gene_costs(const SynthConfig& cfg);
 void dataset_load_genes(Dataset& ds, bool unsupported_allele_warning_only);
 const std::vector<GeneInput>& dataset_genes(Dataset& ds, bool normal);  // genes as the given mode's phase() builds them
 void dataset_load_files(const std::string& bam, const std::string& vcf, const std::string& fasta, std::istream& gtf,

@@ -1,10 +1,14 @@
-"""Gene sharding across ranks (one process per GPU) and the ordered merge of the per-rank outputs.
+"""Gene sharding across ranks (one process per GPU), the ordered merge of the per-rank outputs and the peptidome exchange.
 
-Genes are independent units of the phasing path (reference: phase_gene is called once per gene and shares no
-state across genes, src/microphasing.rs:1963-1979), so `somatic` needs no data-path collective: every rank phases
-a contiguous range of genes and the three output streams are concatenated in gene order. The only communication is
-the final gather of the (already formatted) streams, done with torch.distributed (RCCL on GPUs, gloo on CPU).
+Genes are independent units of the phasing path (reference: phase_gene is called once per gene and shares no state across
+genes, src/microphasing.rs:895-942, :1963-1979), so `somatic` / `normal` need no data-path collective: the genes of ONE exome
+are dealt to the ranks by estimated cost (longest processing time first on CDS_nt x depth), every rank phases
+its own genes, and the output streams are merged back into GTF order - the reference's output order - from the per-gene byte
+offsets the library reports (mp_results_gene_offsets). The one real exchange step of the path is the peptidome union of
+`build_reference` (config E): sorted distinct u64 keys, all-gathered as tensors (RCCL over xGMI on GPUs, gloo on CPU) and
+merged by the library (mp_peptides_union).
 """
+import heapq
 
 
 def shard_range(n_genes, rank, world):
@@ -15,8 +19,29 @@ def shard_range(n_genes, rank, world):
     return lo, hi
 
 
+def lpt_partition(costs, world):
+    """Greedy longest-processing-time-first: genes in descending cost order, each to the least loaded rank.
+    Returns `world` ascending gene lists (deterministic: ties broken by gene ordinal / rank)."""
+    heap = [(0, r) for r in range(world)]
+    heapq.heapify(heap)
+    parts = [[] for _ in range(world)]
+    for g in sorted(range(len(costs)), key=lambda g: (-costs[g], g)):
+        load, r = heapq.heappop(heap)
+        parts[r].append(g)
+        heapq.heappush(heap, (load + costs[g], r))
+    for p in parts:
+        p.sort()
+    return parts
+
+
+def shard_of(results, genes):
+    """dict describing one rank's output: its gene list, the three streams and the per-gene offsets in each of them."""
+    return dict(genes=list(genes), fasta=results.fasta, normal_fasta=results.normal_fasta, tsv=results.tsv,
+                off=[results.gene_offsets(k) for k in range(3)], windows=results.windows)
+
+
 def merge_streams(parts):
-    """parts: list of dict(fasta=bytes, normal_fasta=bytes, tsv=bytes) in rank (= gene) order.
+    """parts: list of dict(fasta=bytes, normal_fasta=bytes, tsv=bytes) in gene order (contiguous ranges).
     FASTA streams concatenate; the TSV header is written once, by the first shard that emitted a record
     (the reference's csv writer emits it with the first record only, src/common.rs:350-373)."""
     fasta = b"".join(p["fasta"] for p in parts)
@@ -30,32 +55,105 @@ def merge_streams(parts):
     return dict(fasta=fasta, normal_fasta=normal, tsv=tsv)
 
 
+def merge_by_gene(shards):
+    """shards: list of shard_of() dicts whose gene lists partition the exome. Returns the three streams in global gene order
+    (what a single-GPU run writes): gene g's bytes are cut out of its shard with the shard's per-gene offsets; the TSV header line
+    is kept once."""
+    owner = {}
+    for s in shards:
+        for k, g in enumerate(s["genes"]):
+            owner[g] = (s, k)
+    out = {"fasta": [], "normal_fasta": [], "tsv": []}
+    header = b""
+    for s in shards:
+        if s["tsv"] and not header:
+            header = s["tsv"][: s["off"][2][0]]
+    for g in sorted(owner):
+        s, k = owner[g]
+        for which, name in enumerate(("fasta", "normal_fasta", "tsv")):
+            off = s["off"][which]
+            if off:
+                out[name].append(s[name][off[k]: off[k + 1]])
+    tsv_body = b"".join(out["tsv"])
+    return dict(fasta=b"".join(out["fasta"]), normal_fasta=b"".join(out["normal_fasta"]), tsv=(header + tsv_body) if tsv_body else b"",
+                windows=sum(s.get("windows", 0) for s in shards))
+
+
+def _bytes_tensor(torch, data, device):
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if data else torch.zeros(0, dtype=torch.uint8)
+    return t.to(device)
+
+
+def gather_shards(local, dist=None, dst=0, device="cpu"):
+    """Gather every rank's shard_of() dict on `dst` (list in rank order): the byte streams and offset tables travel as uint8 /
+    int64 tensors (sizes first, then one padded all_gather per field), not as pickled Python objects."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local]
+    import torch
+    world = dist.get_world_size()
+    fields = [("fasta", "u8"), ("normal_fasta", "u8"), ("tsv", "u8"), ("genes", "i64"), ("off0", "i64"), ("off1", "i64"), ("off2", "i64")]
+    loc = {"fasta": local["fasta"], "normal_fasta": local["normal_fasta"], "tsv": local["tsv"], "genes": local["genes"],
+           "off0": local["off"][0], "off1": local["off"][1], "off2": local["off"][2]}
+    tens = {}
+    for name, kind in fields:
+        tens[name] = _bytes_tensor(torch, loc[name], device) if kind == "u8" else torch.tensor(loc[name], dtype=torch.int64, device=device)
+    sizes = torch.tensor([tens[n].numel() for n, _ in fields] + [int(local.get("windows", 0))], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    gathered = {}
+    for i, (name, kind) in enumerate(fields):
+        m = max(1, max(int(s[i].item()) for s in all_sizes))
+        pad = torch.zeros(m, dtype=tens[name].dtype, device=device)
+        pad[: tens[name].numel()] = tens[name]
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        gathered[name] = [b[: int(s[i].item())].cpu() for b, s in zip(bufs, all_sizes)]
+    if dist.get_rank() != dst:
+        return None
+    out = []
+    for r in range(world):
+        g = {n: gathered[n][r] for n, _ in fields}
+        out.append(dict(genes=g["genes"].tolist(), fasta=bytes(g["fasta"].numpy()), normal_fasta=bytes(g["normal_fasta"].numpy()),
+                        tsv=bytes(g["tsv"].numpy()), off=[g["off0"].tolist(), g["off1"].tolist(), g["off2"].tolist()],
+                        windows=int(all_sizes[r][len(fields)].item())))
+    return out
+
+
+def allgather_keys(local_keys, dist=None, device="cpu"):
+    """The exchange step of the multi-GPU build_reference: every rank contributes its sorted distinct u64 peptide keys (a numpy
+    uint64 array or a torch int64 tensor - keys are < 2^60), every rank gets the list of all ranks' arrays (numpy uint64).
+    Variable-length all-gather = exchange the counts, pad to the maximum, one all_gather (~10 MB per rank at config E: a single
+    direct all-gather over xGMI, no ring needed)."""
+    import numpy as np
+    import torch
+    if isinstance(local_keys, torch.Tensor):
+        t = local_keys.to(device=device, dtype=torch.int64)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(local_keys, dtype=np.uint64).view(np.int64)).to(device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [t.cpu().numpy().view(np.uint64)]
+    world = dist.get_world_size()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    m = max(1, max(int(c.item()) for c in counts))
+    padded = torch.zeros(m, dtype=torch.int64, device=device)
+    padded[: t.numel()] = t
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    return [b[: int(c.item())].cpu().numpy().view(np.uint64) for b, c in zip(bufs, counts)]
+
+
+def union_keys(ctx, local_keys, peptide_len, dist=None, device="cpu"):
+    """All-gather the ranks' key arrays and merge them in the library (mp_peptides_union): the peptidome of the whole exome, the
+    same on every rank (Peptides: .keys, .binary)."""
+    return ctx.peptides_union(allgather_keys(local_keys, dist, device), peptide_len)
+
+
 def gather_streams(local, dist=None, dst=0):
-    """Gather every rank's streams on `dst` (list in rank order) - the only exchange step of `somatic`."""
+    """(kept for contiguous-range shards) Gather every rank's streams on `dst` as Python objects."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [local]
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(local, out, dst=dst)
     return out
-
-
-def union_keys(local_keys, dist=None, device="cpu"):
-    """Peptidome union, the one real exchange step of the path (config E): every rank contributes its sorted
-    distinct u64 peptide keys, all ranks end up with the sorted distinct union. Variable-length all-gather = exchange the
-    counts, pad to the maximum, all_gather (RCCL over xGMI on GPUs; ~10 MB per rank, so a single direct all-gather),
-    then one merge-unique."""
-    import torch
-    t = torch.tensor(sorted(set(local_keys)), dtype=torch.int64, device=device)  # keys < 2^60: safe as int64
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return t.tolist()
-    world = dist.get_world_size()
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    m = int(max(c.item() for c in counts))
-    padded = torch.full((max(m, 1),), -1, dtype=torch.int64, device=device)
-    padded[: t.numel()] = t
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded)
-    allk = torch.cat([b[: int(c.item())] for b, c in zip(bufs, counts)])
-    return torch.unique(allk, sorted=True).tolist()

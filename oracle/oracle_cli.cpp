@@ -7,6 +7,8 @@
 #include <iostream>
 #include <set>
 #include <sstream>
+#include <thread>
+#include <algorithm>
 
 #include "../microphaser_amd/csrc/io.hpp"
 #include "../microphaser_amd/csrc/synth.hpp"
@@ -38,6 +40,7 @@ int main(int argc, char** argv) {
             uint64_t lo = 0, hi = ~0ull, wl = 27;
             std::string stats, prefix;
             bool skip_panics = false, normal_mode = false;
+            unsigned n_threads = 1;   // > 1: genes sharded over host threads (what a user of the single-threaded reference could do per chromosome)
             for (int i = 2; i < argc; i++) {
                 std::string a = argv[i];
                 auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + a); return argv[++i]; };
@@ -53,6 +56,8 @@ int main(int argc, char** argv) {
                 else if (a == "--read-len") cfg.read_len = uint32_t(std::stoul(val()));
                 else if (a == "--mate-rate") cfg.mate_rate = std::stod(val());
                 else if (a == "--isoform-rate") cfg.isoform_rate = std::stod(val());
+                else if (a == "--threads") n_threads = unsigned(std::stoul(val()));
+                else if (a == "--gene-streams") cfg.gene_streams = true;   // the sharded-generation variant of the generator (synth.hpp)
                 else if (a == "--genes") { std::string v = val(); size_t c = v.find(':'); lo = std::stoull(v.substr(0, c)); hi = std::stoull(v.substr(c + 1)); }
                 else if (a == "--stats") stats = val();
                 else if (a == "--prefix") prefix = val();
@@ -63,11 +68,47 @@ int main(int argc, char** argv) {
             synth_generate(cfg, ds);
             const std::vector<GeneInput>& genes = dataset_genes(ds, normal_mode);  // `normal` loads genes without the 3' UTR rule
             if (hi > genes.size()) hi = genes.size();
+            const uint64_t n_genes_run = hi > lo ? hi - lo : 0;
             SomaticOutput out;
             NormalOutput nout;
             auto t0 = std::chrono::steady_clock::now();
             std::string skipped;
-            for (uint64_t g = lo; g < hi; g++) {
+            if (n_threads > 1 && !skip_panics) {
+                // contiguous gene ranges balanced by read count, one per thread; streams concatenated in gene order, TSV header kept once
+                std::vector<uint64_t> cost(hi - lo + 1, 0);
+                for (uint64_t g = lo; g < hi; g++) cost[g - lo + 1] = cost[g - lo] + genes[g].reads.size() + 1;
+                std::vector<uint64_t> cut(n_threads + 1, hi);
+                cut[0] = lo;
+                for (unsigned t = 1; t < n_threads; t++)
+                    cut[t] = std::max<uint64_t>(cut[t - 1], lo + uint64_t(std::lower_bound(cost.begin(), cost.end(), cost.back() * t / n_threads) - cost.begin()));
+                for (unsigned t = 1; t <= n_threads; t++) cut[t] = std::min<uint64_t>(cut[t], hi);
+                std::vector<SomaticOutput> so(n_threads);
+                std::vector<NormalOutput> no(n_threads);
+                std::vector<std::string> errs(n_threads);
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < n_threads; t++)
+                    th.emplace_back([&, t] {
+                        try {
+                            for (uint64_t g = cut[t]; g < cut[t + 1]; g++) {
+                                if (normal_mode) mp_oracle::normal_phase_gene(genes[g], ds.bam.reads, wl, no[t]);
+                                else mp_oracle::phase_gene(genes[g], ds.bam.reads, wl, so[t]);
+                            }
+                        } catch (const std::exception& e) { errs[t] = e.what(); }
+                    });
+                for (auto& x : th) x.join();
+                for (const std::string& e : errs) if (!e.empty()) throw Error(e);
+                auto append_tsv = [](std::string& dst, const std::string& src) {
+                    if (src.empty()) return;
+                    if (dst.empty()) dst = src; else dst.append(src, src.find('\n') + 1, std::string::npos);
+                };
+                for (unsigned t = 0; t < n_threads; t++) {
+                    if (normal_mode) { nout.fasta += no[t].fasta; append_tsv(nout.tsv, no[t].tsv); nout.n_windows += no[t].n_windows; }
+                    else { out.fasta += so[t].fasta; out.normal_fasta += so[t].normal_fasta; append_tsv(out.tsv, so[t].tsv); out.n_windows += so[t].n_windows; }
+                }
+                lo = hi;   // done
+            }
+            const uint64_t lo_seq = lo;
+            for (uint64_t g = lo_seq; g < hi; g++) {
                 auto run = [&] {
                     if (normal_mode) mp_oracle::normal_phase_gene(genes[g], ds.bam.reads, wl, nout);
                     else mp_oracle::phase_gene(genes[g], ds.bam.reads, wl, out);
@@ -94,7 +135,7 @@ int main(int argc, char** argv) {
             }
             char buf[256];
             std::snprintf(buf, sizeof buf, "{\"windows\": %llu, \"phase_seconds\": %.6f, \"genes\": %llu, \"skipped\": [",
-                          (unsigned long long)out.n_windows, secs, (unsigned long long)(hi - lo));
+                          (unsigned long long)out.n_windows, secs, (unsigned long long)n_genes_run);
             std::string js = std::string(buf) + skipped + "]}\n";
             if (!stats.empty()) write_file(stats, js);
             else std::fputs(js.c_str(), stdout);

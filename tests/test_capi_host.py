@@ -61,3 +61,95 @@ def test_synthetic_dataset_roundtrips_through_files(built, tmp_path):
     for ext in ("fa", "normal.fa", "tsv"):
         assert open(str(tmp_path / "mem") + "." + ext, "rb").read() == from_files[ext]
     assert from_files["tsv"].count(b"\n") > 10
+
+
+def _arrays_equal(a, b):
+    import numpy as np
+    assert a.keys() == b.keys()
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_phase_gene_level_arrays_roundtrip_on_a_reference_fixture(built):
+    """mp_dataset_to_arrays / mp_dataset_from_arrays (the phase_gene seam, src/microphasing.rs:882-893): the decoded records of
+    a reference fixture, copied into host-owned arrays and handed back, give a data set with the same phase_gene-level inputs
+    (gene model, refseq, reads before the mapq filter, variants) - and the planner accepts it. The GPU suite runs it through the
+    kernels against the reference's expected output."""
+    import microphaser_amd as m
+    ctx = m.Context(-1)
+    p = fixture_paths("test_reverse")
+    ds = ctx.load(p["bam"], p["vcf"], p["fasta"], p["gtf"])
+    a = ds.to_arrays()
+    assert a["n_genes"] == 1 and 2000 < len(a["r_pos"]) <= ds.num_reads and len(a["v_pos"]) >= 9   # the records the gene's fetch yields
+    assert a["tx_strand"].tolist().count(1) == len(a["tx_strand"])          # the gene is on the '-' strand
+    assert set(a["v_kind"].tolist()) == {0, 1, 2}                          # SNVs, the multi-allelic insertion, the 6-nt deletion
+    ds2 = ctx.from_arrays(a)
+    assert ds2.num_genes == 1 and ds2.num_reads == len(a["r_pos"])
+    b = ds2.to_arrays()
+    a.pop("r_qname_hash"); b.pop("r_qname_hash")                           # names travel as hashes: re-hashed on the way back
+    _arrays_equal(a, b)
+    ds2.batch()                                                            # the planner takes it (no GPU: run() would fail loudly)
+
+
+def test_synthetic_exome_subset_is_the_same_exome(built):
+    """Sharded generation (multi-GPU runs): with per-gene random streams a rank that materialises only its genes holds exactly
+    those genes of the whole exome."""
+    import microphaser_amd as m
+    ctx = m.Context(-1)
+    whole = ctx.synth(77, 12, gene_streams=True)
+    keep = [1, 4, 5, 11]
+    part = ctx.synth(77, 12, keep=keep)
+    assert whole.num_genes == 12 and part.num_genes == len(keep)
+    A, B = whole.to_arrays(), part.to_arrays()
+    import numpy as np
+    for k, g in enumerate(keep):
+        assert A["gene_id"][g] == B["gene_id"][k] and A["gene_start"][g] == B["gene_start"][k] and A["gene_end"][g] == B["gene_end"][k]
+        for off, fields in (("ref_off", ["refseq"]), ("read_off", ["r_pos", "r_mapq"]), ("var_off", ["v_pos", "v_alt", "v_kind", "v_is_germline"])):
+            a0, a1, b0, b1 = int(A[off][g]), int(A[off][g + 1]), int(B[off][k]), int(B[off][k + 1])
+            for f in fields:
+                assert np.array_equal(A[f][a0:a1], B[f][b0:b1]), (g, f)
+        # read bases and qualities
+        ra0, ra1, rb0, rb1 = int(A["read_off"][g]), int(A["read_off"][g + 1]), int(B["read_off"][k]), int(B["read_off"][k + 1])
+        assert np.array_equal(A["seq"][int(A["r_seq_off"][ra0]):int(A["r_seq_off"][ra1])], B["seq"][int(B["r_seq_off"][rb0]):int(B["r_seq_off"][rb1])])
+    costs = ctx.synth_gene_costs(77, 12)
+    assert len(costs) == 12 and all(c > 0 for c in costs)
+    # the estimate tracks the real work: correlation with the generated reads per gene
+    reads = np.diff(A["read_off"]).astype(float)
+    assert np.corrcoef(reads, np.array(costs, dtype=float))[0, 1] > 0.95
+
+
+def test_lpt_partition_is_balanced_and_complete():
+    from microphaser_amd.shard import lpt_partition
+    import random
+    rng = random.Random(5)
+    costs = [rng.randint(100, 5000) for _ in range(2000)]
+    for world in (1, 2, 3, 8):
+        parts = lpt_partition(costs, world)
+        assert sorted(g for p in parts for g in p) == list(range(len(costs)))
+        assert all(p == sorted(p) for p in parts)
+        loads = [sum(costs[g] for g in p) for p in parts]
+        assert max(loads) - min(loads) <= max(costs)          # LPT bound
+        assert max(loads) <= 1.01 * sum(costs) / world
+
+
+def test_peptides_union_merges_sorted_key_arrays(built):
+    """mp_peptides_union (host-side merge of the all-gathered key arrays): no GPU needed."""
+    import numpy as np
+    import microphaser_amd as m
+    ctx = m.Context(-1)
+    a = np.array([m_ for m_ in (3, 5, 9, 1 << 44)], dtype=np.uint64)
+    b = np.array([5, 7, 9, 11, (1 << 44) + 1], dtype=np.uint64)
+    u = ctx.peptides_union([a, b, np.zeros(0, dtype=np.uint64)], 9)
+    assert u.keys == sorted({3, 5, 9, 1 << 44, 7, 11, (1 << 44) + 1})
+    assert m.decode_bincode_set(u.binary) == {m.key_to_peptide(k, 9).encode() for k in u.keys}
+    with pytest.raises(m.MicrophaserError, match="sorted and distinct"):
+        ctx.peptides_union([np.array([5, 3], dtype=np.uint64)], 9)
+
+
+def test_translate_needs_a_gpu(built):
+    import microphaser_amd as m
+    with pytest.raises(m.MicrophaserError, match="no CPU fallback"):
+        m.Context(-1).translate(b"ATGGCC", [0], 2)

@@ -1,7 +1,11 @@
-"""The N>1 path on CPU: world_size-2 gloo run of gene sharding + ordered merge (no GPU).
+"""The N>1 path on CPU: world_size-2 gloo runs (no GPU).
 
-Each rank plans its shard with the host-only context (the product's planner) and produces its shard's output streams
-with the CPU oracle standing in for the kernels; rank 0 gathers and merges them and compares with a single-process run.
+test_two_rank_gloo_shard_and_merge: ONE synthetic exome, its genes dealt to the two ranks by the product's cost-weighted partition
+(lpt_partition on mp_synth_gene_costs); every rank materialises only its genes (per-gene random streams), plans them with the
+product's planner (mp_batch_create_genes on a host-only context), and - the kernels need a GPU - takes its genes' output bytes
+from the CPU oracle, gene by gene, in the shard format the product's consumer reports (streams + per-gene offsets). The shards
+travel as tensors (gather_shards), rank 0 merges them by gene ordinal (merge_by_gene) and the result must be the single-process
+output of the whole exome. The GPU suite checks the same merge on shards the device produced.
 """
 import json
 import os
@@ -17,25 +21,40 @@ import json, os, subprocess, sys
 sys.path.insert(0, %(root)r)
 import torch.distributed as dist
 import microphaser_amd as m
-from microphaser_amd.shard import shard_range, merge_streams, gather_streams
+from microphaser_amd.shard import lpt_partition, merge_by_gene, gather_shards
 dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
 rank, world = dist.get_rank(), dist.get_world_size()
 seed, n = 41, 10
 ctx = m.Context(-1)
-ds = ctx.synth(seed, n)
-lo, hi = shard_range(ds.num_genes, rank, world)
-ds.batch(gene_lo=lo, gene_hi=hi)   # the planner accepts the shard
-prefix = os.path.join(%(tmp)r, "shard%%d" %% rank)
-r = subprocess.run([%(cli)r, "synth", "--seed", str(seed), "--transcripts", str(n), "--genes", "%%d:%%d" %% (lo, hi), "--prefix", prefix],
-                   capture_output=True, check=True)
-st = json.loads(r.stdout)
-local = dict(fasta=open(prefix + ".fa", "rb").read(), normal_fasta=open(prefix + ".normal.fa", "rb").read(),
-             tsv=open(prefix + ".tsv", "rb").read(), windows=st["windows"])
-parts = gather_streams(local, dist)
+costs = ctx.synth_gene_costs(seed, n)
+parts = lpt_partition(costs, world)
+mine = parts[rank]
+ds = ctx.synth(seed, n, keep=mine)                 # only this rank's genes of the exome
+assert ds.num_genes == len(mine)
+ds.batch_genes(range(len(mine)))                   # the product planner takes the shard
+# the shard's bytes, gene by gene, from the oracle run on the WHOLE exome (global gene ordinals)
+shard = dict(genes=mine, fasta=b"", normal_fasta=b"", tsv=b"", off=[[0], [0], [0]], windows=0)
+header = b""
+for g in mine:
+    prefix = os.path.join(%(tmp)r, "g%%d" %% g)
+    r = subprocess.run([%(cli)r, "synth", "--seed", str(seed), "--transcripts", str(n), "--gene-streams", "--genes", "%%d:%%d" %% (g, g + 1), "--prefix", prefix],
+                       capture_output=True, check=True)
+    shard["windows"] += json.loads(r.stdout)["windows"]
+    fa, nfa, tsv = (open(prefix + e, "rb").read() for e in (".fa", ".normal.fa", ".tsv"))
+    if tsv:
+        h, body = tsv.split(b"\n", 1)
+        if not shard["tsv"]:
+            shard["tsv"] = h + b"\n"
+            shard["off"][2] = [len(shard["tsv"])] * len(shard["off"][2])
+        shard["tsv"] += body
+    shard["fasta"] += fa
+    shard["normal_fasta"] += nfa
+    for k, name in enumerate(("fasta", "normal_fasta", "tsv")):
+        shard["off"][k].append(len(shard[name]))
+got = gather_shards(shard, dist)
 if rank == 0:
-    merged = merge_streams(parts)
-    open(os.path.join(%(tmp)r, "merged.json"), "w").write(json.dumps({"windows": sum(p["windows"] for p in parts),
-        "ranges": [shard_range(ds.num_genes, r_, world) for r_ in range(world)]}))
+    merged = merge_by_gene(got)
+    open(os.path.join(%(tmp)r, "merged.json"), "w").write(json.dumps({"windows": merged["windows"], "parts": parts}))
     for k, ext in (("fasta", "fa"), ("normal_fasta", "normal.fa"), ("tsv", "tsv")):
         open(os.path.join(%(tmp)r, "merged." + ext), "wb").write(merged[k])
 dist.barrier()
@@ -62,10 +81,12 @@ def test_two_rank_gloo_shard_and_merge(built, tmp_path):
         out, err = p.communicate(timeout=240)
         assert p.returncode == 0, err.decode()[-2000:]
     whole = tmp_path / "whole"
-    r = subprocess.run([ORACLE_CLI, "synth", "--seed", "41", "--transcripts", "10", "--prefix", str(whole)], capture_output=True, check=True)
+    r = subprocess.run([ORACLE_CLI, "synth", "--seed", "41", "--transcripts", "10", "--gene-streams", "--prefix", str(whole)], capture_output=True, check=True)
     st = json.loads(r.stdout)
     meta = json.loads((tmp_path / "merged.json").read_text())
     assert meta["windows"] == st["windows"]
+    assert sorted(g for p in meta["parts"] for g in p) == list(range(10)) and all(len(p) >= 3 for p in meta["parts"])
+    assert meta["parts"][0] != list(range(len(meta["parts"][0])))     # a cost-weighted deal, not a contiguous range
     for ext in ("fa", "normal.fa", "tsv"):
         assert (tmp_path / ("merged." + ext)).read_bytes() == open(str(whole) + "." + ext, "rb").read()
     assert (tmp_path / "merged.tsv").read_bytes().count(b"\n") > 50
@@ -74,19 +95,21 @@ def test_two_rank_gloo_shard_and_merge(built, tmp_path):
 UNION_WORKER = r'''
 import json, sys
 sys.path.insert(0, %(root)r)
+import numpy as np
 import torch.distributed as dist
+import microphaser_amd as m
 from microphaser_amd.shard import union_keys
 dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
 rank = dist.get_rank()
-local = [3, 5, 9, 1 << 44] if rank == 0 else [5, 7, 11, 12, (1 << 44) + 1, 9]
-u = union_keys(local, dist)
-open(%(tmp)r + "/union%%d.json" %% rank, "w").write(json.dumps(u))
+local = [3, 5, 9, 1 << 44] if rank == 0 else [5, 7, 9, 11, 12, (1 << 44) + 1]
+u = union_keys(m.Context(-1), np.array(local, dtype=np.uint64), 9, dist)    # tensors over gloo, merged by mp_peptides_union
+open(%(tmp)r + "/union%%d.json" %% rank, "w").write(json.dumps({"keys": u.keys, "n_binary": len(m.decode_bincode_set(u.binary))}))
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_peptidome_union(tmp_path):
+def test_two_rank_gloo_peptidome_union(built, tmp_path):
     port = 31500 + (os.getpid() % 2000)
     script = tmp_path / "uworker.py"
     script.write_text(UNION_WORKER % dict(root=ROOT, port=port, tmp=str(tmp_path)))
@@ -96,4 +119,5 @@ def test_two_rank_gloo_peptidome_union(tmp_path):
         assert p.returncode == 0, err.decode()[-2000:]
     want = sorted({3, 5, 9, 1 << 44, 7, 11, 12, (1 << 44) + 1})
     for r in range(2):
-        assert json.loads((tmp_path / ("union%d.json" % r)).read_text()) == want
+        got = json.loads((tmp_path / ("union%d.json" % r)).read_text())
+        assert got["keys"] == want and got["n_binary"] == len(want)

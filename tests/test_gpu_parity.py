@@ -555,3 +555,165 @@ def test_gpu_lane_per_window_and_wave_per_window_replay_agree(ctx, monkeypatch):
         assert (lanes.fasta, lanes.normal_fasta, lanes.tsv, lanes.windows) == (waves.fasta, waves.normal_fasta, waves.tsv, waves.windows)
         assert lanes.tsv.count(b"\n") > 200
     monkeypatch.delenv("MP_NO_LANE_KERNEL", raising=False)
+
+
+# ---- the phase_gene-level boundary, cost-balanced shards and the multi-rank config E driver
+@pytest.mark.parametrize("name", ["test_reverse", "splice_reverse_test", "splice_forward_test"])
+def test_gpu_decoded_records_in_reference_output_out(ctx, name):
+    """mp_dataset_from_arrays (include/microphaser_hip.h mp_gene_batch; reference seam src/microphasing.rs:882-893): a host that
+    keeps its own readers hands over decoded records - here the fixture's, copied into host-owned numpy arrays - and gets the
+    reference's expected bytes."""
+    p = fixture_paths(name)
+    arrays = ctx.load(p["bam"], p["vcf"], p["fasta"], p["gtf"]).to_arrays()
+    res = ctx.from_arrays(arrays).phase()
+    exp = read_expected(p["expected"])
+    assert (res.fasta, res.normal_fasta, res.tsv) == (exp["fa"], exp["normal.fa"], exp["tsv"])
+
+
+def test_gpu_decoded_records_normal_mode(ctx):
+    import microphaser_amd as m
+    bam, vcf, gtf, fa, exp = NORMAL_FIXTURES["splice_forward_test"]
+    d = os.path.join(GOLDEN, "splice_forward_test")
+    arrays = ctx.load(os.path.join(d, bam), os.path.join(d, vcf), os.path.join(d, fa), os.path.join(d, gtf)).to_arrays(mode=m.MODE_NORMAL)
+    res = ctx.from_arrays(arrays).phase(mode=m.MODE_NORMAL)
+    assert res.fasta == open(os.path.join(d, "expected_output", exp), "rb").read()
+
+
+def test_gpu_cost_balanced_shards_merge_into_gtf_order(ctx):
+    """One exome, genes dealt by cost (lpt_partition on mp_dataset_gene_costs) to three shards, each phased as its own batch
+    (mp_batch_create_genes) - on one GPU here - and merged by the per-gene offsets (mp_results_gene_offsets): byte-identical to
+    the single-batch run, including shards generated on their own (per-gene random streams)."""
+    from microphaser_amd.shard import lpt_partition, merge_by_gene, shard_of
+    seed, n = 61, 30
+    ds = ctx.synth(seed, n, gene_streams=True)
+    whole = ds.phase()
+    parts = lpt_partition(ds.gene_costs(), 3)
+    assert all(len(p) >= 5 for p in parts) and parts[0] != list(range(len(parts[0])))
+    shards = []
+    for p in parts:
+        b = ds.batch_genes(p)
+        b.run()
+        shards.append(shard_of(b.results(), p))
+    merged = merge_by_gene(shards)
+    assert (merged["fasta"], merged["normal_fasta"], merged["tsv"], merged["windows"]) == (whole.fasta, whole.normal_fasta, whole.tsv, whole.windows)
+    assert whole.tsv.count(b"\n") > 500
+    # the same shards from ranks that generated only their genes
+    parts2 = lpt_partition(ctx.synth_gene_costs(seed, n), 3)
+    shards2 = []
+    for p in parts2:
+        sub = ctx.synth(seed, n, keep=p)
+        b = sub.batch_genes(range(len(p)))
+        b.run()
+        shards2.append(shard_of(b.results(), p))
+    merged2 = merge_by_gene(shards2)
+    assert (merged2["fasta"], merged2["normal_fasta"], merged2["tsv"]) == (whole.fasta, whole.normal_fasta, whole.tsv)
+
+
+def test_gpu_translate_entry_matches_build_reference(ctx, tmp_path):
+    """mp_translate (to_protein, src/peptides.rs:128-146) on raw windows against build_reference's translation of the same FASTA."""
+    fa = open(os.path.join(GOLDEN, "test_build", "reference.fa"), "rb").read()
+    exp = open(os.path.join(GOLDEN, "test_build", "expected_output", "reference_peptides.fasta"), "rb").read()
+    nt, rev = b"", []
+    lines = fa.decode().split("\n")
+    for i in range(0, len(lines) - 1, 2):
+        rid, seq = lines[i][1:], lines[i + 1]
+        for k in range(0, len(seq) - 12 + 1, 3):
+            nt += seq[k:k + 12].encode()
+            rev.append(0 if rid.endswith("F") else 1)
+    aa, keys = ctx.translate(nt, rev, 4)
+    want = b"".join(l.encode() for l in exp.decode().split("\n")[1::2])
+    assert aa == want and len(keys) == len(rev)
+    import microphaser_amd as m
+    assert [m.key_to_peptide(k, 4).encode() for k in keys] == [want[i:i + 4] for i in range(0, len(want), 4)]
+
+
+TWO_RANK_E = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+import microphaser_amd as m
+from microphaser_amd.shard import lpt_partition
+from microphaser_amd.pipeline import config_e_rank
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank, world = dist.get_rank(), dist.get_world_size()
+seed, n, L = 1212, 24, 9
+ctx = m.Context(0)                                  # both ranks on the box's one GPU: a rehearsal of the 2-GPU run
+parts = lpt_partition(ctx.synth_gene_costs(seed, n, 30.0, 5.4), world)
+mine = parts[rank]
+ds = ctx.synth(seed, n, 30.0, 5.4, keep=mine)
+merged, peptidome, filtered = config_e_rank(ctx, ds, list(range(len(mine))), mine, L, dist)
+open(os.path.join(%(tmp)r, "keys%%d.json" %% rank), "w").write(json.dumps(peptidome.keys))
+if rank == 0:
+    for name, data in (("fa", merged["fasta"]), ("normal.fa", merged["normal_fasta"]), ("tsv", merged["tsv"]), ("f.fa", filtered.fasta),
+                       ("f.tsv", filtered.tsv), ("f.removed.tsv", filtered.removed_tsv)):
+        open(os.path.join(%(tmp)r, "e." + name), "wb").write(data)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gpu_two_rank_config_e_equals_the_single_rank_pipeline(ctx, tmp_path):
+    """BASELINE config E as two ranks (both on this box's GPU, gloo for the exchanges): normal shards -> per-rank build_reference ->
+    all-gather of the key tensors -> mp_peptides_union -> somatic shards -> tensor gather -> merge by gene -> filter, against the
+    same pipeline run by one process on the whole exome."""
+    import sys
+    import microphaser_amd as m
+    from conftest import ROOT
+    port = 33500 + (os.getpid() % 2000)
+    script = tmp_path / "rank.py"
+    script.write_text(TWO_RANK_E % dict(root=ROOT, port=port, tmp=str(tmp_path)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+    seed, n, L = 1212, 24, 9
+    ds = ctx.synth(seed, n, 30.0, 5.4, gene_streams=True)
+    nres = ds.phase(window_len=3 * L, mode=m.MODE_NORMAL)
+    pep = ctx.build_reference(nres.fasta, L)
+    sres = ds.phase(window_len=3 * L)
+    f = ctx.filter(sres.tsv, pep.binary, L)
+    for r in range(2):
+        assert json.loads((tmp_path / ("keys%d.json" % r)).read_text()) == pep.keys
+    got = {name: (tmp_path / ("e." + name)).read_bytes() for name in ("fa", "normal.fa", "tsv", "f.fa", "f.tsv", "f.removed.tsv")}
+    assert (got["fa"], got["normal.fa"], got["tsv"]) == (sres.fasta, sres.normal_fasta, sres.tsv)
+    assert (got["f.fa"], got["f.tsv"], got["f.removed.tsv"]) == (f.fasta, f.tsv, f.removed_tsv)
+    assert len(pep.keys) > 1000 and f.kept > 20
+
+
+def test_gpu_context_survives_a_failed_allocation(ctx, monkeypatch):
+    """ADVICE r1: an allocation failure during upload / buffer growth must leave the context usable: the failed call reports an
+    error, and the batch that was resident before runs again (re-uploaded) with identical results."""
+    import microphaser_amd as m
+    ds = ctx.synth(23, 10)
+    b = ds.batch()
+    b.run()
+    want = b.results().tsv
+    monkeypatch.setenv("MP_TEST_ALLOC_LIMIT", "4096")
+    with pytest.raises(m.MicrophaserError, match="HIP error"):
+        ds.batch(gene_lo=0, gene_hi=5)
+    monkeypatch.delenv("MP_TEST_ALLOC_LIMIT")
+    b.run()
+    assert b.results().tsv == want
+    monkeypatch.setenv("MP_TEST_SMALL_CAPS", "1")
+    b2 = ds.batch()
+    monkeypatch.setenv("MP_TEST_ALLOC_LIMIT", "60000")      # the first pass overflows the tiny result buffers; growing them fails
+    with pytest.raises(m.MicrophaserError):
+        b2.run()
+    monkeypatch.delenv("MP_TEST_ALLOC_LIMIT")
+    monkeypatch.delenv("MP_TEST_SMALL_CAPS")
+    b.run()
+    assert b.results().tsv == want
+
+
+def test_gpu_cli_reports_a_failed_write(built, tmp_path):
+    """ADVICE r1: a write error must end in exit status 1 (the reference propagates writer errors to main, src/main.rs:260-265)."""
+    p = fixture_paths("test_forward")
+    cli = os.path.join(os.path.dirname(os.path.abspath(__import__("microphaser_amd").LIB_PATH)), "microphaser")
+    with open(p["gtf"], "rb") as gtf, open("/dev/full", "wb") as full:
+        r = subprocess.run([cli, "somatic", p["bam"], "--ref", p["fasta"], "--variants", p["vcf"], "--tsv", str(tmp_path / "t.tsv"),
+                            "--normal-output", str(tmp_path / "n.fa")], stdin=gtf, stdout=full, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"cannot write" in r.stderr
+    with open(p["gtf"], "rb") as gtf:
+        r = subprocess.run([cli, "somatic", p["bam"], "--ref", p["fasta"], "--variants", p["vcf"], "--tsv", "/dev/full",
+                            "--normal-output", str(tmp_path / "n.fa")], stdin=gtf, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"cannot write /dev/full" in r.stderr
