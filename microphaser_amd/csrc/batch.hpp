@@ -68,7 +68,7 @@ struct Batch {
     };
     std::vector<SegInfo> seg_info;
     PodVec<ExonW> exons_w;
-    PodVec<WChunk> wchunks, wchunks_m;   // single-block / multi-block window-parallel work items (kernels.hpp)
+    PodVec<WChunk> wchunks, wchunks_m, wchunks_d;   // single-block / multi-block / streamed (any depth) window-parallel work items (kernels.hpp)
     uint32_t rows_per_lane_w = 1;
     PodVec<WinW> winw;                   // lane-per-window replay (plan.hpp WinW): one per entry of lane_small / lane_wide
     uint32_t n_lane_small = 0;           // winw[0 .. n_lane_small): windows with <= K2L_SMALL_COLS columns, the rest: up to K2L_MAX_COLS

@@ -215,7 +215,7 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 // window rows: the lane kernel reads a WinW + window index per window and every RowRec once; the wave-per-window kernels
                 // read the steps of their work items and their share of the read fields / admission entries
                 uint64_t wave_steps = 0;
-                for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m}) for (const WChunk& c : *list) wave_steps += c.n_steps;
+                for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m, &b.wchunks_d}) for (const WChunk& c : *list) wave_steps += c.n_steps;
                 const double wave_share = w_steps ? double(wave_steps) / double(w_steps) : 0.0;
                 // groups are shared out by window counts (the lane kernel's windows are the narrow ones: fewer groups each, so this
                 // overstates the lane kernel's bytes a little and understates the wave kernels')

@@ -108,6 +108,8 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.wchunks = up(b.wchunks);
     d_.wchunks_m = up(b.wchunks_m);
     d_.n_wchunks_m = uint32_t(b.wchunks_m.size());
+    d_.wchunks_d = up(b.wchunks_d);
+    d_.n_wchunks_d = uint32_t(b.wchunks_d.size());
     d_.rows_per_lane_w = b.rows_per_lane_w;
     d_.achunks = up(b.achunks);
     d_.n_achunks = uint32_t(b.achunks.size());
@@ -136,6 +138,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.n_wins = uint32_t(b.wins.size());
     d_.mask_words = b.mask_words;
     d_.normal = b.normal ? 1u : 0u;
+    d_.normal_large = 0;
     d_.seq_cap = b.seq_cap;
     d_.rec_stride = hap_rec_stride(b.seq_cap);
     // K1 outputs
@@ -150,10 +153,11 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
+    last_slots_ = last_recs_ = last_want_ = 0;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
-    const uint64_t waves = b.wchunks.size() + b.segs.size() + b.wchunks_m.size() * (1 + b.rows_per_lane_w);
+    const uint64_t waves = b.wchunks.size() + b.segs.size() + b.wchunks_m.size() * (1 + b.rows_per_lane_w) + b.wchunks_d.size() * 16;
     uint64_t g_need = uint64_t(d_.n_wins) * 6 + waves * 256 + 4096;
     uint64_t r_need = g_need / 3 + waves * 128 + 4096;
     if (b.normal) { g_need += waves * 1024; r_need = g_need; }   // every haplotype of every window has a record in this mode
@@ -210,11 +214,14 @@ void DeviceContext::run(RunTiming& t) {
         launch_k2_window_rows(d_, stream_);              // wave per window: the rest
         HIP_OK(hipEventRecord(ev_[2], stream_));
         // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
+        // (their grids cover an upper bound of the counts: the previous pass's counts of this batch plus a margin, else an estimate)
+        const uint64_t slot_bound = last_slots_ ? last_slots_ + last_slots_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 8 + 65536);
+        const uint64_t want_bound = last_slots_ ? last_want_ + last_want_ / 16 + 4096 : std::min<uint64_t>(rec_cap_, uint64_t(d_.n_wins) * 2 + 65536);
         launch_partition_prefix(d_, false, stream_);
-        launch_k3_window_seq(d_, group_cap_, stream_);
+        launch_k3_window_seq(d_, slot_bound, stream_);
         HIP_OK(hipEventRecord(ev_[3], stream_));
         launch_partition_prefix(d_, true, stream_);
-        launch_k3b_haplotype_ids(d_, rec_cap_, stream_);
+        launch_k3b_haplotype_ids(d_, want_bound, stream_);
         HIP_OK(hipEventRecord(ev_[4], stream_));
         std::vector<unsigned long long> cur(NPART * 32);
         uint32_t err = 0;
@@ -226,8 +233,9 @@ void DeviceContext::run(RunTiming& t) {
             rpl_ *= 2;
             continue;
         }
-        if (err & WD_EPOCH_OVERFLOW) throw Error("normal mode: more than 128 live column epochs in one transcript (variant density too high for this build)");
-        if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 512 distinct haplotypes in one window");
+        if ((err & (WD_EPOCH_OVERFLOW | WD_HAP_OVERFLOW)) && !d_.normal_large) { d_.normal_large = 1; continue; }   // the large tables, again
+        if (err & WD_EPOCH_OVERFLOW) throw Error("normal mode: more than 512 live column epochs in one transcript (variant density too high for this build)");
+        if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 2048 distinct haplotypes in one window");
         uint64_t max_g = 0, max_r = 0, max_w = 0;
         for (uint32_t p = 0; p < NPART; p++) {
             max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]); max_w = std::max<uint64_t>(max_w, cur[p * 32 + 24]);
@@ -262,6 +270,7 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         last_slots_ = slots;
         last_recs_ = rec_slots;
+        last_want_ = n_want;
         t.n_group_slots = slots;    // group slots K3 walked (incl. the unused tail of each wave's last chunk) / records K3b hashed
         t.n_recs = n_want;
         t.n_groups = slots;

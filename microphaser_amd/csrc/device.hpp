@@ -71,7 +71,7 @@ class DeviceContext {
     unsigned long long* part_prefix_ = nullptr;
     int rpl_ = 1;
     uint32_t max_rows_bound_ = 0;
-    uint64_t last_slots_ = 0, last_recs_ = 0;
+    uint64_t last_slots_ = 0, last_recs_ = 0, last_want_ = 0;
 };
 
 }  // namespace mp

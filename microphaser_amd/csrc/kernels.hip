@@ -1347,6 +1347,175 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
 
+// K2w for windows of ANY depth (exons with more than 512 candidate reads per window: amplicons, duplicate pile-ups, highly expressed
+// genes): the window's candidate reads are streamed through the lanes 64 at a time - same row derivation as above - and the haplotype
+// words of the rows that are not bad are counted in an LDS hash table (64-bit CAS, K2D_TABLE slots), so the number of ROWS is not
+// bounded by anything; the distinct words are then sorted (bitonic) and written in ascending order with their counts looked up again.
+// Limit (loud): K2D_TABLE distinct haplotypes in one window.
+constexpr uint32_t K2D_TABLE = 4096;
+template <int W>
+__global__ __launch_bounds__(64) void k2w_window_rows_deep(DeviceBatch d) {
+    __shared__ unsigned long long tkey[K2D_TABLE];   // haplotype + 1 (0 = free)
+    __shared__ uint32_t tcnt[K2D_TABLE];
+    __shared__ uint64_t skey[K2D_TABLE];             // the distinct haplotypes, sorted
+    __shared__ uint32_t ng_lds;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t part = blockIdx.x & (NPART - 1);
+    unsigned long long* const gcur = d.cursors + part * 32;
+    unsigned long long* const rcur = gcur + 16;
+    const uint64_t gpart_lo = uint64_t(part) << d.group_part_log2, gpart_size = 1ull << d.group_part_log2;
+    const uint64_t rpart_lo = uint64_t(part) << d.rec_part_log2, rpart_hi = uint64_t(part + 1) << d.rec_part_log2;
+    uint64_t rec_pos = 0, rec_end = 0;
+    uint32_t sticky_err = 0;
+    for (uint32_t k = lane; k < K2D_TABLE; k += 64) { tkey[k] = 0; tcnt[k] = 0; }
+    if (lane == 0) ng_lds = 0;
+    __syncthreads();
+    const WChunk C = d.wchunks_d[blockIdx.x];
+    const ExonW e = d.exons_w[C.exon];
+    const bool is_rev = e.strand != 0;
+    const uint32_t rbase = e.rbase, vbase = e.vbase;
+    auto slot_of_key = [](uint64_t hap) { return uint32_t((hap * 0x9E3779B97F4A7C15ull) >> 52) & (K2D_TABLE - 1); };
+    for (uint32_t s = 0; s < C.n_steps; s++) {   // work items are a few steps long: every printing window costs thousands of reads
+        const uint32_t si = C.step_first + s;
+        const Step st = d.steps[si];
+        const uint32_t ncols = d.step_ncols[si], rn16 = d.step_rn[si];
+        if (!(st.flags & SF_PRINT) || (d.lane_on && ncols <= K2L_MAX_COLS && rn16 <= K2L_MAX_ROWS)) continue;   // (wave-uniform)
+        const uint32_t sso = st.sso, col_hi = st.col_hi, win = st.win, splice_end = st.sso + st.wlen, r_lo = d.step_rlo[si];
+        uint64_t som_mask = 0;
+        uint32_t flo = 0, fhi = 0;
+        tr_to_f(e, is_rev, col_hi - ncols, col_hi, flo, fhi);
+        if (ncols) {
+            const uint64_t gv = uint64_t(vbase) + flo;
+            const uint64_t x0 = d.v_sombits[gv >> 6], x1 = d.v_sombits[(gv >> 6) + 1];
+            const uint32_t sh = uint32_t(gv & 63);
+            som_mask = (sh ? ((x0 >> sh) | (x1 << (64 - sh))) : x0) & (~0ull >> (64 - ncols));
+            if (!is_rev) som_mask = __brevll(som_mask) >> (64 - ncols);
+        }
+        const uint64_t cmask = ncols ? (~0ull >> (64 - ncols)) : 0ull;
+        uint32_t nrows = 0;
+        bool zero_here = false;
+        for (uint32_t ri0 = r_lo; ri0 < e.read_lo + e.n_reads; ri0 += 64) {
+            const uint32_t ri = ri0 + lane;
+            const bool in = ri >= e.read_lo && ri < e.read_lo + e.n_reads;
+            const uint32_t gi = rbase + (in ? ri : e.read_lo);
+            const uint32_t start = d.r_pos[gi];
+            if (rdlane(start, 0) > sso) break;   // reads are start-sorted and a row starts at or before sso (:312-315): nothing further on
+            bool row = false, act = false;
+            uint64_t hap = 0;
+            if (in && start <= sso) {
+                const AdmEntry a = d.adm[uint64_t(e.adm_off) + (ri - e.read_lo)];
+                const uint32_t end = d.r_end[gi];
+                row = a.ord <= si && (is_rev || end >= splice_end);   // inserted, and not cleaned up since (:259-278)
+                if (row) {
+                    const uint32_t rvl = d.r_varlo[gi];
+                    uint64_t sup[W], dirty[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) {
+                        sup[w] = d.r_sup[uint64_t(gi) * W + w];
+                        dirty[w] = d.r_lq[uint64_t(gi) * W + w] | (sup[w] & bit_range(e.sl_f_lo, e.sl_f_hi, rvl + 64u * w));
+                    }
+                    uint32_t slo, shi;
+                    tr_to_f(e, is_rev, a.seen_lo, col_hi, slo, shi);
+                    act = !mask_hits<W>(dirty, slo, shi, rvl);
+                    if (act && ncols) {
+                        const uint64_t sb = mask_extract<W>(sup, flo, rvl) & cmask;
+                        hap = is_rev ? sb : (__brevll(sb) >> (64 - ncols));
+                    }
+                }
+            }
+            nrows += __popcll(__ballot(row));
+            zero_here |= act && hap == 0;
+            if (act) {
+                const unsigned long long key1 = hap + 1ull;
+                uint32_t slot = slot_of_key(hap);
+                bool done = false;
+                for (uint32_t probe = 0; probe < K2D_TABLE && !done; probe++) {
+                    const unsigned long long old = atomicCAS(&tkey[slot], 0ull, key1);
+                    if (old == 0ull) atomicAdd(&ng_lds, 1u);
+                    if (old == 0ull || old == key1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                    slot = (slot + 1) & (K2D_TABLE - 1);
+                }
+                if (!done) sticky_err |= WD_HAP_OVERFLOW;
+            }
+        }
+        __syncthreads();
+        const bool has_zero = __ballot(zero_here) != 0;
+        const uint32_t n_distinct = ng_lds;
+        // the distinct words, compacted and sorted
+        uint32_t n = 0;
+        for (uint32_t k0 = 0; k0 < K2D_TABLE; k0 += 64) {
+            const unsigned long long kk = tkey[k0 + lane];
+            const uint64_t m = __ballot(kk != 0ull);
+            if (kk != 0ull) skey[n + lanes_below(m, lane)] = kk - 1ull;
+            n += __popcll(m);
+        }
+        uint32_t N = 64;
+        while (N < n) N <<= 1;
+        for (uint32_t i = n + lane; i < N; i += 64) skey[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_wave<uint64_t>(skey, N, lane);
+        const uint32_t lead = has_zero ? 0u : 1u;   // the zero-count reference group goes first (:429-431)
+        const uint32_t ng = n_distinct + lead;
+        unsigned long long gb = 0;
+        if (lane == 0) gb = atomicAdd(gcur, (unsigned long long)ng);
+        const uint64_t gbase_rel = (uint64_t(rdlane(uint32_t(gb >> 32), 0)) << 32) | rdlane(uint32_t(gb), 0);
+        const bool can_write = gbase_rel + ng <= gpart_size;
+        uint32_t werr = sticky_err;
+        if (!can_write) werr |= WD_GROUP_OVERFLOW;
+        const uint64_t gbase = gpart_lo + gbase_rel;
+        const bool need_all = (st.flags & SF_NEED_RECS) != 0;
+        for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+            const uint32_t g = g0 + lane;
+            const bool on = g < ng;
+            uint64_t key = 0;
+            uint32_t cnt = 0;
+            if (on && g >= lead) {
+                key = skey[g - lead];
+                uint32_t slot = slot_of_key(key);
+                while (tkey[slot] != key + 1ull) slot = (slot + 1) & (K2D_TABLE - 1);   // it is there
+                cnt = tcnt[slot];
+            }
+            const bool need = on && can_write && (need_all || (key & som_mask) != 0);
+            const uint64_t nm = __ballot(need);
+            const uint32_t nneed = __popcll(nm);
+            if (nneed && rec_pos + nneed > rec_end) {
+                unsigned long long base = 0;
+                const uint32_t want = max(64u, nneed);
+                if (lane == 0) base = atomicAdd(rcur, (unsigned long long)want);
+                const uint32_t blo = rdlane(uint32_t(base), 0), bhi = rdlane(uint32_t(base >> 32), 0);
+                rec_pos = rpart_lo + ((uint64_t(bhi) << 32) | blo);
+                rec_end = rec_pos + want;
+            }
+            uint32_t rec = 0xFFFFFFFFu;
+            if (need) {
+                const uint64_t r = rec_pos + lanes_below(nm, lane);
+                if (r < rpart_hi) rec = uint32_t(r);
+            }
+            if (nneed && rec_pos + nneed > rpart_hi) sticky_err |= WD_REC_OVERFLOW;
+            rec_pos += nneed;
+            if (on && can_write) {
+                Group G; G.hap = key; G.count = cnt; G.aux = 0;
+                d.groups[gbase + g] = G;
+                d.g_win[gbase + g] = win;
+                d.g_rec[gbase + g] = rec;
+            }
+        }
+        if (lane == 0) {
+            WinDyn wd;
+            wd.group_off = uint32_t(gbase);
+            wd.ngroups = ng;
+            wd.nrows = nrows;
+            wd.flags = WD_DONE | werr;
+            d.win_dyn[win] = wd;
+            ng_lds = 0;
+        }
+        __syncthreads();
+        for (uint32_t k = lane; k < K2D_TABLE; k += 64) { tkey[k] = 0; tcnt[k] = 0; }   // clean for the next window
+        __syncthreads();
+    }
+    if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
+}
+
 // ====================================================================== K2 (normal)
 // `microphaser normal` replays the same schedule on a different matrix (reference: src/normal_microphasing.rs:218-339):
 // no qualities, frames or `contains`, and push_read numbers the columns it finds OLDEST = bit 0 while extend_right
@@ -1360,13 +1529,17 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
 //     length, candidate key range),
 // and at a printing step derives, per (read, epoch), the number of live copies in closed form and the haplotype word
 // from the K1 support mask; haplotypes are counted in an LDS hash table and written in ascending key order.
-constexpr uint32_t K2N_EPOCHS = 128;       // live column epochs of one transcript (ring)
-constexpr uint32_t K2N_TABLE = 512;        // haplotype hash slots per window (LDS: 31 KB per wave -> 5 waves per CU; 1024 slots: 43 KB -> 3)
-constexpr uint32_t K2N_GROUP_CHUNK = 512;  // group slots per allocation (>= K2N_TABLE)
+// Two sizes of the per-wave tables: the small one (128 live column epochs of a transcript, 512 haplotype hash slots per window: 30 KB of
+// LDS, 5 waves per CU) serves every ordinary exome; a batch that overflows it is run again with the large one (512 epochs, 2048
+// slots: 120 KB, one wave per CU) - slower, but dense long-read data no longer fails.
 struct EpochMeta { int32_t xmin, xmax; int32_t w, range; };
 
-template <int RPL>
+template <int RPL, int K2N_EPOCHS_, int K2N_TABLE_>
 __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
+    constexpr uint32_t K2N_EPOCHS = K2N_EPOCHS_;       // live column epochs of one transcript (ring)
+    constexpr uint32_t K2N_TABLE = K2N_TABLE_;         // haplotype hash slots per window
+    constexpr uint32_t K2N_GROUP_CHUNK = K2N_TABLE_;   // group slots per allocation (>= K2N_TABLE)
+    constexpr uint32_t K2N_HASH_SHIFT = K2N_TABLE_ == 512 ? 55 : 53;   // top 9 / 11 bits of the multiplicative hash
     const uint32_t lane = threadIdx.x;
     // this wave's output allocator (kernels.hpp NPART)
     const uint32_t part = blockIdx.x & (NPART - 1);
@@ -1554,7 +1727,7 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
                     if (n[r]) {
                         nrows_l += n[r];
                         const unsigned long long key1 = hv[r] + 1ull;
-                        uint32_t slot = uint32_t((hv[r] * 0x9E3779B97F4A7C15ull) >> 54) & (K2N_TABLE - 1);
+                        uint32_t slot = uint32_t((hv[r] * 0x9E3779B97F4A7C15ull) >> K2N_HASH_SHIFT) & (K2N_TABLE - 1);
                         bool done = false;
                         for (uint32_t probe = 0; probe < K2N_TABLE && !done; probe++) {
                             const unsigned long long old = atomicCAS(&tkey[slot], 0ull, key1);
@@ -2289,14 +2462,13 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
     if (d.n_segs == 0) return;
     dim3 grid(d.n_segs), block(64);
     if (d.normal) {
+#define K2N_CASE(R) case R: if (d.normal_large) hipLaunchKernelGGL((k2n_window_replay<R, 512, 2048>), grid, block, 0, stream, d); \
+                            else hipLaunchKernelGGL((k2n_window_replay<R, 128, 512>), grid, block, 0, stream, d); break;
         switch (rows_per_lane) {
-            case 1: hipLaunchKernelGGL(k2n_window_replay<1>, grid, block, 0, stream, d); break;
-            case 2: hipLaunchKernelGGL(k2n_window_replay<2>, grid, block, 0, stream, d); break;
-            case 4: hipLaunchKernelGGL(k2n_window_replay<4>, grid, block, 0, stream, d); break;
-            case 8: hipLaunchKernelGGL(k2n_window_replay<8>, grid, block, 0, stream, d); break;
-            case 16: hipLaunchKernelGGL(k2n_window_replay<16>, grid, block, 0, stream, d); break;
+            K2N_CASE(1) K2N_CASE(2) K2N_CASE(4) K2N_CASE(8) K2N_CASE(16)
             default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
         }
+#undef K2N_CASE
         HIP_CHECK_LAUNCH();
         return;
     }
@@ -2341,21 +2513,29 @@ void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
         else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
         HIP_CHECK_LAUNCH();
     }
+    if (d.n_wchunks_d) {   // exons with more than 512 candidate reads per window: rows streamed, any depth
+        if (d.mask_words == 1) hipLaunchKernelGGL(k2w_window_rows_deep<1>, dim3(d.n_wchunks_d), dim3(64), 0, stream, d);
+        else if (d.mask_words == 2) hipLaunchKernelGGL(k2w_window_rows_deep<2>, dim3(d.n_wchunks_d), dim3(64), 0, stream, d);
+        else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+        HIP_CHECK_LAUNCH();
+    }
 }
 
 template <int STAGE>
 static void launch_k2l(const DeviceBatch& d, hipStream_t stream) {
-    // persistent-ish grids: as many waves as the LDS admits, each takes tiles of 64 windows in turn
+    // one wave per tile of 64 windows: a wave that walked several tiles would wait for its own result stores to drain before the
+    // next tile's loads return (loads and stores share the in-order vmcnt counter)
     const uint32_t n_small = d.n_lane_small, n_wide = d.n_lane_all - d.n_lane_small;
     const uint32_t lds_small = 4096 + 24 * STAGE, lds_wide = 16384 + 24 * STAGE;
+    static const bool persistent = std::getenv("MP_K2L_PERSISTENT") != nullptr;   // experiments: a fixed grid that walks the tiles
     if (n_small) {
         const uint32_t tiles = (n_small + 63) / 64, waves = min(32u, 163840u / lds_small);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_SMALL_COLS, STAGE>), dim3(min(tiles, 256u * waves)), dim3(64), 0, stream, d, 0u, n_small);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_SMALL_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream, d, 0u, n_small);
         HIP_CHECK_LAUNCH();
     }
     if (n_wide) {
         const uint32_t tiles = (n_wide + 63) / 64, waves = min(32u, 163840u / lds_wide);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(min(tiles, 256u * waves)), dim3(64), 0, stream, d, n_small, n_wide);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream, d, n_small, n_wide);
         HIP_CHECK_LAUNCH();
     }
 }
@@ -2379,9 +2559,9 @@ void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t 
 
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStream_t stream) {
     if (max_group_slots == 0) return;
-    // fixed grid (the LDS admits ~16 one-wave workgroups per CU at the smallest record size); surplus waves find nothing and leave
-    const uint32_t per_cu = d.seq_cap == 48 ? 16u : d.seq_cap == 112 ? 10u : 5u;
-    dim3 grid(uint32_t(std::min<uint64_t>((max_group_slots + K3_THREADS - 1) / K3_THREADS, 256ull * per_cu))), block(K3_THREADS);
+    // the grid covers the host's upper bound of the used slots (surplus waves find nothing and leave; were the bound too low, the
+    // waves walk the rest in turn - slower, still complete)
+    dim3 grid(uint32_t(std::min<uint64_t>((max_group_slots + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull))), block(K3_THREADS);
     if (d.normal) {
         switch (d.seq_cap) {
             case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d); break;
@@ -2403,7 +2583,7 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStr
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {
     if (max_recs == 0) return;
-    dim3 grid(uint32_t(std::min<uint64_t>((max_recs + 63) / 64, 256ull * 10))), block(64);
+    dim3 grid(uint32_t(std::min<uint64_t>((max_recs + 63) / 64, 0x7FFFFFFFull))), block(64);
     switch (d.seq_cap) {
         case 48: hipLaunchKernelGGL(k3b_haplotype_ids<48>, grid, block, 0, stream, d); break;
         case 112: hipLaunchKernelGGL(k3b_haplotype_ids<112>, grid, block, 0, stream, d); break;

@@ -35,6 +35,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const ExonW* exons_w;
     const WChunk* wchunks;          // work items of k2w_window_rows (<= 64 candidate reads per window, one mask word)
     const WChunk* wchunks_m;        // work items of k2w_window_rows_multi (deeper exons, or two mask words)
+    const WChunk* wchunks_d;        // work items of k2w_window_rows_deep (more than 512 candidate reads per window)
+    uint32_t n_wchunks_d, wchunks_d_pad_;
     const uint8_t* step_ncols;
     const uint32_t* step_rlo;
     const uint16_t* step_rn;
@@ -52,6 +54,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     uint64_t n_adm;
     uint32_t n_reads, n_tx, n_wins, mask_words;
     uint32_t normal;              // 1: `microphaser normal` semantics (src/normal_microphasing.rs)
+    uint32_t normal_large;        // k2n_window_replay with the large per-wave tables (set after the small ones overflowed)
     const uint32_t* r_varlo;      // planner: gene-relative index of the first variant with pos >= r_pos
     // K1 output
     uint32_t* r_ncov;             // number of variants (from r_varlo on) whose bits K1 evaluated

