@@ -237,7 +237,8 @@ def main():
             "kernels_hbm_frac": {k: (v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else 0.0) for k, v in kern.items()},
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),
             "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm),
-                       "windows_lane_kernel": int(st.n_windows_lane), "windows_wave_kernel": int(st.n_windows_wave)},
+                       "windows_lane_kernel": int(st.n_windows_lane), "windows_wave_kernel": int(st.n_windows_wave),
+                       "groups": int(st.n_groups), "groups_k3": int(st.n_groups_k3)},
             "hbm_resident_bytes": int(st.hbm_bytes),
             "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "pass_s": t_pass, "d2h_consume_s": None if args.no_consume else t_consume,
                            "windows_per_s": None if args.no_consume else windows / (t_plan + t_pass + t_consume),

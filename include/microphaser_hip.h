@@ -145,6 +145,7 @@ typedef struct mp_run_stats {
      * most of them) and k2w_window_rows (one WAVE per window: the rest). k2w_ms / bytes_k2w above cover the wave kernels only. */
     double k2l_ms;
     uint64_t bytes_k2l, n_windows_lane, n_windows_wave;
+    uint64_t n_groups_k3;                  /* groups k3_window_seq looked at (k2l settles a group of a simple window without a somatic column itself) */
 } mp_run_stats;
 
 /* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM

@@ -73,6 +73,7 @@ struct Batch {
     PodVec<WinW> winw;                   // lane-per-window replay (plan.hpp WinW): one per entry of lane_small / lane_wide
     uint32_t n_lane_small = 0;           // winw[0 .. n_lane_small): windows with <= K2L_SMALL_COLS columns, the rest: up to K2L_MAX_COLS
     PodVec<uint32_t> lane_win;           // window index of each winw entry
+    PodVec<uint32_t> win_trivial;        // bit per window, see kernels.hpp
     bool lane_on = false;                // K2a writes RowRecs and the lane kernel takes the eligible windows
     PodVec<WChunk> achunks;              // admission work items: (exon, first read, count <= 64)
     uint64_t n_adm = 0;                   // AdmEntry count (sum of ExonW::n_reads)

@@ -222,15 +222,20 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 const uint64_t lane_wins = b.winw.size(), wave_wins = batch->w_wins - std::min<uint64_t>(batch->w_wins, lane_wins);
                 const uint64_t groups_l = batch->w_wins ? uint64_t(double(groups_w) * double(lane_wins) / double(batch->w_wins)) : 0;
                 st->k2l_ms = t.k2l_ms; st->n_windows_lane = lane_wins; st->n_windows_wave = wave_wins;
-                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * (sizeof(Group) + 8);
+                const uint64_t settled = t.n_groups - std::min(t.n_groups, t.n_k3);   // groups whose GroupSum K2l wrote itself
+                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * (sizeof(Group) + 8) +
+                                settled * sizeof(GroupSum) + (t.n_k3 > (t.n_groups - groups_l) ? (t.n_k3 - (t.n_groups - groups_l)) * 4 : 0);
                 st->bytes_k2w = wave_steps * (sizeof(Step) + 7) + uint64_t(double(b.n_adm) * wave_share) * (read_bytes + sizeof(AdmEntry)) +
                                 wave_wins * sizeof(WinDyn) + (groups_w - groups_l) * (sizeof(Group) + 8);
                 st->bytes_k2seq = seq_steps * sizeof(Step) + (b.steps.empty() ? 0 : uint64_t(double(b.r_pos.size()) * double(seq_steps) / double(b.steps.size()))) * read_bytes +
                                   seq_wins * sizeof(WinDyn) + groups_seq * (sizeof(Group) + 8);
                 st->bytes_k2 = st->bytes_k2a + st->bytes_k2l + st->bytes_k2w + st->bytes_k2seq;
             }
-            st->bytes_k3 = t.n_groups * (sizeof(Group) + 4 + sizeof(GroupSum)) +
-                           b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols + t.n_recs * hap_rec_stride(b.seq_cap);
+            st->n_groups_k3 = t.n_k3;
+            // K3 looks at the listed groups only; their windows' static records / reference bytes / columns are shared out by the listed share
+            const double k3_share = t.n_groups ? double(t.n_k3) / double(t.n_groups) : 0.0;
+            st->bytes_k3 = t.n_k3 * (4 + sizeof(Group) + 4 + 4 + sizeof(GroupSum)) +
+                           uint64_t(k3_share * double(b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols)) + t.n_recs * hap_rec_stride(b.seq_cap);
             st->bytes_k3b = t.n_recs * (32 + b.seq_cap + 8);
             st->hbm_bytes = dev.hbm_bytes();
             st->rows_per_lane = uint32_t(t.rows_per_lane); st->mask_words = b.mask_words; st->attempts = t.attempts;

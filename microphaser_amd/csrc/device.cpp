@@ -51,7 +51,7 @@ void DeviceContext::free_outputs() {
     out_allocs_.clear();
     hbm_bytes_ -= out_bytes_;
     out_bytes_ = 0;
-    d_.groups = nullptr; d_.g_win = nullptr; d_.g_rec = nullptr; d_.gsum = nullptr; d_.recs = nullptr; d_.want_recs = nullptr;
+    d_.groups = nullptr; d_.g_win = nullptr; d_.g_rec = nullptr; d_.k3_list = nullptr; d_.gsum = nullptr; d_.recs = nullptr; d_.want_recs = nullptr;
 }
 
 void DeviceContext::free_batch() {
@@ -124,6 +124,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.lane_on = b.lane_on ? 1u : 0u;
     d_.winw = up(b.winw);
     d_.lane_win = up(b.lane_win);
+    d_.win_trivial = up(b.win_trivial);
     d_.n_lane_small = b.n_lane_small;
     d_.n_lane_all = uint32_t(b.winw.size());
     if (b.lane_on) {
@@ -153,7 +154,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
-    last_slots_ = last_recs_ = last_want_ = 0;
+    last_slots_ = last_recs_ = last_want_ = last_k3_ = 0;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
@@ -179,6 +180,7 @@ void DeviceContext::alloc_outputs() {
     d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
     d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
+    d_.k3_list = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
     d_.recs = static_cast<uint8_t*>(oalloc(rec_cap_ * d_.rec_stride));
     d_.want_recs = static_cast<uint32_t*>(oalloc(rec_cap_ * 4));
@@ -199,7 +201,6 @@ void DeviceContext::run(RunTiming& t) {
         t.rows_per_lane = rpl_;
         HIP_OK(hipMemsetAsync(d_.cursors, 0, (NPART * 32 + 16) * 8, stream_));
         HIP_OK(hipMemsetAsync(d_.err, 0, 4, stream_));
-        HIP_OK(hipMemsetAsync(d_.g_win, 0xFF, group_cap_ * 4, stream_));
         HIP_OK(hipMemsetAsync(d_.win_dyn, 0, size_t(d_.n_wins) * sizeof(WinDyn), stream_));
         HIP_OK(hipMemsetAsync(d_.tx_first_stop, 0xFF, size_t(d_.n_tx) * 4, stream_));
         HIP_OK(hipEventRecord(ev_[0], stream_));
@@ -215,7 +216,7 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(ev_[2], stream_));
         // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
         // (their grids cover an upper bound of the counts: the previous pass's counts of this batch plus a margin, else an estimate)
-        const uint64_t slot_bound = last_slots_ ? last_slots_ + last_slots_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 8 + 65536);
+        const uint64_t slot_bound = last_slots_ ? last_k3_ + last_k3_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 8 + 65536);
         const uint64_t want_bound = last_slots_ ? last_want_ + last_want_ / 16 + 4096 : std::min<uint64_t>(rec_cap_, uint64_t(d_.n_wins) * 2 + 65536);
         launch_partition_prefix(d_, false, stream_);
         launch_k3_window_seq(d_, slot_bound, stream_);
@@ -251,13 +252,14 @@ void DeviceContext::run(RunTiming& t) {
             continue;
         }
         if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
-        uint64_t slots = 0, rec_slots = 0, n_want = 0;
+        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3 = 0;
         for (uint32_t p = 0; p < NPART; p++) {
             used_g_[p] = cur[p * 32];
             used_r_[p] = cur[p * 32 + 16];
             slots += used_g_[p];
             rec_slots += used_r_[p];
             n_want += cur[p * 32 + 24];
+            n_k3 += cur[p * 32 + 8];
         }
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
@@ -271,9 +273,11 @@ void DeviceContext::run(RunTiming& t) {
         last_slots_ = slots;
         last_recs_ = rec_slots;
         last_want_ = n_want;
+        last_k3_ = n_k3;
         t.n_group_slots = slots;    // group slots K3 walked (incl. the unused tail of each wave's last chunk) / records K3b hashed
         t.n_recs = n_want;
         t.n_groups = slots;
+        t.n_k3 = n_k3;
         return;
     }
     throw Error("device result buffers kept overflowing");

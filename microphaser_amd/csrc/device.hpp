@@ -32,7 +32,7 @@ struct HostResults {         // device results copied back for the consumer
 struct RunTiming {
     float k1_ms = 0, k2_ms = 0, k3_ms = 0, k3b_ms = 0, total_ms = 0;
     float k2seq_ms = 0, k2a_ms = 0, k2l_ms = 0, k2w_ms = 0;   // the launches inside k2_ms: sequential replay, admission, lane-per-window, wave-per-window
-    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0;
+    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0, n_k3 = 0;   // n_k3: groups K3 looked at (the rest were settled by K2l)
     int rows_per_lane = 1;
     uint32_t attempts = 0;
 };
@@ -71,7 +71,7 @@ class DeviceContext {
     unsigned long long* part_prefix_ = nullptr;
     int rpl_ = 1;
     uint32_t max_rows_bound_ = 0;
-    uint64_t last_slots_ = 0, last_recs_ = 0, last_want_ = 0;
+    uint64_t last_slots_ = 0, last_recs_ = 0, last_want_ = 0, last_k3_ = 0;
 };
 
 }  // namespace mp

@@ -148,6 +148,21 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t lane) { 
 
 constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: one emit call)
 
+// K2 -> K3: the group slots K3 has to look at are appended to a dense list per output allocator (list p lives at
+// k3_list[p << group_part_log2 ...], its length in cursors[p * 32 + 8]); one wave-aggregated atomic per call. The lane-per-window
+// kernel settles most groups itself (no somatic column set, simple window without a possible stop: GroupSum = {GS_VALID}) and lists
+// only the rest, so K3 runs over ~1/5 of the groups instead of all of them and no longer scans (or needs cleared) unused slots.
+__device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, bool on, uint64_t slot) {
+    const uint64_t m = __ballot(on);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t leader = uint32_t(__builtin_ctzll(m));
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(d.cursors + part * 32 + 8, (unsigned long long)__popcll(m));
+    const uint64_t b0 = (uint64_t(rdlane(uint32_t(base >> 32), leader)) << 32) | rdlane(uint32_t(base), leader);
+    if (on) d.k3_list[(uint64_t(part) << d.group_part_log2) + b0 + lanes_below(m, lane)] = uint32_t(slot);   // (a list is as long as its slots at most)
+}
+
 template <int RPL>
 __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
     constexpr uint32_t GROUP_CHUNK = RPL <= 4 ? 256u : 64u * RPL;  // group slots per allocation (>= rows of one window)
@@ -489,6 +504,7 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                         d.g_win[gi] = win;
                         d.g_rec[gi] = rec;
                     }
+                    k3_enqueue(d, part, on && can_write, gi);
                 };
                 if constexpr (RPL == 1) {
                     // <= 64 rows: (1) leader loop - pick any remaining row, ballot the rows with the same key (its count),
@@ -757,6 +773,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         const uint32_t r_n = pack & 0x3FF, ncols = (pack >> 10) & 0x3F;
         const bool fwd = (pack & WW_FWD) != 0, need_all = (pack & WW_NEED_ALL) != 0;
+        const bool trivial = (pack & WW_TRIVIAL) != 0;   // simple window that cannot hold a stop: a group without a somatic column needs no K3
         // ---- rows of the window, haplotypes counted as they come (branch-free body: every lane adds 0 or 1 to one counter)
         const uint32_t cmask32 = ncols ? (0xFFFFFFFFu >> (32 - ncols)) : 0u;   // ncols <= 8: the low dword of the shifted mask is enough
         const uint32_t rev_sh = (32u - ncols) & 31u;
@@ -845,13 +862,23 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         const uint32_t total = rdlane(scan, 63);
         const uint32_t tot_g = total & 0xFFFF, tot_r = total >> 16;
-        unsigned long long gb = 0, rb = 0;
+        const uint32_t n3 = trivial ? nneed : ng;        // groups of this window that K3 has to look at
+        uint32_t scan3 = n3;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(scan3, off);
+            if (lane >= off) scan3 += up;
+        }
+        const uint32_t tot_3 = rdlane(scan3, 63);
+        unsigned long long gb = 0, rb = 0, lb = 0;
         if (lane == 0) {
             gb = atomicAdd(gcur, (unsigned long long)tot_g);
             if (tot_r) rb = atomicAdd(rcur, (unsigned long long)tot_r);
+            if (tot_3) lb = atomicAdd(gcur + 8, (unsigned long long)tot_3);
         }
         const uint64_t gbase = (uint64_t(rdlane(uint32_t(gb >> 32), 0)) << 32) | rdlane(uint32_t(gb), 0);
         const uint64_t rbase = (uint64_t(rdlane(uint32_t(rb >> 32), 0)) << 32) | rdlane(uint32_t(rb), 0);
+        uint64_t lslot = gpart_lo + ((uint64_t(rdlane(uint32_t(lb >> 32), 0)) << 32) | rdlane(uint32_t(lb), 0)) + (scan3 - n3);
         const bool can_write = gbase + tot_g <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
@@ -878,6 +905,12 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                             d.groups[gslot] = G;
                             d.g_win[gslot] = win;
                             d.g_rec[gslot] = (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu;
+                            if (trivial && !need) {   // what K3 would find: valid, no stop, mutant == germline, no record
+                                GroupSum gs; gs.flags = GS_VALID; gs.rec = 0;
+                                d.gsum[gslot] = gs;
+                            } else {
+                                d.k3_list[lslot++] = uint32_t(gslot);
+                            }
                         }
                         gslot++;
                         rslot += need ? 1u : 0u;
@@ -1096,6 +1129,9 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
                     d.g_win[gbase + rank] = win;
                     d.g_rec[gbase + rank] = rec;
                 }
+                // (settling the trivial groups here as K2l does - one more dependent load per window for the window's flag - cost this
+                //  kernel more than it saved K3: measured 0.53 -> 0.59 ms against no change in K3)
+                k3_enqueue(d, part, on && can_write, gbase + rank);
             }
             if (lane == 0) {
                 WinDyn wd;
@@ -1284,6 +1320,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
                     d.g_win[gi] = win;
                     d.g_rec[gi] = rec;
                 }
+                k3_enqueue(d, part, on && can_write, gi);
             };
             // ---- count phase of print_haplotypes (:383-411): the haplotype words of the rows that are not bad are compacted into
             // LDS, sorted (bitonic, one wave, 32-bit keys when the window has at most 32 columns) and run-length counted - ascending
@@ -1499,6 +1536,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows_deep(DeviceBatch d) {
                 d.g_win[gbase + g] = win;
                 d.g_rec[gbase + g] = rec;
             }
+            k3_enqueue(d, part, on && can_write, gbase + g);
         }
         if (lane == 0) {
             WinDyn wd;
@@ -1798,6 +1836,7 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
                         const uint64_t rec = rec_pos + rank;
                         d.g_rec[gbase + rank] = rec < rpart_hi ? uint32_t(rec) : 0xFFFFFFFFu;
                     }
+                    k3_enqueue(d, part, g < ng, gbase + g);   // (the slots [gbase, gbase + ng) in any order)
                 }
                 rec_pos += ng;
                 chunk_pos += ng;
@@ -1969,8 +2008,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     // the number of used group slots is only known on the device (k_partition_prefix after K2): a fixed grid walks them in turn
     const uint64_t n_slots = d.part_prefix[NPART];
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
-    const uint64_t li = tile * K3_THREADS + tid;   // index into the dense list of live group slots
-    const uint64_t g = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
+    const uint64_t li = tile * K3_THREADS + tid;   // index into the K2 kernels' lists of group slots (k3_enqueue)
+    const uint64_t lpos = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // (wave-level: every lane takes part)
+    const uint64_t g = li < n_slots ? d.k3_list[lpos] : 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
@@ -2334,7 +2374,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     const uint64_t n_slots = d.part_prefix[NPART];
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
         const uint64_t li = tile * K3_THREADS + threadIdx.x;
-        const uint64_t g = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // li counts the used slots of all allocators
+        const uint64_t lpos = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // (wave-level: every lane takes part)
+    const uint64_t g = li < n_slots ? d.k3_list[lpos] : 0;   // the K2 kernels' lists of group slots
         uint32_t recidx;
         const uint32_t sumflags = k3n_one<SEQ_CAP>(d, lds_slots, g, li < n_slots, recidx);
         append_wanted(d, (sumflags & GS_ID_VALID) != 0, recidx);   // wave-level: every lane takes part
@@ -2424,7 +2465,7 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d) {
 
 // The output allocators' cursors (kernels.hpp NPART) -> exclusive prefix sums, on the device: K3 / K3b walk the used slots of
 // all allocators as one dense index space without the host having to read the cursors in the middle of a pass.
-// which = 0: group slots used after K2 -> part_prefix; which = 24: lengths of K3's wanted lists -> want_prefix.
+// which = 8: lengths of the K2 kernels' lists of group slots for K3 -> part_prefix; which = 24: lengths of K3's wanted lists -> want_prefix.
 __global__ __launch_bounds__(64) void k_partition_prefix(DeviceBatch d, uint32_t which, unsigned long long* out, uint64_t part_size) {
     const uint32_t lane = threadIdx.x;
     const unsigned long long used = min((unsigned long long)d.cursors[lane * 32 + which], (unsigned long long)part_size);   // an overflowing allocator: flagged elsewhere
@@ -2553,7 +2594,7 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream) {
 static_assert(NPART == 64, "k_partition_prefix is one wave");
 void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t stream) {
     if (want_lists) hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 24u, const_cast<unsigned long long*>(d.want_prefix), uint64_t(1) << d.rec_part_log2);
-    else hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 0u, const_cast<unsigned long long*>(d.part_prefix), uint64_t(1) << d.group_part_log2);
+    else hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 8u, const_cast<unsigned long long*>(d.part_prefix), uint64_t(1) << d.group_part_log2);
     HIP_CHECK_LAUNCH();
 }
 

@@ -47,6 +47,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     uint64_t* rr_sup;
     const WinW* winw;
     const uint32_t* lane_win;
+    const uint32_t* win_trivial;    // bit per window: WSF_SIMPLE && WSF_NOSTOP and no record demand of its own (plan.hpp WW_TRIVIAL)
     uint32_t n_lane_small, n_lane_all, lane_on, lane_pad_;
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
     uint32_t n_exons_w, n_wchunks, n_wchunks_m, n_achunks;
@@ -64,14 +65,15 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     Group* groups;
     uint32_t* g_win;              // window of each group slot (0xFFFFFFFF = unused slot)
     uint32_t* g_rec;              // HapRec slot reserved for the group by K2 (0xFFFFFFFF = none)
+    uint32_t* k3_list;            // K2 -> K3: NPART dense lists of the group slots K3 has to look at (kernels.hip k3_enqueue)
     uint32_t* want_recs;          // K3: NPART dense lists of the records that need a SHA-1 id (K3b runs over them)
     const unsigned long long* want_prefix;   // after K3: [p] = number of entries in the lists < p (NPART + 1 entries)
     // Output slots are handed out by NPART independent allocators (a wave uses allocator blockIdx & (NPART - 1)), each with
     // its own cursors in their own 128-byte lines and its own power-of-two sub-range of the output arrays: slot =
     // (partition << log2 size) + offset. One shared cursor serialises in L2 at ~60 atomics/us - with one wave per run of
     // windows that alone would bound the replay.
-    unsigned long long* cursors;  // [p * 32] group-slot cursor of partition p, [p * 32 + 16] record-slot cursor, [p * 32 + 24] length of K3's wanted list p
-    const unsigned long long* part_prefix;   // after K2: [p] = number of group slots used by partitions < p (NPART + 1 entries)
+    unsigned long long* cursors;  // [p * 32] group-slot cursor of partition p, [p * 32 + 8] length of its K3 list, [p * 32 + 16] record-slot cursor, [p * 32 + 24] length of K3's wanted list p
+    const unsigned long long* part_prefix;   // after K2: [p] = number of K3-list entries of partitions < p (NPART + 1 entries)
     uint32_t group_part_log2, rec_part_log2;
     uint64_t group_cap, rec_cap;  // NPART << log2
     uint32_t* err;                // sticky error word (WD_* bits)

@@ -431,6 +431,12 @@ static void route_lane_windows(Batch& b) {
     b.winw.clear();
     b.lane_win.clear();
     b.n_lane_small = 0;
+    b.win_trivial.assign(b.wins.size() / 32 + 2, 0u);
+    for (size_t w = 0; w < b.wins.size(); w++) {
+        const WinStatic& ws = b.wins[w];
+        if (!b.normal && (ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP) && !(ws.need_recs & WS_MASK) && !(b.steps[ws.step].flags & SF_NEED_RECS))
+            b.win_trivial[w >> 5] |= 1u << (w & 31);
+    }
     if (!b.lane_on) return;
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>(host_threads(), b.exons_w.size() / 64 + 1));
     struct Part { PodVec<WinW> w[2]; PodVec<uint32_t> id[2]; };
@@ -448,7 +454,8 @@ static void route_lane_windows(Batch& b) {
                 const uint32_t nc = b.step_ncols[si], rn = b.step_rn[si];
                 WinW w{};
                 w.rr_lo = rn ? e.adm_off + (b.step_rlo[si] - e.read_lo) : 0;
-                w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u);
+                const bool trivial = (b.win_trivial[st.win >> 5] >> (st.win & 31)) & 1u;
+                w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u) | (trivial ? WW_TRIVIAL : 0u);
                 w.wkey = rev ? ~st.sso : st.sso + uint32_t(st.wlen);
                 w.step = si;
                 w.col_hi = st.col_hi;

@@ -91,7 +91,8 @@ struct WinW {
     uint32_t som_lo, som_hi;   // somatic columns of the window in haplotype bit order
 };
 static_assert(sizeof(WinW) == 32, "WinW layout");
-enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17 };
+enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17,
+                  WW_TRIVIAL = 1u << 18 };   // WSF_SIMPLE && WSF_NOSTOP and no record demand of its own: a group without a somatic column is settled by K2l
 struct RowRecA {         // K2a output per (ExonW, read), first half (the second is the 64-bit support mask)
     uint32_t key;        // '+': end_pos, '-': ~start
     uint32_t ord;        // AdmEntry::ord
