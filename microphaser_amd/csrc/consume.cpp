@@ -171,15 +171,16 @@ struct ConsumerHooks {
         if (frame_in == 0) out.n_windows++;
         const std::vector<Variant>& gvars = gh.input->variants;
         const uint32_t ncols = ws.ncols;
-        // window variants in ascending position (print_haplotypes order, :373-379)
-        std::vector<const Variant*> variants(ncols);
-        for (uint32_t j = 0; j < ncols; j++) {
+        // window variants in ascending position (print_haplotypes order, :373-379); at most 63 columns (the planner enforces it)
+        const Variant* variants[64];
+        for (uint32_t j = 0; j < ncols && j < 64; j++) {
             uint32_t dq = is_fwd ? j : ncols - 1 - j;
             variants[j] = &gvars[b.win_cols[ws.col_off + dq].f];
         }
         // haplotype keys of this call (:383-411) from the device groups (ascending (hap, frame0, f1nz))
         struct Key { uint64_t hap, hframe; size_t count; uint64_t slot; };
-        std::vector<Key> keys;
+        static thread_local std::vector<Key> keys;   // scratch: one allocation per consumer thread, not per window
+        keys.clear();
         size_t frame_depth = 0;
         uint64_t frame = frame_in;
         uint64_t zero_slot = ~0ull;
@@ -208,12 +209,14 @@ struct ConsumerHooks {
             std::fclose(tf);
         }
         const char* strand = is_fwd ? "Forward" : "Reverse";
-        const std::string strand_s(strand);
+        static const std::string kForward("Forward"), kReverse("Reverse");
+        const std::string& strand_s = is_fwd ? kForward : kReverse;
         const bool has_frameshift = frame > 0;
         const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
         const uint64_t wl = eg.ewl;  // print_haplotypes' window_len parameter (:1421)
         const bool boundary = (ws.need_recs & WS_CARRY) != 0;  // haplotypes feed a splice-side merge
         std::vector<HapSeq> haplotypes_vec;
+        haplotypes_vec.reserve(keys.size());
         uint64_t shift_in_window = 0;
         for (const Key& key : keys) {
             const GroupSum& gs = res.gsm(key.slot);
@@ -343,10 +346,13 @@ struct ConsumerHooks {
                     write_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, roffset, frame, frame_frequency, wd.nrows, n_variants,
                                      n_somatic, n_sites, n_som_sites, strand_s, sites, som_pos, som_pc, germ_pos, germ_pc, normal_peptide, neopeptide);
                 }
-                {   // the record is kept for every window that is marked as feeding a merge OR emitted: with window lengths that are not a
-                    // multiple of 3 and indels a merge can reach a window the planner's marks miss (fuzz seeds 970028, 970791)
+                // The record is kept for every window that is marked as feeding a merge; an emitted window keeps it too where a merge can
+                // reach a window the planner's marks miss: window lengths that are not a multiple of 3, or an indel / frameshift context
+                // (keep_all; fuzz seeds 970028, 970791). An SNV-only window of a 3n-nt run that is emitted but not marked is never read
+                // again - and were it, the merge fails loudly on the missing record (splice_merge) instead of using a wrong one.
+                if (boundary || keep_all || window_len % 3 != 0) {
                     hs.filled = true;
-                    IDRecord& r = hs.record;
+                    IDRecord& r = hs.make().record;
                     r.id = std::move(idstr);
                     r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
                     r.offset = roffset;
@@ -392,16 +398,16 @@ struct ConsumerHooks {
         if (const char* tr = trace_path()) {
             FILE* tf = std::fopen(tr, "a");
             std::fprintf(tf, "M %s %llu\n", transcript.id.c_str(), (unsigned long long)offset);
-            for (const auto& h : first_hap_vec) std::fprintf(tf, "  F %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
-            for (const auto& h : sec_hap_vec) std::fprintf(tf, "  S %.17g %s %s\n", h.record.freq, h.record.mutant_sequence.c_str(), h.record.normal_sequence.c_str());
+            for (const auto& h : first_hap_vec) std::fprintf(tf, "  F %.17g %s %s\n", h.get().record.freq, h.get().record.mutant_sequence.c_str(), h.get().record.normal_sequence.c_str());
+            for (const auto& h : sec_hap_vec) std::fprintf(tf, "  S %.17g %s %s\n", h.get().record.freq, h.get().record.mutant_sequence.c_str(), h.get().record.normal_sequence.c_str());
             std::fclose(tf);
         }
         for (const HapSeq& hapseq : first_hap_vec) {
-            const IDRecord& record = hapseq.record;
+            const IDRecord& record = hapseq.get().record;
             const std::string& wt = record.normal_sequence;
             const std::string& mt = record.mutant_sequence;
             for (const HapSeq& prev_hapseq : sec_hap_vec) {
-                const IDRecord& prev = prev_hapseq.record;
+                const IDRecord& prev = prev_hapseq.get().record;
                 const std::string& pwt = prev.normal_sequence;
                 const std::string& pmt = prev.mutant_sequence;
                 std::string new_wt = pwt + wt;
@@ -416,14 +422,14 @@ struct ConsumerHooks {
                 if (eg.is_short && !eg.is_last) {
                     HapSeq nh;
                     nh.filled = true;
-                    nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_wt, window_len, false);   // carried, never written
+                    nh.make().record = record_update(prev, record, 0, record.frame, merged, new_wt, new_wt, window_len, false);   // carried, never written
                     new_hap_vec.push_back(std::move(nh));
                 }
                 for (const std::string& new_mt : new_mts) {
                     if (eg.is_short && !eg.is_last) {
                         HapSeq nh;
                         nh.filled = true;
-                        nh.record = record_update(prev, record, 0, record.frame, merged, new_wt, new_mt, window_len, false);
+                        nh.make().record = record_update(prev, record, 0, record.frame, merged, new_wt, new_mt, window_len, false);
                         new_hap_vec.push_back(std::move(nh));
                         continue;
                     }
@@ -593,7 +599,8 @@ struct NormalConsumerHooks {
         std::vector<const Variant*> variants(ncols);
         for (uint32_t j = 0; j < ncols; j++) variants[j] = &gvars[b.win_cols[ws.col_off + (is_fwd ? j : ncols - 1 - j)].f];
         const char* strand = is_fwd ? "Forward" : "Reverse";
-        const std::string strand_s(strand);
+        static const std::string kForward("Forward"), kReverse("Reverse");
+        const std::string& strand_s = is_fwd ? kForward : kReverse;
         const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
         const uint64_t wl = eg.ewl;
         const bool boundary = (ws.need_recs & WS_CARRY) != 0;
@@ -667,7 +674,7 @@ struct NormalConsumerHooks {
                 }
                 {   // the record is kept for every window of a regular exon: `normal` merges reach further back than the planner's marks
                     hs.filled = true;
-                    NormalRecord& r = hs.nrecord;
+                    NormalRecord& r = hs.make().nrecord;
                     r.id = std::move(idstr);
                     r.somatic_positions = std::move(somatic_positions); r.somatic_aa_change = std::move(somatic_aa_change);
                     r.germline_positions = std::move(germline_positions); r.germline_aa_change = std::move(germline_aa_change);
@@ -676,7 +683,7 @@ struct NormalConsumerHooks {
                     r.offset = offset; r.frame = frame; r.freq = freq; r.depth = nrows;
                     r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
                     r.strand = strand_s;
-                    hs.sequence.assign(rseq, rseq + seq_len);
+                    hs.make().sequence.assign(rseq, rseq + seq_len);
                     r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);  // carried record: unsliced (:618-625)
                 }
             }
@@ -698,14 +705,14 @@ struct NormalConsumerHooks {
         std::vector<HapSeq> new_hap_vec;
         for (const HapSeq& hapseq : first_hap_vec) {
             for (const HapSeq& prev_hapseq : sec_hap_vec) {
-                Bytes prev_sequence = prev_hapseq.sequence;
-                const NormalRecord& prev_record = prev_hapseq.nrecord;
-                prev_sequence.insert(prev_sequence.end(), hapseq.sequence.begin(), hapseq.sequence.end());
+                Bytes prev_sequence = prev_hapseq.get().sequence;
+                const NormalRecord& prev_record = prev_hapseq.get().nrecord;
+                prev_sequence.insert(prev_sequence.end(), hapseq.get().sequence.begin(), hapseq.get().sequence.end());
                 if (eg.is_short) {
                     HapSeq nh;
-                    nh.sequence = prev_sequence;
+                    nh.make().sequence = prev_sequence;
                     nh.filled = true;
-                    nh.nrecord = nrecord_update(prev_record, hapseq.nrecord, 0, prev_sequence, false);   // carried, never written
+                    nh.make().nrecord = nrecord_update(prev_record, hapseq.get().nrecord, 0, prev_sequence, false);   // carried, never written
                     new_hap_vec.push_back(std::move(nh));
                 }
                 uint64_t splice_offset = 3;
@@ -719,7 +726,7 @@ struct NormalConsumerHooks {
                     if (end_offset > prev_sequence.size()) throw Error("reference would panic: attempt to subtract with overflow (merge)");
                     if (!(splice_offset + window_len <= uint64_t(prev_sequence.size() - end_offset))) break;
                     Bytes out_seq(prev_sequence.begin() + long(splice_offset), prev_sequence.begin() + long(splice_offset + window_len));
-                    NormalRecord out_record = nrecord_update(prev_record, hapseq.nrecord, splice_offset, out_seq, false);
+                    NormalRecord out_record = nrecord_update(prev_record, hapseq.get().nrecord, splice_offset, out_seq, false);
                     auto key = std::make_pair(splice_offset, out_seq);
                     auto fit = output_map.find(key);
                     const double old_freq = fit == output_map.end() ? 0.0 : fit->second.freq;
@@ -743,8 +750,14 @@ struct NormalConsumerHooks {
     }
 };
 
-void reserve_streams(SomaticOutput& p, size_t recs) { p.tsv.reserve(recs * 340); p.fasta.reserve(recs * 52); p.normal_fasta.reserve(recs * 52); }
-void reserve_streams(NormalOutput& p, size_t recs) { p.tsv.reserve(recs * 320); p.fasta.reserve(recs * 56); }
+void reserve_streams(SomaticOutput& p, size_t recs) {
+    p.tsv.reserve(recs * 340); p.fasta.reserve(recs * 52); p.normal_fasta.reserve(recs * 52);
+    advise_huge(p.tsv.data(), p.tsv.capacity());
+}
+void reserve_streams(NormalOutput& p, size_t recs) {
+    p.tsv.reserve(recs * 320); p.fasta.reserve(recs * 56);
+    advise_huge(p.tsv.data(), p.tsv.capacity()); advise_huge(p.fasta.data(), p.fasta.capacity());
+}
 const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
 const std::string* normal_stream(const NormalOutput&) { return nullptr; }
 
@@ -779,6 +792,7 @@ void assemble(std::vector<Out>& parts, PhasedStreams& out, size_t nthreads) {
         for (const auto& pc : pieces) total += pc.second;
         dst.n = total;
         dst.p.reset(total ? new char[total] : nullptr);
+        if (total) advise_huge(dst.p.get(), total);
         size_t at = 0;
         for (const auto& pc : pieces) {
             for (size_t o = 0; o < pc.second; o += CHUNK) tasks.push_back({dst.p.get() + at + o, pc.first + o, std::min(CHUNK, pc.second - o)});

@@ -293,6 +293,10 @@ void DeviceContext::download(HostResults& r) {
     r.seq_cap = d_.seq_cap;
     r.rec_stride = d_.rec_stride;
     r.recs.resize(last_recs_ * d_.rec_stride);
+    advise_huge(r.groups.data(), r.groups.size() * sizeof(Group));
+    advise_huge(r.gsum.data(), r.gsum.size() * sizeof(GroupSum));
+    advise_huge(r.recs.data(), r.recs.size());
+    advise_huge(r.win_dyn.data(), r.win_dyn.size() * sizeof(WinDyn));
     r.group_part_log2 = glog_;
     r.rec_part_log2 = rlog_;
     if (d_.n_wins) HIP_OK(hipMemcpyAsync(r.win_dyn.data(), d_.win_dyn, size_t(d_.n_wins) * sizeof(WinDyn), hipMemcpyDeviceToHost, stream_));

@@ -82,6 +82,11 @@ template <class T> struct DefaultInitAlloc : std::allocator<T> {
 };
 template <class T> using PodVec = std::vector<T, DefaultInitAlloc<T>>;
 
+// Large, freshly allocated host buffers (the merged batch arrays, the device results, the output streams - gigabytes at whole-exome
+// size) are first touched by many threads at once: ask for transparent huge pages so that this costs thousands of page faults, not
+// millions. A hint only; no effect where the kernel does not offer it.
+void advise_huge(const void* p, size_t bytes);
+
 struct ReadStore {
     PodVec<int32_t> tid;
     PodVec<int64_t> pos;

@@ -94,9 +94,10 @@ struct PlannerHooksT {
     }
 
     // gene-relative index of the first kept read with pos >= key
+    HintedLower read_hint;   // (the queries of consecutive steps are one nt apart)
     uint32_t read_lower(uint64_t key) const {
         const uint32_t* p = b.r_pos.data() + gh.read_off;
-        return uint32_t(std::lower_bound(p, p + gh.n_reads, key, [](uint32_t a, uint64_t k) { return uint64_t(a) < k; }) - p);
+        return uint32_t(read_hint.lower(key, gh.n_reads, [p](size_t i) { return uint64_t(p[i]); }));
     }
 
     void ensure_window(const ExonGeom& eg, const StepGeom& sg) {
@@ -778,6 +779,7 @@ struct MergeTasks {
         dst.clear();
         dst.reserve(at.back() + 1);   // +1: the offset arrays get their end sentinel appended afterwards
         dst.resize(at.back());
+        advise_huge(dst.data(), dst.size() * sizeof(typename V::value_type));
         for (size_t t = 0; t < parts.size(); t++) {
             const size_t n = at[t + 1] - at[t], o = at[t];
             run.push_back([&dst, &parts, m, fix, t, n, o] {
@@ -794,6 +796,7 @@ struct MergeTasks {
         for (size_t t = 0; t < parts.size(); t++) at[t + 1] = at[t] + (parts[t].*m).size();
         dst.clear();
         dst.resize(at.back());
+        advise_huge(dst.data(), dst.size() * sizeof(T));
         for (size_t t = 0; t < parts.size(); t++) {
             const size_t o = at[t];
             run.push_back([&dst, &parts, m, t, o] {

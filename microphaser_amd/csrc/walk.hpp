@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "model.hpp"
@@ -24,13 +25,20 @@ namespace mp {
 using FsFreq = std::map<uint64_t, std::pair<double, bool>>;  // frameshift_frequencies
 
 struct HapSeq {  // reference: HaplotypeSeq (microphasing.rs:141-145); record carries the unsliced sequences
-    IDRecord record;
-    // `normal` mode (normal_microphasing.rs:182-186): the sequence bytes + its own record type
-    std::vector<uint8_t> sequence;
-    NormalRecord nrecord;
+    // The record types hold two dozen strings; most haplotypes of most windows never get one (nothing can observe them), and the
+    // consumer creates a HapSeq per haplotype per window - so the payload is allocated only when a record is actually built.
+    struct Payload {
+        IDRecord record;
+        // `normal` mode (normal_microphasing.rs:182-186): the sequence bytes + its own record type
+        std::vector<uint8_t> sequence;
+        NormalRecord nrecord;
+    };
+    std::unique_ptr<Payload> p;
     bool filled = false;   // consumer: the record was built (the planner marked the window as carried or it is emitted)
     uint32_t win = 0xFFFFFFFFu;   // consumer: window the haplotype came from (diagnostics)
     uint64_t frame = 0;
+    Payload& make() { if (!p) p.reset(new Payload()); return *p; }
+    const Payload& get() const { static const Payload empty; return p ? *p : empty; }
 };
 
 struct ExonGeom {
@@ -50,16 +58,51 @@ struct StepGeom {
     size_t vlo = 0, vhi = 0;                // forward (position-sorted) variant index range of [sso, splice_end)
 };
 
+// lower_bound on a sorted position array for query streams that move by a few positions per call (the window scheduler asks for
+// sso, splice_end, old_offset, old_end ... of consecutive nt offsets): a few remembered (position, index) pairs, the nearest one is
+// walked linearly to the answer; a far query falls back to the binary search. Pure function of (array, pos): same results.
+struct HintedLower {
+    static constexpr int SLOTS = 4;
+    mutable uint64_t hpos[SLOTS] = {0, 0, 0, 0};
+    mutable size_t hidx[SLOTS] = {0, 0, 0, 0};
+    mutable int filled = 0, next = 0;
+    template <class At>   // at(i) = position of element i, ascending; n elements
+    size_t lower(uint64_t pos, size_t n, const At& at) const {
+        int best = -1;
+        uint64_t best_d = 64;   // only hints within 64 positions are worth walking from
+        for (int k = 0; k < filled; k++) {
+            const uint64_t dlt = hpos[k] > pos ? hpos[k] - pos : pos - hpos[k];
+            if (dlt < best_d) { best_d = dlt; best = k; }
+        }
+        size_t i;
+        if (best >= 0) {
+            i = hidx[best];
+            while (i < n && at(i) < pos) i++;
+            while (i > 0 && at(i - 1) >= pos) i--;
+        } else {
+            size_t lo = 0, hi = n;
+            while (lo < hi) {
+                size_t mid = (lo + hi) / 2;
+                if (at(mid) < pos) lo = mid + 1; else hi = mid;
+            }
+            i = lo;
+            best = next;
+            next = (next + 1) % SLOTS;
+            if (filled < SLOTS) filled++;
+        }
+        hpos[best] = pos;
+        hidx[best] = i;
+        return i;
+    }
+};
+
 // Variant positions of one gene in forward order (ascending pos, ALT order within a pos) with range counting.
 struct VarIndex {
     const std::vector<Variant>* vars = nullptr;
+    HintedLower hint;
     size_t lower(uint64_t pos) const {
-        size_t lo = 0, hi = vars->size();
-        while (lo < hi) {
-            size_t mid = (lo + hi) / 2;
-            if ((*vars)[mid].pos < pos) lo = mid + 1; else hi = mid;
-        }
-        return lo;
+        const std::vector<Variant>& v = *vars;
+        return hint.lower(pos, v.size(), [&v](size_t i) { return v[i].pos; });
     }
     size_t count(uint64_t a, uint64_t b) const {
         if (a > b) throw Error("reference would panic: range start is greater than range end in BTreeMap");
@@ -92,7 +135,8 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
     size_t last_window_vars = 0;
     size_t carry_shrink = 0;  // exon-start shrink not yet folded into a step (exon without any window)
     size_t exon_count = 0;
-    std::vector<size_t> new_cols;
+    std::vector<size_t> new_cols, all;                       // per-step scratch, allocated once per transcript
+    std::vector<std::pair<uint64_t, uint64_t>> active;
     for (size_t ei = 0; ei < transcript.exons.size(); ei++) {
         const Interval& exon = transcript.exons[ei];
         if (frameshifts.empty()) break;
@@ -189,7 +233,7 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
                 for (size_t k = sg.vlo + (sg.nvars - sg.added); k < sg.vhi; k++) new_cols.push_back(k);
             } else {
                 // positions descending, ALT order kept within one position
-                std::vector<size_t> all;
+                all.clear();
                 size_t hi = sg.vhi;
                 while (hi > sg.vlo) {
                     size_t lo = hi - 1;
@@ -216,7 +260,7 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
             }
             hooks.on_step(eg, sg, new_cols);
             uint64_t stopped_frameshift = 3;
-            std::vector<std::pair<uint64_t, uint64_t>> active;  // :1347-1350
+            active.clear();  // :1347-1350
             if (is_fwd) {
                 for (auto it = frameshifts.begin(); it != frameshifts.end() && it->first < offset; ++it) active.push_back(*it);
             } else {
