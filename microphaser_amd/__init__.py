@@ -345,9 +345,18 @@ class Peptides:
         p = L.mp_peptides_binary(h, ctypes.byref(n))
         self.binary = _bytes_at(p, n.value)
         p = L.mp_peptides_keys(h, ctypes.byref(n))
-        self.keys = list((ctypes.c_uint64 * n.value).from_address(p)) if n.value else []
+        import numpy as np
+        # the keys as a numpy array (a whole-exome peptidome holds ~10^7 of them); `.keys` gives the same as a Python list on demand
+        self.keys_np = np.frombuffer((ctypes.c_char * (8 * n.value)).from_address(p), dtype=np.uint64).copy() if n.value else np.zeros(0, dtype=np.uint64)
+        self._keys = None
         self.count = L.mp_peptides_count(h)
         L.mp_peptides_free(h)
+
+    @property
+    def keys(self):
+        if self._keys is None:
+            self._keys = self.keys_np.tolist()
+        return self._keys
 
 
 class Filtered:

@@ -91,44 +91,80 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
     uint32_t ncov = 0;
     bool more = true;   // the group's run may continue (every variant of the previous round was covered)
-    for (uint32_t b0 = 0; b0 < 64u * W; b0 += K1_LANES) {
+    // The kernel is bound by dependent loads, not by bytes: (variant position -> base, quality) is a two-level chain per variant. K1_ROUNDS
+    // rounds of K1_LANES variants are therefore taken together - all their positions are loaded first, then all their bases and
+    // qualities, then everything is evaluated - so a typical read (about 20 variants in its span) pays the chain once, not five times.
+    constexpr uint32_t K1_ROUNDS = 6;
+    for (uint32_t b0 = 0; b0 < 64u * W; b0 += K1_LANES * K1_ROUNDS) {
         if (__ballot(more) == 0) break;   // wave-uniform
-        const uint32_t b = b0 + sub;
-        const bool in = more && b < maxn;
-        uint32_t vpos = 0xFFFFFFFFu, info = 0;
-        if (in) { vpos = d.v_pos[vbase + lo + b]; info = d.v_info[vbase + lo + b]; }
-        const bool cov = in && vpos < cover_end;
-        bool s = false, q = false;
-        if (cov) {
-            const uint32_t kind = info & VI_KIND_MASK;
-            if (kind == 0) {  // SNV (:97-112, :80-92)
-                const uint32_t rel = vpos - rpos;
-                const uint8_t qb = rel < lseq ? qual[rel] : uint8_t(255);
-                q = !d.normal && qb < 10;  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
+        uint32_t vpos[K1_ROUNDS], info[K1_ROUNDS];
+        bool in[K1_ROUNDS];
+        // (the loads are unconditional, at clamped addresses - the pools are padded -, and their results selected afterwards: a load
+        //  under a branch makes the compiler drain the memory counter at the join, which would serialise the rounds again)
+        const uint32_t last_b = maxn ? maxn - 1 : 0;
+#pragma unroll
+        for (uint32_t r = 0; r < K1_ROUNDS; r++) {
+            const uint32_t b = b0 + r * K1_LANES + sub;
+            in[r] = more && b < maxn;
+            const uint32_t at = vbase + lo + min(b, last_b);
+            vpos[r] = d.v_pos[at];
+            info[r] = d.v_info[at];
+        }
+        bool cov[K1_ROUNDS], snv[K1_ROUNDS];
+        uint8_t qb[K1_ROUNDS], b4[K1_ROUNDS];
+        int rp[K1_ROUNDS];
+        const uint32_t last_q = lseq ? lseq - 1 : 0;
+        uint8_t ql[K1_ROUNDS], sl[K1_ROUNDS];
+#pragma unroll
+        for (uint32_t r = 0; r < K1_ROUNDS; r++) {   // second level: qualities and (single-M CIGARs: the common case) bases - all issued first
+            if (!in[r]) { vpos[r] = 0xFFFFFFFFu; info[r] = 0; }
+            const uint32_t relc = min(vpos[r] - rpos, last_q);
+            ql[r] = qual[relc];
+            sl[r] = seq4[relc >> 1];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < K1_ROUNDS; r++) {
+            cov[r] = in[r] && vpos[r] < cover_end;
+            snv[r] = cov[r] && (info[r] & VI_KIND_MASK) == 0;
+            const uint32_t rel = vpos[r] - rpos;
+            qb[r] = (snv[r] && rel < lseq) ? ql[r] : uint8_t(255);   // the reference indexes the qualities by reference offset (:82-88)
+            rp[r] = (snv[r] && simple && rel < (c0 >> 4)) ? int(rel) : -1;
+            b4[r] = (rp[r] >= 0 && rel < lseq) ? sl[r] : uint8_t(0);
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < K1_ROUNDS; r++) {
+            bool s = false, q = false;
+            if (snv[r]) {  // SNV (:97-112, :80-92)
+                q = !d.normal && qb[r] < 10;  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
                 if (!q) {
-                    int p = simple ? int(vpos - rpos) : cigar_read_pos_dev(cig, ncig, rpos, vpos);
-                    if (simple && uint32_t(p) >= (c0 >> 4)) p = -1;
+                    int p = rp[r];
+                    uint8_t byte = b4[r];
+                    if (!simple) {
+                        p = cigar_read_pos_dev(cig, ncig, rpos, vpos[r]);
+                        if (p >= 0 && uint32_t(p) < lseq) byte = seq4[p >> 1];
+                    }
                     if (p >= 0 && uint32_t(p) < lseq) {
-                        const uint8_t b4 = seq4[p >> 1];
-                        const uint32_t code = (p & 1) ? (b4 & 0xF) : (b4 >> 4);
-                        s = decode_base4(code) == uint8_t(info >> VI_ALT_SHIFT);
+                        const uint32_t code = (p & 1) ? (byte & 0xF) : (byte >> 4);
+                        s = decode_base4(code) == uint8_t(info[r] >> VI_ALT_SHIFT);
                     }
                 }
-            } else {  // insertion / deletion: any I / D op of exactly that length (:113-137)
-                const uint32_t want = kind == 1 ? 1u : 2u;
+            } else if (cov[r]) {  // insertion / deletion: any I / D op of exactly that length (:113-137)
+                const uint32_t b = b0 + r * K1_LANES + sub;
+                const uint32_t want = (info[r] & VI_KIND_MASK) == 1 ? 1u : 2u;
                 const uint32_t vlen = d.v_len[vbase + lo + b];
                 for (uint32_t c = 0; c < ncig; c++)
                     if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
             }
-        }
-        // the group's slices of the three wave ballots: coverage (a prefix of the lanes), support, low quality
-        const uint32_t covm = uint32_t(__ballot(cov) >> gshift) & K1_SLICE;
-        const uint64_t supm = (__ballot(s) >> gshift) & uint64_t(K1_SLICE), lqm = (__ballot(q) >> gshift) & uint64_t(K1_SLICE);
-        ncov += __popc(covm);
+            // the group's slices of the three wave ballots: coverage (a prefix of the lanes), support, low quality
+            const uint32_t bb = b0 + r * K1_LANES;
+            const uint32_t covm = uint32_t(__ballot(cov[r]) >> gshift) & K1_SLICE;
+            const uint64_t supm = (__ballot(s) >> gshift) & uint64_t(K1_SLICE), lqm = (__ballot(q) >> gshift) & uint64_t(K1_SLICE);
+            ncov += __popc(covm);
 #pragma unroll
-        for (int w = 0; w < W; w++)
-            if ((b0 >> 6) == uint32_t(w)) { sup[w] |= supm << (b0 & 63); lq[w] |= lqm << (b0 & 63); }
-        more = more && covm == K1_SLICE;
+            for (int w = 0; w < W; w++)
+                if ((bb >> 6) == uint32_t(w)) { sup[w] |= supm << (bb & 63); lq[w] |= lqm << (bb & 63); }
+            more = more && covm == K1_SLICE;
+        }
     }
     if (valid && sub == 0) {
         d.r_ncov[i] = ncov;
@@ -684,7 +720,9 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
             } else if (start > sso0 && e.n_steps > 1 && start >= sso1) {
                 // afterwards only the reads that start exactly at sso (:1241-1248); steps 1.. advance by one nt each
                 uint32_t t = 1 + (start - sso1);
-                if (t < e.n_steps) {
+                if (t < e.unit_steps) {
+                    try_step(e.step_off + t);            // sso(t) == start by the exon's arithmetic (plan.hpp ExonW::unit_steps)
+                } else if (t < e.n_steps) {
                     uint32_t s_t = d.steps[e.step_off + t].sso;
                     while (s_t > start && t > 1) s_t = d.steps[e.step_off + --t].sso;            // (never taken for unit steps)
                     while (s_t < start && t + 1 < e.n_steps) s_t = d.steps[e.step_off + ++t].sso;
@@ -695,11 +733,14 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
             // candidate while sso - R <= start <= sso; sso never increases along the exon (one nt per step, repeats at the end)
             const uint32_t top = start + e.range;
             uint32_t t = sso0 > top ? sso0 - top : 0;   // first step with sso <= start + R if every step moved by one
-            if (t >= e.n_steps) t = e.n_steps - 1;
-            while (t > 0 && d.steps[e.step_off + t - 1].sso <= top) t--;
-            while (t < e.n_steps && d.steps[e.step_off + t].sso > top) t++;
+            if (t >= e.unit_steps) {                    // beyond the arithmetic stretch: look at the steps
+                if (t >= e.n_steps) t = e.n_steps - 1;
+                while (t > 0 && d.steps[e.step_off + t - 1].sso <= top) t--;
+                while (t < e.n_steps && d.steps[e.step_off + t].sso > top) t++;
+            }
             for (; t < e.n_steps; t++) {
-                if (d.steps[e.step_off + t].sso < start) break;
+                const uint32_t s_t = t < e.unit_steps ? sso0 - t : d.steps[e.step_off + t].sso;
+                if (s_t < start) break;
                 if (try_step(e.step_off + t)) break;
             }
         }

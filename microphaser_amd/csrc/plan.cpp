@@ -548,6 +548,12 @@ static void route_window_parallel(Batch& b) {
         e.strand = T.strand; e.rbase = gh.read_off; e.vbase = gh.var_off;
         e.sso0 = b.steps[g.step_off].sso;
         e.sso1 = g.n_steps > 1 ? b.steps[g.step_off + 1].sso : e.sso0;
+        {
+            uint32_t u = 1;
+            if (T.strand) { while (u < g.n_steps && b.steps[g.step_off + u].sso + u == e.sso0) u++; }
+            else { while (u < g.n_steps && b.steps[g.step_off + u].sso == e.sso1 + (u - 1)) u++; }
+            e.unit_steps = u;
+        }
         const uint32_t ei = uint32_t(b.exons_w.size());
         b.exons_w.push_back(e);
         for (uint32_t k0 = 0; k0 < e.n_reads; k0 += 64) b.achunks.push_back(WChunk{ei, k0, std::min(64u, e.n_reads - k0), 0});

@@ -64,6 +64,8 @@ struct ExonW {
     uint32_t strand;                // TxDev::strand
     uint32_t rbase, vbase;          // batch index of the gene's first read / first variant
     uint32_t sso0, sso1;            // splice_side_offset of the exon's first and second step
+    uint32_t unit_steps;            // steps [0, unit_steps) move by exactly one nt each: '+' sso(t) = sso1 + (t - 1) for t >= 1, '-' sso(t) = sso0 - t -
+                                    // K2a then finds a read's first candidate step by arithmetic alone, without looking at the steps
 };
 struct WChunk {                     // K2w work item: a run of steps of one ExonW
     uint32_t exon, step_first, n_steps, pad;

@@ -22,7 +22,7 @@ def normal_peptidome_keys(ctx, ds, local_genes, peptide_len):
     nb.run()
     nres = nb.results()
     pep = ctx.build_reference(nres.fasta, peptide_len)
-    return np.array(pep.keys, dtype=np.uint64), nres
+    return pep.keys_np, nres
 
 
 def somatic_shard(ds, local_genes, global_genes, peptide_len):
