@@ -2066,8 +2066,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     uint64_t prof_set = 0;
     bool want_id = false;
     uint32_t seq_len = 0, germ_len = 0, prof_len = 0, nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
+    uint32_t rec_sso = 0, rec_tx = 0;
     if (live) {
         const WinStatic ws = d.wins[w];
+        rec_sso = ws.sso; rec_tx = ws.tx;
         const uint32_t vbase = ws.vbase;
         const uint64_t hap = hap_pre;
         const bool is_rev = (ws.flags & WSF_REVERSE) != 0;
@@ -2076,10 +2078,19 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
         // stage the reference window [sso, sso + wlen) with aligned dword loads
         const uint8_t* wref = d.ref_pool + ws.ref_off;
         const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(wref) & 3u);
+        // (all loads of this level - the staged reference dwords and the first eight columns - are issued together and unconditionally, at
+        //  clamped addresses into padded pools: a load under a branch makes the compiler drain the memory counter at the join)
+        uint32_t refw[K3_REFCAP / 4];
+        uint32_t cp[8], ci[8];
         {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(wref - mis);
-            const uint32_t ndw = (mis + ws.wlen + 3) >> 2;
-            for (uint32_t k = 0; k < ndw && k < K3_REFCAP / 4; k++) slot[k] = src[k];
+#pragma unroll
+            for (int k = 0; k < K3_REFCAP / 4; k++) refw[k] = src[k];
+            const uint32_t last_c = ncols ? ncols - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const WinCol* wc = d.win_cols + ws.col_off + min(uint32_t(k), last_c); cp[k] = wc->pos; ci[k] = wc->info; }
+#pragma unroll
+            for (int k = 0; k < K3_REFCAP / 4; k++) slot[k] = refw[k];
         }
         const uint32_t staged = min(uint32_t(ws.wlen), uint32_t(K3_REFCAP) - mis);
         auto ref_at = [&](uint32_t pos) -> uint8_t {  // reference base at absolute position pos (>= sso)
@@ -2108,11 +2119,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
                 nvar++;
                 prof_set |= 1ull << (is_rev ? (ncols - 1 - dq) : dq);
             };
-            // the first eight columns are fetched together (independent loads), the rare rest one by one
-            uint32_t cp[8], ci[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (uint32_t(k) < ncols) { const WinCol* wc = d.win_cols + ws.col_off + k; cp[k] = wc->pos; ci[k] = wc->info; }
+            // the first eight columns were fetched together above (cp / ci, deque order), the rare rest one by one
             // only the first `vis` columns in walk order can ever be visited: deque columns [0, vis) on '+', [ncols - vis, ncols) on '-'
             const uint32_t vis = ws.need_recs >> WS_PREFIX_SHIFT;
             const uint32_t dlo = is_rev ? ncols - vis : 0u, dhi = is_rev ? ncols : vis;
@@ -2132,8 +2139,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
                 cpos[k] = 0xFFFFFFFFu; cinfo[k] = 0;
                 if (uint32_t(k) < ncols) {
                     const uint32_t dq = is_rev ? (ncols - 1 - k) : uint32_t(k);
-                    const WinCol* wc = d.win_cols + ws.col_off + dq;
-                    cpos[k] = wc->pos; cinfo[k] = wc->info;
+                    if (is_rev || dq >= 8) { const WinCol* wc = d.win_cols + ws.col_off + dq; cpos[k] = wc->pos; cinfo[k] = wc->info; }
+                    else { cpos[k] = cp[k]; cinfo[k] = ci[k]; }
                 }
             }
             auto load_j = [&]() {
@@ -2256,15 +2263,14 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
         if (slot_idx != 0xFFFFFFFFu) {
             uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
             if (need_rec) {
-                out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
-                out[2] = 0; out[3] = 0;
-                out[4] = seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24);
-                out[5] = nsom | (first_fs << 8) | (first_fs_j << 16);
-                out[6] = w;
-                out[7] = want_id ? 1u : 0u;
+                // 16-byte stores (records are 16-byte aligned: rec_stride and the header are multiples of 16): a quarter of the store instructions
+                uint4* const out4 = reinterpret_cast<uint4*>(out);
+                out4[0] = make_uint4(uint32_t(prof_set), uint32_t(prof_set >> 32), rec_sso, rec_tx);   // [2], [3]: what K3b hashes besides the sequence
+                                                                                                      // (it overwrites them with the id)
+                out4[1] = make_uint4(seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24), nsom | (first_fs << 8) | (first_fs_j << 16), w, want_id ? 1u : 0u);
                 const uint32_t* sq = slot + K3_REFCAP / 4;
 #pragma unroll
-                for (int k = 0; k < 2 * SEQ_CAP / 4; k++) out[8 + k] = sq[k];
+                for (int k = 0; k < 2 * SEQ_CAP / 16; k++) out4[2 + k] = make_uint4(sq[4 * k], sq[4 * k + 1], sq[4 * k + 2], sq[4 * k + 3]);
                 sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
                 recidx = slot_idx;
             } else {
@@ -2390,7 +2396,7 @@ __device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_
         uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
         germ_dw[0] = uint32_t(prof_som); germ_dw[1] = uint32_t(prof_som >> 32);
         out[0] = uint32_t(prof_set); out[1] = uint32_t(prof_set >> 32);
-        out[2] = 0; out[3] = 0;
+        out[2] = ws.sso; out[3] = ws.tx;   // what K3b hashes besides the sequence (it overwrites them with the id)
         out[4] = seq_len | (0u << 8) | (min(prof_len, 255u) << 16) | (min(nvar, 255u) << 24);
         out[5] = min(nsom, 255u);
         out[6] = w;
@@ -2449,13 +2455,27 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d) {
     if (li >= n_recs) continue;
     const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + woff];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
-    const uint32_t seq_len = rec[4] & 0xFF;
-    const WinStatic ws = d.wins[rec[6]];
-    const TxDev T = d.tx[ws.tx];
+    // everything the id needs sits in the record K3 wrote (header: sequence length, window offset, transcript; then the sequence):
+    // one contiguous read instead of record -> window -> transcript hops, issued at once
+    const uint4* rec4 = reinterpret_cast<const uint4*>(rec);
+    const uint4 h0 = rec4[0], h1 = rec4[1];
+    uint32_t sq[SEQ_CAP / 4];
+#pragma unroll
+    for (int k = 0; k < SEQ_CAP / 16; k++) { const uint4 v = rec4[2 + k]; sq[4 * k] = v.x; sq[4 * k + 1] = v.y; sq[4 * k + 2] = v.z; sq[4 * k + 3] = v.w; }
+    const uint32_t seq_len = h1.x & 0xFF, win_sso = h0.z;
+    const TxDev T = d.tx[h0.w];
+    // the transcript id: its first 20+ characters as six aligned dwords, fetched together (longer ids: the rest byte by byte)
+    const uint8_t* idp = d.str_pool + T.id_off;
+    const uint32_t id_mis = uint32_t(reinterpret_cast<uintptr_t>(idp) & 3u);
+    uint32_t idw[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) idw[k] = reinterpret_cast<const uint32_t*>(idp - id_mis)[k];   // (the pool is padded)
     auto feed_message = [&](auto& sh) {
         sh.feed('[', 1);
-        for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP) && k0 < seq_len; k0 += 4) {
-            const uint32_t dw = rec[8 + (k0 >> 2)];
+#pragma unroll
+        for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP); k0 += 4) {
+            if (k0 >= seq_len) break;
+            const uint32_t dw = sq[k0 >> 2];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const uint32_t k = k0 + b;
@@ -2470,13 +2490,22 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d) {
             }
         }
         sh.feed(']', 1);
-        for (uint32_t k = 0; k < T.id_len; k += 4) {   // transcript id, four characters per feed
+#pragma unroll
+        for (uint32_t k = 0; k < 20; k += 4) {   // transcript id, four characters per feed: from the prefetched dwords
+            if (k < T.id_len) {
+                const uint32_t n = min(4u, T.id_len - k);
+                const uint32_t le = __builtin_amdgcn_alignbyte(idw[k / 4 + 1], idw[k / 4], id_mis);   // characters k .. k + 3, first one in the low byte
+                const uint32_t be = __builtin_bswap32(le) >> (8 * (4 - n));                           // big-endian, the first n of them
+                sh.feed(be, n);
+            }
+        }
+        for (uint32_t k = 20; k < T.id_len; k += 4) {
             uint64_t txt = 0;
             const uint32_t n = min(4u, T.id_len - k);
             for (uint32_t c = 0; c < n; c++) txt = (txt << 8) | d.str_pool[T.id_off + k + c];
             sh.feed(txt, n);
         }
-        sh.feed_dec(ws.sso);
+        sh.feed_dec(win_sso);
         sh.finish();
     };
     uint32_t o0, o1;
