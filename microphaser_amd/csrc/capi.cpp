@@ -222,9 +222,9 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 const uint64_t lane_wins = b.winw.size(), wave_wins = batch->w_wins - std::min<uint64_t>(batch->w_wins, lane_wins);
                 const uint64_t groups_l = batch->w_wins ? uint64_t(double(groups_w) * double(lane_wins) / double(batch->w_wins)) : 0;
                 st->k2l_ms = t.k2l_ms; st->n_windows_lane = lane_wins; st->n_windows_wave = wave_wins;
-                const uint64_t settled = t.n_groups - std::min(t.n_groups, t.n_k3);   // groups whose GroupSum K2l wrote itself
-                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * (sizeof(Group) + 8) +
-                                settled * sizeof(GroupSum) + (t.n_k3 > (t.n_groups - groups_l) ? (t.n_k3 - (t.n_groups - groups_l)) * 4 : 0);
+                // the lane kernel writes a Group per group; window / record index / K3-list entry only for the groups it hands on to K3
+                const uint64_t listed_l = t.n_k3 > (t.n_groups - groups_l) ? t.n_k3 - (t.n_groups - groups_l) : 0;
+                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * sizeof(Group) + listed_l * 12;
                 st->bytes_k2w = wave_steps * (sizeof(Step) + 7) + uint64_t(double(b.n_adm) * wave_share) * (read_bytes + sizeof(AdmEntry)) +
                                 wave_wins * sizeof(WinDyn) + (groups_w - groups_l) * (sizeof(Group) + 8);
                 st->bytes_k2seq = seq_steps * sizeof(Step) + (b.steps.empty() ? 0 : uint64_t(double(b.r_pos.size()) * double(seq_steps) / double(b.steps.size()))) * read_bytes +

@@ -189,7 +189,7 @@ struct ConsumerHooks {
             const Group& G = res.grp(slot);
             if (G.hap == 0 && zero_slot == ~0ull) zero_slot = slot;
             if (G.count == 0) continue;
-            uint64_t f0 = G.aux >> 1;
+            uint64_t f0 = (G.aux & ~GROUP_SETTLED) >> 1;
             bool f1nz = G.aux & 1;
             if (frame > 0 && f0 != frame && f1nz) continue;
             frame_depth += G.count;
@@ -219,7 +219,9 @@ struct ConsumerHooks {
         haplotypes_vec.reserve(keys.size());
         uint64_t shift_in_window = 0;
         for (const Key& key : keys) {
-            const GroupSum& gs = res.gsm(key.slot);
+            // a group the lane-per-window kernel settled itself (plan.hpp GROUP_SETTLED) has no GroupSum: it is {valid, no record}
+            const GroupSum settled_gs{GS_VALID, 0};
+            const GroupSum& gs = (res.grp(key.slot).aux & GROUP_SETTLED) ? settled_gs : res.gsm(key.slot);
             if (!(gs.flags & GS_VALID)) throw Error("internal error: haplotype was not processed by the window-sequence kernel");
             const HapRecHdr* rec = (gs.flags & GS_HAS_REC) ? res.rec(gs.rec) : nullptr;
             const uint8_t* rseq = rec ? res.rec_seq(gs.rec) : nullptr;

@@ -805,12 +805,16 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         const bool valid = li < count;
         uint32_t win = 0, rr_lo = 0, pack = 0, wkey = 0, step = 0, col_hi = 0, flo = 0;
         uint64_t som_mask = 0;
-        if (valid) {
-            const uint4* wp = reinterpret_cast<const uint4*>(d.winw + first + li);
+        {   // (unconditional loads at a clamped index, selected afterwards: no memory-counter drain at a branch join)
+            const uint32_t at = first + min(li, count - 1);
+            const uint4* wp = reinterpret_cast<const uint4*>(d.winw + at);
             const uint4 w0 = wp[0], w1 = wp[1];
-            rr_lo = w0.x; pack = w0.y; wkey = w0.z; step = w0.w;
-            col_hi = w1.x; flo = w1.y; som_mask = (uint64_t(w1.w) << 32) | w1.z;
-            win = d.lane_win[first + li];
+            const uint32_t wn = d.lane_win[at];
+            if (valid) {
+                rr_lo = w0.x; pack = w0.y; wkey = w0.z; step = w0.w;
+                col_hi = w1.x; flo = w1.y; som_mask = (uint64_t(w1.w) << 32) | w1.z;
+                win = wn;
+            }
         }
         const uint32_t r_n = pack & 0x3FF, ncols = (pack >> 10) & 0x3F;
         const bool fwd = (pack & WW_FWD) != 0, need_all = (pack & WW_NEED_ALL) != 0;
@@ -864,9 +868,22 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
             const bool fit = pending && rr_lo - base + r_n <= STAGE;
             const uint32_t n_stage = wave_max(fit ? rr_lo - base + r_n : 0u), rn_max = wave_max(fit ? r_n : 0u);
             __syncthreads();   // the previous pass's reads of the stage are done
-            for (uint32_t i = lane; i < n_stage; i += 64) {
-                st_a[i] = *reinterpret_cast<const uint4*>(d.rr_a + base + i);
-                st_s[i] = d.rr_sup[base + i];
+            {   // n_stage <= STAGE records: all of a lane's loads first (clamped index), then the LDS writes
+                constexpr uint32_t PER_LANE = (STAGE + 63) / 64;
+                uint4 va[PER_LANE];
+                uint64_t vs[PER_LANE];
+                const uint32_t last = n_stage ? n_stage - 1 : 0;
+#pragma unroll
+                for (uint32_t u = 0; u < PER_LANE; u++) {
+                    const uint32_t i = min(lane + 64u * u, last);
+                    va[u] = *reinterpret_cast<const uint4*>(d.rr_a + base + i);
+                    vs[u] = d.rr_sup[base + i];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < PER_LANE; u++) {
+                    const uint32_t i = lane + 64u * u;
+                    if (i < n_stage) { st_a[i] = va[u]; st_s[i] = vs[u]; }
+                }
             }
             __syncthreads();
             const uint32_t s_at = fit ? rr_lo - base : 0u, s_last = fit ? r_n - 1 : 0u;
@@ -942,14 +959,12 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                     if (cnt || key == 0) {
                         const bool need = need_all || (uint64_t(key) & som_mask) != 0;
                         if (can_write) {
-                            Group G; G.hap = key; G.count = cnt; G.aux = 0;
+                            const bool settled = trivial && !need;   // what K3 would find: valid, no stop, mutant == germline, no record
+                            Group G; G.hap = key; G.count = cnt; G.aux = settled ? GROUP_SETTLED : 0u;
                             d.groups[gslot] = G;
-                            d.g_win[gslot] = win;
-                            d.g_rec[gslot] = (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu;
-                            if (trivial && !need) {   // what K3 would find: valid, no stop, mutant == germline, no record
-                                GroupSum gs; gs.flags = GS_VALID; gs.rec = 0;
-                                d.gsum[gslot] = gs;
-                            } else {
+                            if (!settled) {   // the rest is for K3 only
+                                d.g_win[gslot] = win;
+                                d.g_rec[gslot] = (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu;
                                 d.k3_list[lslot++] = uint32_t(gslot);
                             }
                         }

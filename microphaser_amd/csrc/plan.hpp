@@ -179,8 +179,11 @@ enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4, WD_RE
 struct Group {           // K2 output: one distinct (haplotype, frame.0, frame.1 != 0) key of one window, ascending
     uint64_t hap;
     uint32_t count;
-    uint32_t aux;        // frame0 << 1 | (frame1 != 0)
+    uint32_t aux;        // frame0 << 1 | (frame1 != 0); GROUP_SETTLED: see below
 };
+// K2l settles a group of a simple window that cannot hold a stop and that carries no somatic column itself: what K3 would find for it is
+// GroupSum {GS_VALID, no record}. It says so in the group (no GroupSum is written, K3 never sees the group).
+constexpr uint32_t GROUP_SETTLED = 1u << 31;
 
 // GroupSum.flags
 enum : uint32_t {
