@@ -154,7 +154,7 @@ def main():
         st = batch.run()
     sync_all()
     t0 = time.perf_counter()
-    k1 = k2s = k2a = k2l = k2w = k3 = k3b = 0.0
+    k1 = k2s = k2a = k2l = k2w = k3 = k3b = k2win = 0.0
     for _ in range(args.steps):
         st = batch.run()          # returns after the launch stream has drained (results in HBM)
         k1 += st.k1_ms
@@ -162,6 +162,7 @@ def main():
         k2a += st.k2a_ms
         k2l += st.k2l_ms
         k2w += st.k2w_ms
+        k2win += st.k2win_ms
         k3 += st.k3_ms
         k3b += st.k3b_ms
     sync_all()
@@ -233,6 +234,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms,
                          "limiter": "instruction issue / latency, not HBM (integer and bitset work: see DESIGN.md section 4 and profiles/)"},
             "kernels_ms": {k: v[0] for k, v in kern.items()},
+            "kernels_note": "k2l_window_lanes (its two launches) and k2w_window_rows run side by side on separate streams after k2a (and k2_window_replay beside k2a): "
+                            "their intervals overlap; k2_window_phase_ms is the wall time of that phase",
+            "k2_window_phase_ms": k2win / steps,
             "kernels_algorithmic_bytes": {k: int(v[1]) for k, v in kern.items()},
             "kernels_hbm_frac": {k: (v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else 0.0) for k, v in kern.items()},
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),

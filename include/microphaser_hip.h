@@ -146,6 +146,10 @@ typedef struct mp_run_stats {
     double k2l_ms;
     uint64_t bytes_k2l, n_windows_lane, n_windows_wave;
     uint64_t n_groups_k3;                  /* groups k3_window_seq looked at (k2l settles a group of a simple window without a somatic column itself) */
+    /* The launches of the window phase run side by side on several streams (sequential replay beside k2a; then k2l <= 6 columns, k2l 7-8
+     * columns and the wave-per-window kernels together): k2seq_ms, k2l_ms and k2w_ms are overlapping intervals; k2win_ms is the wall
+     * time from the end of k2a until all of them have finished. */
+    double k2win_ms;
 } mp_run_stats;
 
 /* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM

@@ -207,7 +207,7 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 const double wfrac = b.wins.empty() ? 0.0 : double(batch->w_wins) / double(b.wins.size());
                 const uint64_t groups_w = uint64_t(double(t.n_groups) * wfrac), groups_seq = t.n_groups - groups_w;
                 const uint64_t read_bytes = 20 + 16ull * b.mask_words;   // start, end, first variant, coverage, dup + the two masks
-                st->k2seq_ms = t.k2seq_ms; st->k2a_ms = t.k2a_ms; st->k2w_ms = t.k2w_ms;
+                st->k2seq_ms = t.k2seq_ms; st->k2a_ms = t.k2a_ms; st->k2w_ms = t.k2w_ms; st->k2win_ms = t.k2win_ms;
                 st->n_steps_seq = seq_steps; st->n_steps_w = w_steps; st->n_adm = b.n_adm;
                 // K2a writes an AdmEntry per (exon, read) and, for the lane-per-window kernel, a RowRec (16 + 8 bytes)
                 const uint64_t rowrec = b.lane_on ? sizeof(RowRecA) + 8 : 0;

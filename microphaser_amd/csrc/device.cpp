@@ -19,12 +19,18 @@ DeviceContext::DeviceContext(int device) : device_(device) {
     HIP_OK(hipSetDevice(device));
     HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     for (auto& ev : ev_) HIP_OK(hipEventCreate(&ev));
+    for (auto& st : side_) HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto& ev : fork_) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto& ev : join_) HIP_OK(hipEventCreate(&ev));
 }
 
 DeviceContext::~DeviceContext() {
     hipSetDevice(device_);
     free_batch();
-    for (auto& ev : ev_) if (ev) hipEventDestroy(ev);
+    for (auto& ev : ev_) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : fork_) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : join_) if (ev) (void)hipEventDestroy(ev);
+    for (auto& st : side_) if (st) (void)hipStreamDestroy(st);
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -206,13 +212,25 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(ev_[0], stream_));
         launch_k1_pileup_bits(d_, stream_);
         HIP_OK(hipEventRecord(ev_[1], stream_));
-        launch_k2_window_replay(d_, rpl_, stream_);     // sequential replay of the segments that need it
+        // The launches of the window phase work on disjoint windows and are each bound by latency at modest occupancy, so they run side
+        // by side: the sequential replay (needs K1 only) beside K2a; after K2a the two lane-per-window launches and the wave-per-window
+        // kernels on three streams. Everything joins before K3. (The output allocators are shared: atomics.)
+        HIP_OK(hipEventRecord(fork_[0], stream_));
+        HIP_OK(hipStreamWaitEvent(side_[2], fork_[0], 0));
+        launch_k2_window_replay(d_, rpl_, side_[2]);    // sequential replay of the segments that need it
+        HIP_OK(hipEventRecord(join_[2], side_[2]));
         HIP_OK(hipEventRecord(ev_[5], stream_));
         launch_k2_admission(d_, stream_);                // K2a + K2l + K2w: everything else, window-parallel
         HIP_OK(hipEventRecord(ev_[6], stream_));
-        launch_k2_window_lanes(d_, stream_);             // lane per window: the narrow windows (most of them)
+        HIP_OK(hipEventRecord(fork_[1], stream_));
+        HIP_OK(hipStreamWaitEvent(side_[0], fork_[1], 0));
+        HIP_OK(hipStreamWaitEvent(side_[1], fork_[1], 0));
+        launch_k2_window_lanes(d_, stream_, side_[0]);   // lane per window: <= 6 columns here, 7-8 columns beside it
         HIP_OK(hipEventRecord(ev_[7], stream_));
-        launch_k2_window_rows(d_, stream_);              // wave per window: the rest
+        HIP_OK(hipEventRecord(join_[0], side_[0]));
+        launch_k2_window_rows(d_, side_[1]);             // wave per window: the rest, beside them
+        HIP_OK(hipEventRecord(join_[1], side_[1]));
+        for (auto& ev : join_) HIP_OK(hipStreamWaitEvent(stream_, ev, 0));
         HIP_OK(hipEventRecord(ev_[2], stream_));
         // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
         // (their grids cover an upper bound of the counts: the previous pass's counts of this batch plus a margin, else an estimate)
@@ -264,10 +282,15 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
         HIP_OK(hipEventElapsedTime(&t.k2_ms, ev_[1], ev_[2]));
-        HIP_OK(hipEventElapsedTime(&t.k2seq_ms, ev_[1], ev_[5]));
-        HIP_OK(hipEventElapsedTime(&t.k2a_ms, ev_[5], ev_[6]));
-        HIP_OK(hipEventElapsedTime(&t.k2l_ms, ev_[6], ev_[7]));
-        HIP_OK(hipEventElapsedTime(&t.k2w_ms, ev_[7], ev_[2]));
+        // (overlapping intervals: k2seq beside k2a; k2l = the longer of its two launches, k2w beside them, both from the end of K2a)
+        HIP_OK(hipEventElapsedTime(&t.k2seq_ms, ev_[1], join_[2]));
+        HIP_OK(hipEventElapsedTime(&t.k2a_ms, ev_[1], ev_[6]));
+        float l6 = 0, l8 = 0;
+        HIP_OK(hipEventElapsedTime(&l6, ev_[6], ev_[7]));
+        HIP_OK(hipEventElapsedTime(&l8, ev_[6], join_[0]));
+        t.k2l_ms = std::max(l6, l8);
+        HIP_OK(hipEventElapsedTime(&t.k2w_ms, ev_[6], join_[1]));
+        HIP_OK(hipEventElapsedTime(&t.k2win_ms, ev_[6], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));
         HIP_OK(hipEventElapsedTime(&t.total_ms, ev_[0], ev_[4]));
         last_slots_ = slots;

@@ -2648,7 +2648,7 @@ void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
 }
 
 template <int STAGE>
-static void launch_k2l(const DeviceBatch& d, hipStream_t stream) {
+static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide) {
     // one wave per tile of 64 windows: a wave that walked several tiles would wait for its own result stores to drain before the
     // next tile's loads return (loads and stores share the in-order vmcnt counter)
     const uint32_t n_small = d.n_lane_small, n_wide = d.n_lane_all - d.n_lane_small;
@@ -2656,23 +2656,23 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream) {
     static const bool persistent = std::getenv("MP_K2L_PERSISTENT") != nullptr;   // experiments: a fixed grid that walks the tiles
     if (n_small) {
         const uint32_t tiles = (n_small + 63) / 64, waves = min(32u, 163840u / lds_small);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_SMALL_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream, d, 0u, n_small);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_SMALL_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_small, d, 0u, n_small);
         HIP_CHECK_LAUNCH();
     }
     if (n_wide) {
         const uint32_t tiles = (n_wide + 63) / 64, waves = min(32u, 163840u / lds_wide);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream, d, n_small, n_wide);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
         HIP_CHECK_LAUNCH();
     }
 }
-void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream) {
+void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide) {
     if (!d.lane_on) return;
     static const int stage = [] { const char* e = std::getenv("MP_K2L_STAGE"); return e ? std::atoi(e) : 256; }();   // experiments
     switch (stage) {
-        case 0: launch_k2l<0>(d, stream); break;
-        case 128: launch_k2l<128>(d, stream); break;
-        case 384: launch_k2l<384>(d, stream); break;
-        default: launch_k2l<256>(d, stream); break;
+        case 0: launch_k2l<0>(d, stream_small, stream_wide); break;
+        case 128: launch_k2l<128>(d, stream_small, stream_wide); break;
+        case 384: launch_k2l<384>(d, stream_small, stream_wide); break;
+        default: launch_k2l<256>(d, stream_small, stream_wide); break;
     }
 }
 

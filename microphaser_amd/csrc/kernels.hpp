@@ -89,7 +89,8 @@ void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
 void launch_k2_admission(const DeviceBatch& d, hipStream_t stream);     // K2a over the ExonW part of the plan
 void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream);   // K2w, after K2a
-void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream);  // K2l, after K2a: the windows of winw
+// K2l, after K2a: the windows of winw; the <= 6-column and the 7-8-column launch are independent and may go to different streams
+void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide);
 // K3 / K3b read the number of used group slots / wanted records from the device (launch_partition_prefix first); the host only
 // passes an upper bound that sizes the fixed grid.
 void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t stream);
