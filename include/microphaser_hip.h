@@ -193,6 +193,9 @@ void mp_results_free(mp_results* r);
 typedef struct mp_peptides mp_peptides;
 int mp_build_reference(mp_ctx* ctx, const char* fasta_path, uint32_t peptide_len, mp_peptides** out);
 int mp_build_reference_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, uint32_t peptide_len, mp_peptides** out);   /* the FASTA's bytes */
+/* The same without the translated FASTA (mp_peptides_fasta is empty): the peptidome only - keys and binary -, what a pipeline that
+ * goes on to `filter` needs (a whole-exome `normal` FASTA translates into ~10^8 peptide records of text nobody reads). */
+int mp_peptidome_from_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, uint32_t peptide_len, mp_peptides** out);
 const char* mp_peptides_fasta(const mp_peptides* p, size_t* len);     /* stdout of build_reference            */
 const char* mp_peptides_binary(const mp_peptides* p, size_t* len);    /* --output: bincode HashSet<Vec<u8>>   */
 const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n);    /* sorted distinct keys (5 bits/residue): the unit
@@ -212,11 +215,14 @@ int mp_peptides_union(mp_ctx* ctx, const uint64_t* const* keys, const uint64_t* 
  * post-stop peptides, remove those present in the reference peptidome (bincode HashSet<Vec<u8>> from build_reference)
  * and annotate the rest with the maximum-likelihood frequency and the 95 % credible interval of their variant region.
  * Translation, peptidome membership and the per-region statistics run on the GPU. peptide_len <= 12.
- * mp_filter reads the two files; mp_filter_buffers takes their bytes. */
+ * mp_filter reads the two files; mp_filter_buffers takes their bytes (read in place); mp_filter_peptides takes the peptidome as the
+ * handle build_reference / mp_peptides_union returned (its sorted keys go to the GPU as they are: no bincode round trip) and
+ * filters at that peptidome's peptide length. */
 typedef struct mp_filtered mp_filtered;
 int mp_filter(mp_ctx* ctx, const char* tsv_path, const char* reference_binary_path, uint32_t peptide_len, mp_filtered** out);
 int mp_filter_buffers(mp_ctx* ctx, const char* tsv, size_t tsv_len, const char* reference_binary, size_t reference_len,
                       uint32_t peptide_len, mp_filtered** out);
+int mp_filter_peptides(mp_ctx* ctx, const char* tsv, size_t tsv_len, const mp_peptides* reference, mp_filtered** out);
 const char* mp_filtered_fasta(const mp_filtered* f, size_t* len);          /* stdout: kept tumor peptides           */
 const char* mp_filtered_normal_fasta(const mp_filtered* f, size_t* len);   /* --normal-output                       */
 const char* mp_filtered_tsv(const mp_filtered* f, size_t* len);            /* --tsv-output (header always present)  */

@@ -185,6 +185,7 @@ def lib():
         "mp_results_free": (None, [vp]),
         "mp_build_reference": (i32, [vp, cp, u32, pp]),
         "mp_build_reference_buffer": (i32, [vp, cp, ctypes.c_size_t, u32, pp]),
+        "mp_peptidome_from_buffer": (i32, [vp, cp, ctypes.c_size_t, u32, pp]),
         "mp_peptides_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_peptides_binary": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_peptides_keys": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
@@ -192,6 +193,7 @@ def lib():
         "mp_peptides_free": (None, [vp]),
         "mp_filter": (i32, [vp, cp, cp, u32, pp]),
         "mp_filter_buffers": (i32, [vp, cp, ctypes.c_size_t, cp, ctypes.c_size_t, u32, pp]),
+        "mp_filter_peptides": (i32, [vp, cp, ctypes.c_size_t, vp, pp]),
         "mp_filtered_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_filtered_normal_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
         "mp_filtered_tsv": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
@@ -214,10 +216,10 @@ C_ABI_SYMBOLS = [
     "mp_batch_results", "mp_batch_free", "mp_phase_dataset", "mp_results_fasta", "mp_results_normal_fasta",
     "mp_results_tsv", "mp_results_windows", "mp_results_free",
     "mp_build_reference", "mp_peptides_fasta", "mp_peptides_binary", "mp_peptides_keys", "mp_peptides_count", "mp_peptides_free",
-    "mp_filter", "mp_filter_buffers", "mp_filtered_fasta", "mp_filtered_normal_fasta", "mp_filtered_tsv", "mp_filtered_removed_tsv",
+    "mp_filter", "mp_filter_buffers", "mp_filter_peptides", "mp_filtered_fasta", "mp_filtered_normal_fasta", "mp_filtered_tsv", "mp_filtered_removed_tsv",
     "mp_filtered_removed_fasta", "mp_filtered_count", "mp_filtered_free",
     "mp_synth_gene_costs", "mp_dataset_from_arrays", "mp_dataset_to_arrays", "mp_gene_batch_free", "mp_dataset_gene_costs",
-    "mp_batch_create_genes", "mp_results_gene_offsets", "mp_translate", "mp_peptides_union", "mp_build_reference_buffer",
+    "mp_batch_create_genes", "mp_results_gene_offsets", "mp_translate", "mp_peptides_union", "mp_build_reference_buffer", "mp_peptidome_from_buffer",
 ]
 
 
@@ -258,6 +260,12 @@ class Context:
                                           int(unsupported_allele_warning_only), ctypes.byref(h)))
         return Dataset(self, h)
 
+    def peptidome(self, fasta_bytes, peptide_len=9, lazy=True):
+        """The peptidome of a nucleotide FASTA (bytes) without the translated FASTA text: Peptides with keys_np (and binary on demand)."""
+        h = ctypes.c_void_p()
+        self._check(lib().mp_peptidome_from_buffer(self._h, fasta_bytes, len(fasta_bytes), peptide_len, ctypes.byref(h)))
+        return Peptides(h, with_binary=not lazy)
+
     def build_reference(self, fasta_path, peptide_len=9):
         """`microphaser build_reference`: translation + peptide de-duplication on the GPU."""
         h = ctypes.c_void_p()
@@ -268,9 +276,13 @@ class Context:
         return Peptides(h)
 
     def filter(self, tsv, reference_binary, peptide_len=9):
-        """`microphaser filter`: `tsv` / `reference_binary` are file paths (str) or the files' bytes."""
+        """`microphaser filter`: `tsv` / `reference_binary` are file paths (str) or the files' bytes; `reference_binary` may also be
+        the Peptides object of build_reference / peptides_union (filters at that peptidome's peptide length)."""
         h = ctypes.c_void_p()
-        if isinstance(tsv, bytes) and isinstance(reference_binary, bytes):
+        if isinstance(reference_binary, Peptides):
+            assert isinstance(tsv, bytes) and reference_binary._h
+            self._check(lib().mp_filter_peptides(self._h, tsv, len(tsv), reference_binary._h, ctypes.byref(h)))
+        elif isinstance(tsv, bytes) and isinstance(reference_binary, bytes):
             self._check(lib().mp_filter_buffers(self._h, tsv, len(tsv), reference_binary, len(reference_binary), peptide_len, ctypes.byref(h)))
         else:
             self._check(lib().mp_filter(self._h, tsv.encode(), reference_binary.encode(), peptide_len, ctypes.byref(h)))
@@ -320,7 +332,7 @@ class Context:
         counts = (ctypes.c_uint64 * max(1, len(arrs)))(*[a.size for a in arrs])
         h = ctypes.c_void_p()
         self._check(lib().mp_peptides_union(self._h, ptrs, counts, len(arrs), peptide_len, ctypes.byref(h)))
-        return Peptides(h)
+        return Peptides(h, with_binary=False)     # .binary is encoded when somebody asks for it
 
     def synth_gene_costs(self, seed, n_transcripts, depth=30.0, var_spacing=5.4, read_len=0):
         """Work estimate per gene (CDS nt + one read length per exon, i.e. ~ reads and windows) of the gene_streams exome, without generating it."""
@@ -335,28 +347,49 @@ def _bytes_at(p, n):
 
 
 class Peptides:
-    """Result of `build_reference`: translated FASTA, bincode peptide set, and the sorted distinct u64 keys."""
+    """Result of `build_reference`: translated FASTA, the sorted distinct u64 keys, and (on demand) the bincode peptide set.
+    The library handle lives as long as the object, so that `Context.filter` can take the peptidome without a bincode round trip."""
 
-    def __init__(self, h):
+    def __init__(self, h, with_binary=True):
         L = lib()
+        self._h = h
         n = ctypes.c_size_t()
         p = L.mp_peptides_fasta(h, ctypes.byref(n))
         self.fasta = _bytes_at(p, n.value)
-        p = L.mp_peptides_binary(h, ctypes.byref(n))
-        self.binary = _bytes_at(p, n.value)
+        self._binary = None
         p = L.mp_peptides_keys(h, ctypes.byref(n))
         import numpy as np
         # the keys as a numpy array (a whole-exome peptidome holds ~10^7 of them); `.keys` gives the same as a Python list on demand
         self.keys_np = np.frombuffer((ctypes.c_char * (8 * n.value)).from_address(p), dtype=np.uint64).copy() if n.value else np.zeros(0, dtype=np.uint64)
         self._keys = None
         self.count = L.mp_peptides_count(h)
-        L.mp_peptides_free(h)
+        if with_binary:
+            self.binary
+
+    @property
+    def binary(self):
+        if self._binary is None:
+            n = ctypes.c_size_t()
+            p = lib().mp_peptides_binary(self._h, ctypes.byref(n))
+            self._binary = _bytes_at(p, n.value)
+        return self._binary
 
     @property
     def keys(self):
         if self._keys is None:
             self._keys = self.keys_np.tolist()
         return self._keys
+
+    def close(self):
+        if self._h:
+            lib().mp_peptides_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Filtered:

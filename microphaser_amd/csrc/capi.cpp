@@ -300,8 +300,21 @@ int mp_build_reference_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, u
         *out = p.release();
     });
 }
+int mp_peptidome_from_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, uint32_t peptide_len, mp_peptides** out) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        std::unique_ptr<mp_peptides> p(new mp_peptides());
+        build_reference_device(dev.device(), std::string(fasta_text, len), peptide_len, p->res, false);
+        *out = p.release();   // (the bincode image is built on demand: mp_peptides_binary)
+    });
+}
 const char* mp_peptides_fasta(const mp_peptides* p, size_t* len) { if (len) *len = p->res.fasta.size(); return p->res.fasta.data(); }
-const char* mp_peptides_binary(const mp_peptides* p, size_t* len) { if (len) *len = p->bin.size(); return p->bin.data(); }
+const char* mp_peptides_binary(const mp_peptides* p, size_t* len) {
+    mp_peptides* q = const_cast<mp_peptides*>(p);
+    if (q->bin.empty() && !q->res.keys.empty()) q->bin = q->res.binary();   // built on first use
+    if (len) *len = q->bin.size();
+    return q->bin.data();
+}
 const uint64_t* mp_peptides_keys(const mp_peptides* p, size_t* n) { if (n) *n = p->res.keys.size(); return p->res.keys.data(); }
 uint64_t mp_peptides_count(const mp_peptides* p) { return p->res.n_peptides; }
 void mp_peptides_free(mp_peptides* p) { delete p; }
@@ -311,7 +324,16 @@ int mp_filter_buffers(mp_ctx* ctx, const char* tsv, size_t tsv_len, const char* 
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         std::unique_ptr<mp_filtered> f(new mp_filtered());
-        filter_device(dev.device(), std::string(reference_binary, reference_len), std::string(tsv, tsv_len), peptide_len, f->res);
+        filter_device(dev.device(), std::string_view(reference_binary, reference_len), nullptr, std::string_view(tsv, tsv_len), peptide_len, f->res);
+        *out = f.release();
+    });
+}
+int mp_filter_peptides(mp_ctx* ctx, const char* tsv, size_t tsv_len, const mp_peptides* reference, mp_filtered** out) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        if (!reference) throw Error("mp_filter_peptides: no peptidome");
+        std::unique_ptr<mp_filtered> f(new mp_filtered());
+        filter_device(dev.device(), std::string_view(), &reference->res.keys, std::string_view(tsv, tsv_len), reference->res.peptide_len, f->res);
         *out = f.release();
     });
 }

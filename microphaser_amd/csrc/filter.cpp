@@ -2,14 +2,24 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <charconv>
+#include <deque>
+#include <exception>
 #include <limits>
 #include <map>
 #include <set>
+#include <string_view>
+#include <thread>
 #include <tuple>
 #include <vector>
 
+#include "batch.hpp"
 #include "kernels_filter.hpp"
 #include "kernels_pep.hpp"
 #include "pep.hpp"
@@ -22,53 +32,155 @@ namespace mp {
 
 namespace {
 
-// csv::ReaderBuilder::new().delimiter(b'\t') with default quoting: records of fields
-std::vector<std::vector<std::string>> parse_tsv(const std::string& text) {
-    std::vector<std::vector<std::string>> rows;
-    std::vector<std::string> row;
-    std::string field;
-    bool quoted = false, started = false;
-    auto end_record = [&] {
-        if (started || !field.empty()) { row.push_back(field); rows.push_back(row); }
-        row.clear(); field.clear(); started = false;
-    };
-    for (size_t i = 0; i < text.size(); i++) {
-        const char c = text[i];
-        if (quoted) {
-            if (c != '"') field.push_back(c);
-            else if (i + 1 < text.size() && text[i + 1] == '"') { field.push_back('"'); i++; }
-            else quoted = false;
-        } else if (c == '"' && field.empty()) { quoted = true; started = true; }
-        else if (c == '\t') { row.push_back(field); field.clear(); started = true; }
-        else if (c == '\n') end_record();
-        else if (c == '\r') { if (i + 1 < text.size() && text[i + 1] == '\n') i++; end_record(); }
-        else { field.push_back(c); started = true; }
-    }
-    end_record();
-    return rows;
-}
-uint64_t field_u64(const std::string& s, const char* name) {
-    if (s.empty() || s.find_first_not_of("0123456789") != std::string::npos)
+// One row of info.tsv (IDRecord, src/common.rs:350-373): text fields as views into the TSV buffer (or, for a quoted field, into the
+// arena that holds its unescaped form), numbers parsed.
+struct Row {
+    std::string_view id, transcript, gene_id, gene_name, chrom, strand, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
+        germline_aa_change, normal_sequence, mutant_sequence;
+    uint64_t offset = 0, frame = 0;
+    double freq = 0;
+    uint32_t depth = 0, nvar = 0, nsomatic = 0, nvariant_sites = 0, nsomvariant_sites = 0;
+};
+
+uint64_t field_u64(std::string_view s, const char* name) {
+    uint64_t v = 0;
+    const auto r = std::from_chars(s.data(), s.data() + s.size(), v);
+    if (s.empty() || r.ptr != s.data() + s.size() || r.ec == std::errc::invalid_argument)
         throw Error(std::string("CSV deserialize error: field ") + name + ": invalid digit found in string");
-    return std::strtoull(s.c_str(), nullptr, 10);
+    if (r.ec == std::errc::result_out_of_range)
+        throw Error(std::string("CSV deserialize error: field ") + name + ": number too large to fit in target type");
+    return v;
 }
-IDRecord row_from_fields(const std::vector<std::string>& f) {  // serde positional deserialize of IDRecord (src/common.rs:350-373)
-    if (f.size() != 21) throw Error("CSV deserialize error: found record with " + std::to_string(f.size()) + " fields, but expected 21");
-    IDRecord r;
+uint32_t field_u32(std::string_view s, const char* name) {
+    const uint64_t v = field_u64(s, name);
+    if (v > 0xFFFFFFFFull) throw Error(std::string("CSV deserialize error: field ") + name + ": number too large to fit in target type");
+    return uint32_t(v);
+}
+double field_f64(std::string_view s, const char* name) {
+    char buf[64];
+    std::string big;
+    const char* z = buf;
+    if (s.size() < sizeof buf) { std::memcpy(buf, s.data(), s.size()); buf[s.size()] = 0; }
+    else { big.assign(s); z = big.c_str(); }
+    char* e = nullptr;
+    const double v = std::strtod(z, &e);
+    if (s.empty() || *e) throw Error(std::string("CSV deserialize error: field ") + name + ": invalid float literal");
+    return v;
+}
+void row_from_fields(const std::string_view* f, size_t n, Row& r) {   // serde positional deserialize of IDRecord
+    if (n != 21) throw Error("CSV deserialize error: found record with " + std::to_string(n) + " fields, but expected 21");
     r.id = f[0]; r.transcript = f[1]; r.gene_id = f[2]; r.gene_name = f[3]; r.chrom = f[4];
     r.offset = field_u64(f[5], "offset");
     r.frame = field_u64(f[6], "frame");
-    char* e = nullptr;
-    r.freq = std::strtod(f[7].c_str(), &e);
-    if (f[7].empty() || *e) throw Error("CSV deserialize error: field freq: invalid float literal");
-    r.depth = uint32_t(field_u64(f[8], "depth"));
-    r.nvar = uint32_t(field_u64(f[9], "nvar"));
-    r.nsomatic = uint32_t(field_u64(f[10], "nsomatic"));
-    r.nvariant_sites = uint32_t(field_u64(f[11], "nvariant_sites"));
-    r.nsomvariant_sites = uint32_t(field_u64(f[12], "nsomvariant_sites"));
+    r.freq = field_f64(f[7], "freq");
+    r.depth = field_u32(f[8], "depth");
+    r.nvar = field_u32(f[9], "nvar");
+    r.nsomatic = field_u32(f[10], "nsomatic");
+    r.nvariant_sites = field_u32(f[11], "nvariant_sites");
+    r.nsomvariant_sites = field_u32(f[12], "nsomvariant_sites");
     r.strand = f[13]; r.variant_sites = f[14]; r.somatic_positions = f[15]; r.somatic_aa_change = f[16];
     r.germline_positions = f[17]; r.germline_aa_change = f[18]; r.normal_sequence = f[19]; r.mutant_sequence = f[20];
-    return r;
+}
+
+// csv::ReaderBuilder::new().delimiter(b'\t') with default quoting over [p, end): every record after the first `skip` ones becomes a Row.
+// Unquoted fields (all of them in what `somatic` writes, unless a value holds a tab, a quote or a line break) are byte ranges of the
+// buffer; a field that starts with a quote is unescaped into `arena` ("" is a quote; the closing quote ends the quoting, further bytes
+// up to the delimiter are appended).
+void parse_rows(const char* p, const char* const end, size_t skip, std::vector<Row>& rows, std::deque<std::string>& arena) {
+    std::vector<std::string_view> rec;
+    rec.reserve(32);
+    bool started = false;        // the current record holds at least one field or delimiter
+    std::string_view field;
+    auto end_record = [&]() {
+        if (started || !field.empty()) {
+            rec.push_back(field);
+            if (skip) skip--;
+            else { rows.emplace_back(); row_from_fields(rec.data(), rec.size(), rows.back()); }
+            rec.clear();
+        }
+        field = std::string_view();
+        started = false;
+    };
+    while (p < end) {
+        if (*p == '"') {
+            started = true;
+            p++;
+            std::string text;
+            bool quoted = true;
+            while (p < end) {
+                const char c = *p;
+                if (quoted) {
+                    if (c != '"') { text.push_back(c); p++; }
+                    else if (p + 1 < end && p[1] == '"') { text.push_back('"'); p += 2; }
+                    else { quoted = false; p++; }
+                } else if (c == '\t' || c == '\n' || c == '\r') break;
+                else { text.push_back(c); p++; }
+            }
+            arena.push_back(std::move(text));
+            field = arena.back();
+        } else {
+            const char* q = p;
+            while (q < end && *q != '\t' && *q != '\n' && *q != '\r') q++;
+            if (q > p) { field = std::string_view(p, size_t(q - p)); started = true; }
+            p = q;
+        }
+        if (p >= end) break;
+        if (*p == '\t') { rec.push_back(field); field = std::string_view(); started = true; p++; }
+        else if (*p == '\n') { end_record(); p++; }
+        else { if (p + 1 < end && p[1] == '\n') p++; end_record(); p++; }   // '\r' or "\r\n"
+    }
+    end_record();
+}
+
+// Threads of the host legs, in order: the error of the earliest part is the one reported (what a sequential pass would have hit first).
+template <class F> void run_parts(size_t n, F f) {
+    std::vector<std::exception_ptr> errors(n);
+    std::vector<std::thread> th;
+    auto guarded = [&](size_t t) { try { f(t); } catch (...) { errors[t] = std::current_exception(); } };
+    for (size_t t = 1; t < n; t++) th.emplace_back(guarded, t);
+    guarded(0);
+    for (auto& x : th) x.join();
+    for (auto& e : errors) if (e) std::rethrow_exception(e);
+}
+
+// All rows of the TSV (first record = header). Without a quote anywhere in the text no field spans lines, so the text is cut at line
+// breaks and the parts are parsed by all host threads; rows stay in file order.
+void parse_tsv(std::string_view text, std::vector<Row>& rows, std::deque<std::string>& arena) {
+    const char* const b = text.data();
+    const char* const e = b + text.size();
+    size_t parts = std::min<size_t>(host_threads(), text.size() / (4u << 20) + 1);
+    // part 0 must hold the header (the first record that holds anything): a text that opens with a blank line is parsed in one piece
+    if (parts > 1 && (*b == '\n' || *b == '\r' || std::memchr(b, '"', text.size()) != nullptr)) parts = 1;
+    if (parts <= 1) {
+        size_t nl = 0;
+        for (const char* q = b; (q = static_cast<const char*>(std::memchr(q, '\n', size_t(e - q)))) != nullptr; q++) nl++;
+        rows.reserve(nl + 1);
+        parse_rows(b, e, 1, rows, arena);
+        return;
+    }
+    std::vector<const char*> cut(parts + 1, e);
+    cut[0] = b;
+    for (size_t t = 1; t < parts; t++) {
+        const char* q = b + text.size() / parts * t;
+        if (q < cut[t - 1]) q = cut[t - 1];
+        const char* nl = static_cast<const char*>(std::memchr(q, '\n', size_t(e - q)));
+        cut[t] = nl ? nl + 1 : e;
+    }
+    std::vector<std::vector<Row>> part_rows(parts);
+    std::vector<std::deque<std::string>> part_arena(parts);   // stays empty: no quotes
+    run_parts(parts, [&](size_t t) {
+        size_t nl = 0;
+        for (const char* q = cut[t]; (q = static_cast<const char*>(std::memchr(q, '\n', size_t(cut[t + 1] - q)))) != nullptr; q++) nl++;
+        part_rows[t].reserve(nl + 1);
+        parse_rows(cut[t], cut[t + 1], t == 0 ? 1 : 0, part_rows[t], part_arena[t]);
+    });
+    (void)arena;
+    size_t total = 0;
+    for (auto& v : part_rows) total += v.size();
+    rows.resize(total);
+    std::vector<size_t> at(parts + 1, 0);
+    for (size_t t = 0; t < parts; t++) at[t + 1] = at[t] + part_rows[t].size();
+    run_parts(parts, [&](size_t t) { std::copy(part_rows[t].begin(), part_rows[t].end(), rows.begin() + ptrdiff_t(at[t])); });
 }
 
 // FilteredRecord::FIELD_NAMES_AS_ARRAY (src/peptides.rs:21-47)
@@ -77,22 +189,66 @@ const char* const FILTERED_HEADER =
     "strand\tvariant_sites\tsomatic_positions\tsomatic_aa_change\tgermline_positions\tgermline_aa_change\tnormal_sequence\tmutant_sequence\t"
     "normal_peptide\ttumor_peptide\n";
 
-void write_filtered_record(std::string& t, const IDRecord& r, double freq, const std::string& id, const char* ci, const std::string& normal_pep,
-                           const std::string& tumor_pep) {
-    auto S = [&](const std::string& f) { tsv_field(t, f); t.push_back('\t'); };
-    auto U = [&](uint64_t v) { t += std::to_string(v); t.push_back('\t'); };
+// csv crate, QuoteStyle::Necessary with delimiter '\t' (= tsv_field of util.hpp on a view)
+void put_field(std::string& out, std::string_view f) {
+    bool need = false;
+    for (char c : f)
+        if (c == '\t' || c == '"' || c == '\n' || c == '\r') { need = true; break; }
+    if (!need) { out.append(f.data(), f.size()); return; }
+    out.push_back('"');
+    for (char c : f) {
+        if (c == '"') out.push_back('"');
+        out.push_back(c);
+    }
+    out.push_back('"');
+}
+void put_u64(std::string& out, uint64_t v) {
+    char buf[24];
+    const auto r = std::to_chars(buf, buf + sizeof buf, v);
+    out.append(buf, size_t(r.ptr - buf));
+}
+void put_fasta(std::string& out, std::string_view id, const uint8_t* seq, size_t n) {   // bio::io::fasta::Writer::write(id, None, seq)
+    out.push_back('>');
+    out.append(id.data(), id.size());
+    out.push_back('\n');
+    out.append(reinterpret_cast<const char*>(seq), n);
+    out.push_back('\n');
+}
+void write_filtered_record(std::string& t, const Row& r, double freq, std::string_view id, const char* ci, std::string_view normal_pep,
+                           std::string_view tumor_pep) {
+    auto S = [&](std::string_view f) { put_field(t, f); t.push_back('\t'); };
+    auto U = [&](uint64_t v) { put_u64(t, v); t.push_back('\t'); };
     S(id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom); U(r.offset); U(r.frame);
     t += fmt_f64(freq); t.push_back('\t');
     S(ci); U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
     S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change); S(r.germline_positions); S(r.germline_aa_change);
     S(r.normal_sequence); S(r.mutant_sequence); S(normal_pep);
-    tsv_field(t, tumor_pep);
+    put_field(t, tumor_pep);
     t.push_back('\n');
 }
 
-template <class T>
-T* to_device(const std::vector<T>& v, hipStream_t stream, std::vector<void*>& owned, size_t pad = 0) {
+// The peptides already seen in the current (transcript, somatic_positions, germline_positions) run (seen_peptides, :262-400): a handful
+// per run, so a flat list; a run that grows past it gets an ordered set.
+struct SeenPeptides {
+    std::vector<std::string_view> few;
+    std::set<std::string_view> many;
+    bool contains(std::string_view p) const {
+        if (!many.empty()) return many.count(p) != 0;
+        for (std::string_view q : few) if (q == p) return true;
+        return false;
+    }
+    void insert(std::string_view p) {
+        if (!many.empty()) { many.insert(p); return; }
+        few.push_back(p);
+        if (few.size() > 48) { many.insert(few.begin(), few.end()); few.clear(); }
+    }
+    void clear() { few.clear(); many.clear(); }
+};
+
+template <class V>
+typename V::value_type* to_device(const V& v, hipStream_t stream, std::vector<void*>& owned, size_t pad = 0) {
     void* p = nullptr;
+    using T = typename V::value_type;
     HIP_OK(hipMalloc(&p, v.size() * sizeof(T) + pad + 16));
     owned.push_back(p);
     if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
@@ -101,17 +257,27 @@ T* to_device(const std::vector<T>& v, hipStream_t stream, std::vector<void*>& ow
 
 }  // namespace
 
-void filter_device(int device, const std::string& reference_binary, const std::string& tsv_text, uint32_t L, FilterResult& out) {
+void filter_device(int device, std::string_view reference_binary, const std::vector<uint64_t>* reference_keys, std::string_view tsv_text,
+                   uint32_t L, FilterResult& out) {
     if (L == 0 || L > 12) throw Error("peptide length must be 1..12 for the device peptidome (5-bit residue keys in a u64)");
     out = FilterResult();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw Error("no HIP device available: `filter` translates and scores on the GPU, there is no CPU fallback");
     HIP_OK(hipSetDevice(device));
+    const bool dbg = std::getenv("MP_DEBUG") != nullptr;   // wall time of the phases on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (dbg) std::fprintf(stderr, "[mp]   filter: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    const size_t threads = host_threads();
 
-    // ---- reference peptidome: bincode v1 HashSet<Vec<u8>> (deserialize_from(...).unwrap(), :242) -> keys of the length-L members
+    // ---- reference peptidome: bincode v1 HashSet<Vec<u8>> (deserialize_from(...).unwrap(), :242) -> keys of the length-L members;
+    //      or the sorted distinct keys themselves (a peptidome that never left the library)
     std::vector<uint64_t> ref_keys;
-    {
+    if (!reference_keys) {
         size_t p = 0;
         auto u64 = [&]() {
             if (p + 8 > reference_binary.size())
@@ -129,35 +295,55 @@ void filter_device(int device, const std::string& reference_binary, const std::s
             if (l == L) {  // only a member of the same length can equal a tumor peptide
                 bool letters = true;
                 for (uint64_t k = 0; k < l; k++) { const char c = reference_binary[p + k]; letters &= c >= 'A' && c <= 'Z'; }
-                if (letters) ref_keys.push_back(peptide_to_key(reference_binary.substr(p, l)));
+                if (letters) {
+                    uint64_t key = 0;
+                    for (uint64_t k = 0; k < l; k++) key = (key << 5) | uint64_t((reference_binary[p + k] - 'A') & 31);   // = peptide_to_key
+                    ref_keys.push_back(key);
+                }
             }
             p += l;
         }
     }
+    lap("reference set decoded");
 
     // ---- rows and their two nucleotide windows
-    const auto fields = parse_tsv(tsv_text);
-    std::vector<IDRecord> rows;
-    for (size_t i = 1; i < fields.size(); i++) rows.push_back(row_from_fields(fields[i]));  // first record = header
+    std::vector<Row> rows;
+    std::deque<std::string> arena;
+    parse_tsv(tsv_text, rows, arena);
+    lap("tsv parsed");
     out.n_rows = rows.size();
     const size_t n_seq = rows.size() * 2;   // 2r = mutant, 2r + 1 = normal
-    std::vector<uint8_t> nt, rev(n_seq);
-    std::vector<uint64_t> nt_off(n_seq), aa_off(n_seq + 1, 0);
-    std::vector<uint32_t> nt_len(n_seq);
-    for (size_t r = 0; r < rows.size(); r++) {
-        const uint8_t rv = (!rows[r].id.empty() && rows[r].id.back() == 'F') ? 0 : 1;  // :291-294
-        const std::string* seqs[2] = {&rows[r].mutant_sequence, &rows[r].normal_sequence};
-        for (int k = 0; k < 2; k++) {
-            const size_t s = 2 * r + k;
-            if (seqs[k]->size() > 0xFFFFFFFFull) throw Error("sequence too long");
-            nt_off[s] = nt.size();
-            nt_len[s] = uint32_t(seqs[k]->size());
-            rev[s] = rv;
-            nt.insert(nt.end(), seqs[k]->begin(), seqs[k]->end());
-            aa_off[s + 1] = aa_off[s] + (seqs[k]->size() > 2 ? (seqs[k]->size() - 2 + 2) / 3 : 0);
+    PodVec<uint8_t> nt, rev(n_seq);
+    PodVec<uint64_t> nt_off(n_seq), aa_off(n_seq + 1);
+    PodVec<uint32_t> nt_len(n_seq);
+    aa_off[0] = 0;
+    {
+        uint64_t at = 0;
+        for (size_t r = 0; r < rows.size(); r++) {
+            const uint8_t rv = (!rows[r].id.empty() && rows[r].id.back() == 'F') ? 0 : 1;  // :291-294
+            const std::string_view seqs[2] = {rows[r].mutant_sequence, rows[r].normal_sequence};
+            for (int k = 0; k < 2; k++) {
+                const size_t s = 2 * r + k;
+                if (seqs[k].size() > 0xFFFFFFFFull) throw Error("sequence too long");
+                nt_off[s] = at;
+                nt_len[s] = uint32_t(seqs[k].size());
+                rev[s] = rv;
+                at += seqs[k].size();
+                aa_off[s + 1] = aa_off[s] + (seqs[k].size() > 2 ? (seqs[k].size() - 2 + 2) / 3 : 0);
+            }
         }
+        nt.resize(at);
+        advise_huge(nt.data(), nt.size());
+        const size_t parts = std::min<size_t>(threads, rows.size() / 65536 + 1);
+        run_parts(parts, [&](size_t t) {
+            for (size_t r = rows.size() * t / parts, e = rows.size() * (t + 1) / parts; r < e; r++) {
+                if (nt_len[2 * r]) std::memcpy(nt.data() + nt_off[2 * r], rows[r].mutant_sequence.data(), nt_len[2 * r]);
+                if (nt_len[2 * r + 1]) std::memcpy(nt.data() + nt_off[2 * r + 1], rows[r].normal_sequence.data(), nt_len[2 * r + 1]);
+            }
+        });
     }
     const uint64_t n_aa = aa_off[n_seq];
+    lap("windows laid out");
 
     hipStream_t stream;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -171,10 +357,13 @@ void filter_device(int device, const std::string& reference_binary, const std::s
         hipStreamDestroy(stream);
     };
     try {
-        // sorted distinct reference keys (device radix sort + unique)
+        // sorted distinct reference keys (device radix sort + unique, unless they came sorted)
         uint64_t n_ref = 0;
         uint64_t* d_ref = nullptr;
-        if (!ref_keys.empty()) {
+        if (reference_keys) {
+            n_ref = reference_keys->size();
+            if (n_ref) d_ref = to_device(*reference_keys, stream, owned);
+        } else if (!ref_keys.empty()) {
             uint64_t* d_in = to_device(ref_keys, stream, owned);
             void *d_tmp = nullptr, *d_out = nullptr;
             HIP_OK(hipMalloc(&d_tmp, ref_keys.size() * 8)); owned.push_back(d_tmp);
@@ -198,7 +387,7 @@ void filter_device(int device, const std::string& reference_binary, const std::s
         device_translate_records(d_nt, d_nt_off, d_nt_len, d_rev, d_aa_off, n_seq, L, d_ref, n_ref, static_cast<uint8_t*>(d_aa),
                                  static_cast<uint8_t*>(d_flags), static_cast<uint32_t*>(d_err), stream);
         HIP_OK(hipEventRecord(e1, stream));
-        std::vector<uint8_t> aa(n_aa), flags(n_aa);
+        PodVec<uint8_t> aa(n_aa), flags(n_aa);
         uint32_t err = 0;
         if (n_aa) {
             HIP_OK(hipMemcpyAsync(aa.data(), d_aa, n_aa, hipMemcpyDeviceToHost, stream));
@@ -207,59 +396,110 @@ void filter_device(int device, const std::string& reference_binary, const std::s
         HIP_OK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         HIP_OK(hipEventElapsedTime(&out.translate_ms, e0, e1));
+        lap("reference sort + K5 + copies");
 
         // ---- the row stream (:262-563): which (row, i) peptides survive, and the groups they are scored in
-        struct Entry { uint32_t row; uint32_t i1; uint64_t tumor_at; std::string normal_pep; uint64_t group; };
+        struct Entry { uint32_t row; uint32_t i1; uint64_t tumor_at; const uint8_t* normal_pep; uint32_t normal_len; uint64_t group; };
         std::vector<Entry> entries;                 // in output order
         std::vector<uint64_t> grp_off{0};
         std::vector<uint8_t> grp_final;
         std::vector<double> g_alt;
         std::vector<uint32_t> g_depth;
-        using Key = std::tuple<uint64_t, std::string, std::string>;
-        struct Pending { std::vector<double> alt; std::vector<uint32_t> depth; std::vector<Entry> recs; };
-        std::map<Key, Pending> pending;             // records / frequencies / depth of the current region
-        std::tuple<std::string, std::string, std::string> current{"", "", ""};
-        std::pair<std::string, std::string> region_sites{"", ""};
-        std::set<std::string> seen_peptides;
-        std::map<std::pair<std::string, uint64_t>, size_t> stop_gained;
+        entries.reserve(rows.size());
+        // records / frequencies / depth of the current region, by (frame, somatic_positions, germline_positions): the reference's BTreeMaps.
+        // A region holds a few keys; the slots keep their buffers from region to region and are put in key order when the region is flushed
+        struct Key {
+            uint64_t frame; std::string_view som, germ;
+            bool operator==(const Key& o) const { return frame == o.frame && som == o.som && germ == o.germ; }
+            bool operator<(const Key& o) const { return std::tie(frame, som, germ) < std::tie(o.frame, o.som, o.germ); }
+        };
+        struct Pending { Key key; std::vector<double> alt; std::vector<uint32_t> depth; std::vector<Entry> recs; };
+        std::vector<Pending> slots;
+        size_t n_used = 0;
+        std::map<Key, size_t> slot_index;           // only for a region with more keys than a scan should look through
+        constexpr size_t SCAN_LIMIT = 12;
+        auto find_slot = [&](const Key& k) -> Pending* {
+            if (n_used > SCAN_LIMIT) {
+                auto it = slot_index.find(k);
+                return it == slot_index.end() ? nullptr : &slots[it->second];
+            }
+            for (size_t i = 0; i < n_used; i++) if (slots[i].key == k) return &slots[i];
+            return nullptr;
+        };
+        auto add_slot = [&](const Key& k) -> Pending& {
+            if (n_used == slots.size()) slots.emplace_back();
+            Pending& p = slots[n_used];
+            p.key = k; p.alt.clear(); p.depth.clear(); p.recs.clear();
+            n_used++;
+            if (n_used == SCAN_LIMIT + 1) for (size_t i = 0; i + 1 < n_used; i++) slot_index[slots[i].key] = i;
+            if (n_used > SCAN_LIMIT) slot_index[k] = n_used - 1;
+            return p;
+        };
+        std::vector<size_t> order;
         auto flush = [&](bool final_pass) {
-            for (auto& kv : pending) {
+            order.resize(n_used);
+            for (size_t i = 0; i < n_used; i++) order[i] = i;
+            if (n_used > 1) std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return slots[a].key < slots[b].key; });
+            for (size_t i : order) {
+                Pending& p = slots[i];
                 const uint64_t g = grp_final.size();
                 grp_final.push_back(final_pass ? 1 : 0);
-                g_alt.insert(g_alt.end(), kv.second.alt.begin(), kv.second.alt.end());
-                g_depth.insert(g_depth.end(), kv.second.depth.begin(), kv.second.depth.end());
+                g_alt.insert(g_alt.end(), p.alt.begin(), p.alt.end());
+                g_depth.insert(g_depth.end(), p.depth.begin(), p.depth.end());
                 grp_off.push_back(g_alt.size());
-                for (Entry& e : kv.second.recs) { e.group = g; entries.push_back(std::move(e)); }
+                for (Entry& e : p.recs) { e.group = g; entries.push_back(e); }
             }
-            pending.clear();
+            n_used = 0;
+            slot_index.clear();
         };
+        // `current` (transcript, somatic_positions, germline_positions) and `region_sites` (transcript, variant_sites) of the reference are
+        // kept as the row that last set them; both start as tuples of empty strings
+        static const Row kEmptyRow{};
+        const Row* current = &kEmptyRow;
+        const Row* region = &kEmptyRow;
+        SeenPeptides seen_peptides;
+        // stop_gained: (transcript, frame) -> offset of the stop-gain row. Rows come in runs of one (transcript, frame), so the entry
+        // of the previous row is remembered.
+        std::map<std::pair<std::string_view, uint64_t>, size_t> stop_gained;
+        const Row* sg_row = nullptr;                // the row the remembered look-up was made for
+        size_t* sg_at = nullptr;                    // its entry (nullptr: none)
         for (size_t r = 0; r < rows.size(); r++) {
-            const IDRecord& row = rows[r];
+            const Row& row = rows[r];
             if (row.mutant_sequence.size() < 2 || (!row.normal_sequence.empty() && row.normal_sequence.size() < 2))  // `r.len() - 2` (:139)
                 throw Error("reference would panic: attempt to subtract with overflow (to_protein)");
             size_t som_pos = 0;
-            if (!row.somatic_positions.empty() && row.somatic_positions.find('|') == std::string::npos) {
-                if (row.somatic_positions.find_first_not_of("0123456789") != std::string::npos)
+            if (!row.somatic_positions.empty() && row.somatic_positions.find('|') == std::string_view::npos) {
+                uint64_t v = 0;
+                const auto pr = std::from_chars(row.somatic_positions.data(), row.somatic_positions.data() + row.somatic_positions.size(), v);
+                if (pr.ec != std::errc() || pr.ptr != row.somatic_positions.data() + row.somatic_positions.size())
                     throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (somatic_positions)");
-                som_pos = size_t(std::strtoull(row.somatic_positions.c_str(), nullptr, 10));
+                som_pos = size_t(v);
             }
             const size_t offset = size_t(row.offset);
             const uint8_t* tp = aa.data() + aa_off[2 * r];
             const size_t tlen = size_t(aa_off[2 * r + 1] - aa_off[2 * r]);
             const uint8_t* np = aa.data() + aa_off[2 * r + 1];
             const size_t nlen = size_t(aa_off[2 * r + 2] - aa_off[2 * r + 1]);
-            for (size_t k = 0; k < tlen + nlen; k++)
-                if ((k < tlen ? tp[k] : np[k - tlen]) == '?')
-                    throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (codon with a base other than A, C, G, T)");
-            const std::pair<std::string, uint64_t> check{row.transcript, row.frame};
-            auto sg = stop_gained.find(check);
-            if (sg != stop_gained.end()) {  // :304-317
-                const bool downstream = row.strand == "Forward" ? offset > sg->second : row.strand == "Reverse" ? offset < sg->second : false;
+            if (err & 1)   // some codon held a base other than A, C, G, T: find the first row it is in
+                for (size_t k = 0; k < tlen + nlen; k++)
+                    if ((k < tlen ? tp[k] : np[k - tlen]) == '?')
+                        throw Error("reference would panic: called `Result::unwrap()` on an `Err` value (codon with a base other than A, C, G, T)");
+            const bool fwd = row.strand == "Forward", rvs = row.strand == "Reverse";
+            if (!(sg_row && sg_row->frame == row.frame && sg_row->transcript == row.transcript)) {
+                auto sg = stop_gained.find({row.transcript, row.frame});
+                sg_at = sg == stop_gained.end() ? nullptr : &sg->second;
+            }
+            sg_row = &row;
+            if (sg_at) {  // :304-317
+                const bool downstream = fwd ? offset > *sg_at : rvs ? offset < *sg_at : false;
                 if (downstream) continue;
             }
             bool has_x = false;
             for (size_t k = 0; k < tlen; k++) has_x |= tp[k] == 'X';
-            if (has_x && (std::fabs(row.freq - 1.0) < std::numeric_limits<double>::epsilon() || row.frame > 0)) stop_gained[check] = offset;
+            if (has_x && (std::fabs(row.freq - 1.0) < std::numeric_limits<double>::epsilon() || row.frame > 0)) {
+                if (sg_at) *sg_at = offset;
+                else sg_at = &(stop_gained[{row.transcript, row.frame}] = offset);
+            }
             const uint8_t* tf = flags.data() + aa_off[2 * r];
             size_t i = 0;
             while (i + L <= tlen) {
@@ -268,48 +508,42 @@ void filter_device(int device, const std::string& reference_binary, const std::s
                 const size_t nl = normal_full ? L : nlen;
                 const uint8_t* npep = normal_full ? np + i : np;
                 if (nl == 0 && som_pos > 0) {  // :343-360
-                    if (row.strand == "Forward") {
+                    if (fwd) {
                         if ((i + L) * 3 + offset <= som_pos) { i += 1; continue; }
-                    } else if (row.strand == "Reverse") {
+                    } else if (rvs) {
                         if ((tlen - (i + L)) * 3 + offset > som_pos) { i += 1; continue; }
                     }
                 }
                 const size_t i0 = i;
                 i += 1;
                 if (nl == L && std::equal(tp + i0, tp + i0 + L, npep)) continue;  // self-similar (:363-365)
-                const std::string tumor_pep(reinterpret_cast<const char*>(tp + i0), L);
-                const std::tuple<std::string, std::string, std::string> cur{row.transcript, row.somatic_positions, row.germline_positions};
-                if (cur == current) {
-                    if (seen_peptides.count(tumor_pep)) continue;
+                const std::string_view tumor_pep(reinterpret_cast<const char*>(tp + i0), L);
+                if (row.transcript == current->transcript && row.somatic_positions == current->somatic_positions &&
+                    row.germline_positions == current->germline_positions) {
+                    if (seen_peptides.contains(tumor_pep)) continue;
                 } else {
-                    current = cur;
+                    current = &row;
                     seen_peptides.clear();
                 }
                 seen_peptides.insert(tumor_pep);
-                Entry e;
-                e.row = uint32_t(r);
-                e.i1 = uint32_t(i);
-                e.tumor_at = aa_off[2 * r] + i0;
-                e.normal_pep.assign(reinterpret_cast<const char*>(npep), nl);
-                e.group = 0;
+                const Entry e{uint32_t(r), uint32_t(i), aa_off[2 * r] + i0, npep, uint32_t(nl), 0};
                 const Key key{row.frame, row.somatic_positions, row.germline_positions};
                 const double alt = row.freq * double(row.depth);
-                const std::pair<std::string, std::string> current_sites{row.transcript, row.variant_sites};
-                if (current_sites != region_sites) {  // :398-541
+                if (row.transcript != region->transcript || row.variant_sites != region->variant_sites) {  // :398-541
                     flush(false);
-                    Pending& p = pending[key];
-                    p.alt = {alt}; p.depth = {row.depth}; p.recs.push_back(std::move(e));
-                    region_sites = current_sites;
+                    Pending& p = add_slot(key);
+                    p.alt.push_back(alt); p.depth.push_back(row.depth); p.recs.push_back(e);
+                    region = &row;
                 } else {
                     // entry(key).or_insert_with(|| vec![x]).push(x): a key first seen here holds its first value twice (:548-560)
-                    const bool fresh = !pending.count(key);
-                    Pending& p = pending[key];
-                    if (fresh) { p.alt.push_back(alt); p.depth.push_back(row.depth); p.recs.push_back(e); }
-                    p.alt.push_back(alt); p.depth.push_back(row.depth); p.recs.push_back(std::move(e));
+                    Pending* p = find_slot(key);
+                    if (!p) { p = &add_slot(key); p->alt.push_back(alt); p->depth.push_back(row.depth); p->recs.push_back(e); }
+                    p->alt.push_back(alt); p->depth.push_back(row.depth); p->recs.push_back(e);
                 }
             }
         }
         flush(true);
+        lap("row stream");
         out.n_peptides = entries.size();
         out.n_groups = grp_final.size();
 
@@ -336,32 +570,64 @@ void filter_device(int device, const std::string& reference_binary, const std::s
             HIP_OK(hipStreamSynchronize(stream));
             HIP_OK(hipEventElapsedTime(&out.stats_ms, e2, e3));
         }
+        lap("K6 credible intervals");
 
-        // ---- emission (:483-533, :662-706)
-        out.tsv += FILTERED_HEADER;
-        bool removed_header = false;
-        for (const Entry& e : entries) {
-            const IDRecord& row = rows[e.row];
-            const CredibleInterval& c = ci[e.group];
-            if (c.status) throw Error("reference would panic: called `Option::unwrap()` on a `None` value (partial_cmp of a NaN likelihood)");
-            char buf[64];
-            std::snprintf(buf, sizeof buf, "%.2f-%.2f", c.a, c.b);
-            const std::string id = std::to_string(e.i1) + "_" + row.id;
-            const double freq = row.depth == 0 ? 0.0 : double(c.ml) * 0.01;
-            const std::string tumor_pep(reinterpret_cast<const char*>(aa.data() + e.tumor_at), L);
-            if (flags[e.tumor_at] & 2) {
-                write_fasta(out.removed_fasta, id, aa.data() + e.tumor_at, L);
-                if (!removed_header) { out.removed_tsv += FILTERED_HEADER; removed_header = true; }
-                write_filtered_record(out.removed_tsv, row, freq, id, buf, e.normal_pep, tumor_pep);
-                out.n_removed++;
-            } else {
-                write_fasta(out.fasta, id, aa.data() + e.tumor_at, L);
-                if (!e.normal_pep.empty())
-                    write_fasta(out.normal_fasta, id, reinterpret_cast<const uint8_t*>(e.normal_pep.data()), e.normal_pep.size());
-                write_filtered_record(out.tsv, row, freq, id, buf, e.normal_pep, tumor_pep);
-                out.n_kept++;
+        // ---- emission (:483-533, :662-706): the entries in order, written by all host threads (entry ranges) and joined
+        for (const Entry& e : entries)
+            if (ci[e.group].status) throw Error("reference would panic: called `Option::unwrap()` on a `None` value (partial_cmp of a NaN likelihood)");
+        struct Streams { std::string tsv, removed_tsv, fasta, normal_fasta, removed_fasta; uint64_t kept = 0, removed = 0; };
+        const size_t parts = std::max<size_t>(1, std::min<size_t>(threads, entries.size() / 2048 + 1));
+        std::vector<Streams> part(parts);
+        run_parts(parts, [&](size_t t) {
+            Streams& o = part[t];
+            const size_t lo = entries.size() * t / parts, hi = entries.size() * (t + 1) / parts;
+            o.tsv.reserve((hi - lo) * 320);
+            std::string id;
+            for (size_t k = lo; k < hi; k++) {
+                const Entry& e = entries[k];
+                const Row& row = rows[e.row];
+                const CredibleInterval& c = ci[e.group];
+                char buf[64];
+                std::snprintf(buf, sizeof buf, "%.2f-%.2f", c.a, c.b);
+                id.clear();
+                put_u64(id, e.i1);
+                id.push_back('_');
+                id.append(row.id.data(), row.id.size());
+                const double freq = row.depth == 0 ? 0.0 : double(c.ml) * 0.01;
+                const std::string_view tumor_pep(reinterpret_cast<const char*>(aa.data() + e.tumor_at), L);
+                const std::string_view normal_pep(reinterpret_cast<const char*>(e.normal_pep), e.normal_len);
+                if (flags[e.tumor_at] & 2) {
+                    put_fasta(o.removed_fasta, id, aa.data() + e.tumor_at, L);
+                    write_filtered_record(o.removed_tsv, row, freq, id, buf, normal_pep, tumor_pep);
+                    o.removed++;
+                } else {
+                    put_fasta(o.fasta, id, aa.data() + e.tumor_at, L);
+                    if (e.normal_len) put_fasta(o.normal_fasta, id, e.normal_pep, e.normal_len);
+                    write_filtered_record(o.tsv, row, freq, id, buf, normal_pep, tumor_pep);
+                    o.kept++;
+                }
             }
-        }
+        });
+        for (const Streams& o : part) { out.n_kept += o.kept; out.n_removed += o.removed; }
+        const std::string_view header(FILTERED_HEADER);
+        auto join = [&](PodVec<char>& dst, std::string Streams::*m, bool with_header) {
+            std::vector<size_t> at(parts + 1, with_header ? header.size() : 0);
+            for (size_t t = 0; t < parts; t++) at[t + 1] = at[t] + (part[t].*m).size();
+            dst.resize(at[parts]);
+            advise_huge(dst.data(), dst.size());
+            if (with_header) std::memcpy(dst.data(), header.data(), header.size());
+            run_parts(parts, [&](size_t t) {
+                std::string& src = part[t].*m;
+                if (!src.empty()) std::memcpy(dst.data() + at[t], src.data(), src.size());
+                std::string().swap(src);
+            });
+        };
+        join(out.tsv, &Streams::tsv, true);
+        join(out.removed_tsv, &Streams::removed_tsv, out.n_removed > 0);   // its header is written with its first record
+        join(out.fasta, &Streams::fasta, false);
+        join(out.normal_fasta, &Streams::normal_fasta, false);
+        join(out.removed_fasta, &Streams::removed_fasta, false);
+        lap("emission");
     } catch (...) {
         cleanup();
         throw;

@@ -4,22 +4,27 @@
 // bookkeeping of the reference (stop-gain suppression, per-variant-region grouping, de-duplication) stays on the host.
 #pragma once
 #include <string>
+#include <string_view>
+#include <vector>
 
 #include "model.hpp"
 
 namespace mp {
 
 struct FilterResult {
-    std::string fasta;          // stdout: kept tumor peptides
-    std::string normal_fasta;   // --normal-output
-    std::string tsv;            // --tsv-output (header always present)
-    std::string removed_tsv;    // --similar-removed
-    std::string removed_fasta;  // --removed-peptides
+    PodVec<char> fasta;          // stdout: kept tumor peptides
+    PodVec<char> normal_fasta;   // --normal-output
+    PodVec<char> tsv;            // --tsv-output (header always present)
+    PodVec<char> removed_tsv;    // --similar-removed
+    PodVec<char> removed_fasta;  // --removed-peptides
     uint64_t n_rows = 0, n_peptides = 0, n_groups = 0, n_kept = 0, n_removed = 0;
     float translate_ms = 0, stats_ms = 0;
 };
 
-// reference_binary: bytes of the bincode HashSet<Vec<u8>> written by build_reference; tsv_text: info.tsv of `somatic`.
-void filter_device(int device, const std::string& reference_binary, const std::string& tsv_text, uint32_t peptide_len, FilterResult& out);
+// reference_binary: bytes of the bincode HashSet<Vec<u8>> written by build_reference - or, with reference_keys != nullptr, the
+// peptidome as sorted distinct keys of peptide_len residues (PeptideResult::keys; reference_binary is then not read);
+// tsv_text: info.tsv of `somatic`. Both buffers are read in place and must stay valid for the call.
+void filter_device(int device, std::string_view reference_binary, const std::vector<uint64_t>* reference_keys, std::string_view tsv_text,
+                   uint32_t peptide_len, FilterResult& out);
 
 }  // namespace mp

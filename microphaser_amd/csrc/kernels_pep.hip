@@ -1,9 +1,13 @@
 // K4: codon -> peptide translation and reference-peptidome keys (reference: src/peptides.rs:85-146 to_protein /
 // to_aminoacid / make_pairs, :148-186 build). One thread per peptide window; integer/byte work, HBM-bound:
 // reads 3L nucleotide bytes (neighbouring windows overlap by 3L-3, so the stream is read once through L2),
-// writes L amino-acid bytes + one u64 key. De-duplication = radix sort + unique on the keys (hipCUB/rocPRIM).
+// writes L amino-acid bytes + one u64 key. De-duplication = radix sort + unique on the keys (rocPRIM device primitives, called directly).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/functional.hpp>
 
 #include "kernels_pep.hpp"
 
@@ -57,20 +61,21 @@ void device_translate(const uint8_t* d_nt, const uint64_t* d_off, const uint8_t*
 // sort + unique of the u64 peptide keys; returns the number of distinct keys (in d_out[0..n_unique))
 uint64_t device_sort_unique(uint64_t* d_keys, uint64_t* d_tmp, uint64_t* d_out, uint64_t n, uint32_t key_bits, hipStream_t stream) {
     if (!n) return 0;
+    const size_t count = size_t(n);   // (64-bit sizes throughout: a whole-exome normal peptidome has > 2^31 / 8 windows within reach)
     size_t bytes1 = 0, bytes2 = 0;
-    HIP_OK_(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes1, d_keys, d_tmp, int(n), 0, int(key_bits), stream));
-    uint64_t* d_count = nullptr;
-    HIP_OK_(hipMalloc(&d_count, 8));
-    HIP_OK_(hipcub::DeviceSelect::Unique(nullptr, bytes2, d_tmp, d_out, d_count, int(n), stream));
-    void* d_ws = nullptr;
-    HIP_OK_(hipMalloc(&d_ws, std::max(bytes1, bytes2) + 256));
-    HIP_OK_(hipcub::DeviceRadixSort::SortKeys(d_ws, bytes1, d_keys, d_tmp, int(n), 0, int(key_bits), stream));
-    HIP_OK_(hipcub::DeviceSelect::Unique(d_ws, bytes2, d_tmp, d_out, d_count, int(n), stream));
+    HIP_OK_(rocprim::radix_sort_keys(nullptr, bytes1, d_keys, d_tmp, count, 0u, key_bits, stream));
+    HIP_OK_(rocprim::unique(nullptr, bytes2, d_tmp, d_out, static_cast<uint64_t*>(nullptr), count, rocprim::equal_to<uint64_t>(), stream));
+    const size_t ws_bytes = (std::max(bytes1, bytes2) + 255) & ~size_t(255);
+    char* d_ws = nullptr;   // one allocation: workspace + the count word behind it
+    HIP_OK_(hipMalloc(&d_ws, ws_bytes + 256));
+    uint64_t* d_count = reinterpret_cast<uint64_t*>(d_ws + ws_bytes);
     uint64_t cnt = 0;
-    HIP_OK_(hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, stream));
-    HIP_OK_(hipStreamSynchronize(stream));
-    hipFree(d_ws);
-    hipFree(d_count);
+    hipError_t e = rocprim::radix_sort_keys(d_ws, bytes1, d_keys, d_tmp, count, 0u, key_bits, stream);
+    if (e == hipSuccess) e = rocprim::unique(d_ws, bytes2, d_tmp, d_out, d_count, count, rocprim::equal_to<uint64_t>(), stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_ws);
+    HIP_OK_(e);
     return cnt;
 }
 

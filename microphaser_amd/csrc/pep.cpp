@@ -2,6 +2,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <sstream>
 
 #include "kernels_pep.hpp"
@@ -30,7 +31,7 @@ std::string PeptideResult::binary() const {
     return b;
 }
 
-void build_reference_device(int device, const std::string& fasta_text, uint32_t L, PeptideResult& out) {
+void build_reference_device(int device, const std::string& fasta_text, uint32_t L, PeptideResult& out, bool want_fasta) {
     if (L == 0 || L > 12) throw Error("peptide length must be 1..12 for the device peptidome (5-bit residue keys in a u64)");
     out = PeptideResult();
     out.peptide_len = L;
@@ -38,30 +39,39 @@ void build_reference_device(int device, const std::string& fasta_text, uint32_t 
     std::vector<uint8_t> nt;
     std::vector<uint64_t> off;
     std::vector<uint8_t> rev;
-    std::vector<std::pair<std::string, uint64_t>> recs;  // (id, number of windows)
+    std::vector<std::pair<std::string, uint64_t>> recs;  // (id, number of windows); only kept when the translated FASTA is wanted
     {
-        std::istringstream in(fasta_text);
-        std::string line, id, seq;
+        nt.reserve(fasta_text.size());
+        off.reserve(fasta_text.size() / (3 * size_t(L) + 20) + 16);
+        rev.reserve(off.capacity());
+        const char* p = fasta_text.data();
+        const char* const end = p + fasta_text.size();
+        std::string id;
         bool have = false;
+        uint64_t base = 0;
         auto flush = [&]() {
             if (!have) return;
-            uint8_t r = (!id.empty() && id.back() == 'F') ? 0 : 1;  // :161-164
-            uint64_t base = nt.size(), nwin = 0;
-            nt.insert(nt.end(), seq.begin(), seq.end());
-            for (uint64_t i = 0; i + 3ull * L <= seq.size(); i += 3) { off.push_back(base + i); rev.push_back(r); nwin++; }
-            recs.emplace_back(id, nwin);
+            const uint8_t r = (!id.empty() && id.back() == 'F') ? 0 : 1;  // :161-164
+            const uint64_t len = nt.size() - base;
+            uint64_t nwin = 0;
+            for (uint64_t i = 0; i + 3ull * L <= len; i += 3) { off.push_back(base + i); rev.push_back(r); nwin++; }
+            if (want_fasta) recs.emplace_back(id, nwin);
         };
-        while (std::getline(in, line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            if (!line.empty() && line[0] == '>') {
+        while (p < end) {
+            const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
+            const char* le = nl ? nl : end;
+            const char* lend = (le > p && le[-1] == '\r') ? le - 1 : le;
+            if (lend > p && *p == '>') {
                 flush();
-                size_t sp = line.find_first_of(" \t");
-                id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-                seq.clear();
+                const char* q = p + 1;
+                while (q < lend && *q != ' ' && *q != '\t') q++;
+                id.assign(p + 1, q);
+                base = nt.size();
                 have = true;
-            } else {
-                seq += line;
+            } else if (have) {
+                nt.insert(nt.end(), reinterpret_cast<const uint8_t*>(p), reinterpret_cast<const uint8_t*>(lend));
             }
+            p = nl ? nl + 1 : end;
         }
         flush();
     }
@@ -78,7 +88,7 @@ void build_reference_device(int device, const std::string& fasta_text, uint32_t 
     uint8_t *d_nt = nullptr, *d_rev = nullptr, *d_aa = nullptr;
     uint64_t *d_off = nullptr, *d_keys = nullptr, *d_tmp = nullptr, *d_out = nullptr;
     uint32_t* d_err = nullptr;
-    std::vector<uint8_t> aa(n * L);
+    std::vector<uint8_t> aa(want_fasta ? n * L : 0);
     if (n) {
         HIP_OK(hipMalloc(&d_nt, nt.size() + 64)); HIP_OK(hipMalloc(&d_rev, n)); HIP_OK(hipMalloc(&d_aa, n * L));
         HIP_OK(hipMalloc(&d_off, n * 8)); HIP_OK(hipMalloc(&d_keys, n * 8)); HIP_OK(hipMalloc(&d_tmp, n * 8)); HIP_OK(hipMalloc(&d_out, n * 8));
@@ -95,7 +105,7 @@ void build_reference_device(int device, const std::string& fasta_text, uint32_t 
         uint32_t err = 0;
         out.keys.resize(nu);
         HIP_OK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(aa.data(), d_aa, n * L, hipMemcpyDeviceToHost, stream));
+        if (want_fasta) HIP_OK(hipMemcpyAsync(aa.data(), d_aa, n * L, hipMemcpyDeviceToHost, stream));
         if (nu) HIP_OK(hipMemcpyAsync(out.keys.data(), d_out, nu * 8, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         HIP_OK(hipEventElapsedTime(&out.translate_ms, e0, e1));
@@ -106,13 +116,20 @@ void build_reference_device(int device, const std::string& fasta_text, uint32_t 
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
     hipStreamDestroy(stream);
     // FASTA in record order (fasta_writer.write(id, None, pepseq), :171)
-    uint64_t k = 0;
-    for (const auto& r : recs)
-        for (uint64_t w = 0; w < r.second; w++, k++) {
-            out.fasta += ">" + r.first + "\n";
-            out.fasta.append(reinterpret_cast<const char*>(aa.data() + k * L), L);
-            out.fasta += "\n";
-        }
+    if (want_fasta) {
+        size_t total = 0;
+        for (const auto& r : recs) total += size_t(r.second) * (r.first.size() + L + 3);
+        out.fasta.reserve(total);
+        uint64_t k = 0;
+        for (const auto& r : recs)
+            for (uint64_t w = 0; w < r.second; w++, k++) {
+                out.fasta.push_back('>');
+                out.fasta += r.first;
+                out.fasta.push_back('\n');
+                out.fasta.append(reinterpret_cast<const char*>(aa.data() + k * L), L);
+                out.fasta.push_back('\n');
+            }
+    }
 }
 
 }  // namespace mp

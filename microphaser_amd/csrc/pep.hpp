@@ -20,6 +20,7 @@ std::string peptide_from_key(uint64_t key, uint32_t L);
 uint64_t peptide_to_key(const std::string& pep);
 
 // Translate every 3-nt-step window of every record of a nucleotide FASTA and de-duplicate, on HIP device `device`.
-void build_reference_device(int device, const std::string& fasta_text, uint32_t peptide_len, PeptideResult& out);
+// want_fasta = false: the peptidome (keys, binary) only - what a pipeline that feeds `filter` needs; the translated FASTA stays empty.
+void build_reference_device(int device, const std::string& fasta_text, uint32_t peptide_len, PeptideResult& out, bool want_fasta = true);
 
 }  // namespace mp

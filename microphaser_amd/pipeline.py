@@ -21,7 +21,7 @@ def normal_peptidome_keys(ctx, ds, local_genes, peptide_len):
     nb = ds.batch_genes(local_genes, window_len=3 * peptide_len, mode=MODE_NORMAL)
     nb.run()
     nres = nb.results()
-    pep = ctx.build_reference(nres.fasta, peptide_len)
+    pep = ctx.peptidome(nres.fasta, peptide_len)   # keys only (no translated FASTA text)
     return pep.keys_np, nres
 
 
@@ -42,5 +42,5 @@ def config_e_rank(ctx, ds, local_genes, global_genes, peptide_len=9, dist=None, 
     if shards is None:
         return None, peptidome, None
     merged = merge_by_gene(shards)
-    filtered = ctx.filter(merged["tsv"], peptidome.binary, peptide_len) if merged["tsv"] else None
+    filtered = ctx.filter(merged["tsv"], peptidome) if merged["tsv"] else None
     return merged, peptidome, filtered

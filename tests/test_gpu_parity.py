@@ -385,6 +385,54 @@ def test_gpu_config_e_pipeline_matches_oracle(ctx, tmp_path):
     assert (f2.fasta, f2.tsv, f2.removed_tsv) == (f.fasta, f.tsv, f.removed_tsv)
 
 
+def test_gpu_filter_host_legs_threaded_quoted_and_by_handle(ctx, tmp_path, monkeypatch):
+    """`filter` on a TSV large enough for the threaded host legs (the text is cut at line breaks and parsed / written by all host
+    threads): byte-identical to the oracle's sequential filter and to the same call on one thread; the peptidome handed over as the
+    build_reference handle (no bincode round trip) gives the same streams; a TSV with quoted fields (parsed in one piece) too."""
+    import microphaser_amd as m
+    L = 9
+    ds = ctx.synth(515, 80, 30.0, 5.4, gene_streams=True)
+    nres = ds.phase(window_len=3 * L, mode=m.MODE_NORMAL)
+    pep = ctx.build_reference(nres.fasta, L)
+    sres = ds.phase(window_len=3 * L)
+    assert len(sres.tsv) > 2 * (4 << 20)                 # several parts of 4 MiB
+    info, ref_bin = tmp_path / "info.tsv", tmp_path / "reference.binary"
+    info.write_bytes(sres.tsv)
+    ref_bin.write_bytes(pep.binary)
+    r = subprocess.run([ORACLE_CLI, "filter", "-r", str(ref_bin), "-l", str(L), "-t", str(info), "-o", str(tmp_path / "o.tsv"),
+                        "-n", str(tmp_path / "o.normal.fa"), "-s", str(tmp_path / "o.removed.tsv"), "-p", str(tmp_path / "o.removed.fa")],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    want = (r.stdout, (tmp_path / "o.normal.fa").read_bytes(), (tmp_path / "o.tsv").read_bytes(), (tmp_path / "o.removed.tsv").read_bytes(),
+            (tmp_path / "o.removed.fa").read_bytes())
+    streams = lambda f: (f.fasta, f.normal_fasta, f.tsv, f.removed_tsv, f.removed_fasta)
+    f = ctx.filter(sres.tsv, pep.binary, L)
+    assert streams(f) == want and f.kept > 1000 and f.removed > 100
+    assert streams(ctx.filter(sres.tsv, pep)) == want                      # mp_filter_peptides
+    monkeypatch.setenv("MP_THREADS", "1")
+    assert streams(ctx.filter(sres.tsv, pep.binary, L)) == want
+    monkeypatch.delenv("MP_THREADS")
+    # quoted fields: gene names with a tab / a quote, written by the csv rules, read back and written again
+    lines = sres.tsv.split(b"\n")
+    for k in range(1, len(lines) - 1, 7):
+        c = lines[k].split(b"\t")
+        c[3] = b'"' + (b"na\tme" if k % 2 else b'na""me') + b'"'
+        lines[k] = b"\t".join(c)
+    quoted = b"\n".join(lines)
+    info.write_bytes(quoted)
+    r = subprocess.run([ORACLE_CLI, "filter", "-r", str(ref_bin), "-l", str(L), "-t", str(info), "-o", str(tmp_path / "q.tsv"),
+                        "-n", str(tmp_path / "q.normal.fa"), "-s", str(tmp_path / "q.removed.tsv"), "-p", str(tmp_path / "q.removed.fa")],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    fq = ctx.filter(quoted, pep.binary, L)
+    assert (fq.fasta, fq.tsv, fq.removed_tsv) == (r.stdout, (tmp_path / "q.tsv").read_bytes(), (tmp_path / "q.removed.tsv").read_bytes())
+    assert b'"na\tme"' in fq.tsv + fq.removed_tsv and b'"na""me"' in fq.tsv + fq.removed_tsv
+    # a malformed row in the middle of the file is reported the same way by every part
+    bad = sres.tsv.replace(b"\tForward\t", b"\tForward\tx\t", 1)
+    with pytest.raises(m.MicrophaserError, match="22 fields"):
+        ctx.filter(bad, pep.binary, L)
+
+
 def test_gpu_sequential_and_window_parallel_replay_agree(ctx, monkeypatch):
     """The two replay paths (K2 state machine per segment; K2a + K2w closed form per window) write identical results:
     the same exome planned with MP_SEQUENTIAL_REPLAY=1 (everything through K2) and by default (everything eligible

@@ -56,7 +56,7 @@ def main():
         res.close(); b.close()
         t_normal += time.perf_counter() - t0
         t0 = time.perf_counter()
-        pep = ctx.build_reference(fa, L)
+        pep = ctx.peptidome(fa, L)            # keys only: nobody reads the translated FASTA in this pipeline
         stats["peptide_windows"] += pep.count
         key_arrays.append(pep.keys_np)
         del fa, pep
@@ -84,7 +84,7 @@ def main():
     stats["somatic_windows"] = som_windows
     stats["somatic_tsv_rows"] = merged["tsv"].count(b"\n") - 1
     t0 = time.perf_counter()
-    f = ctx.filter(merged["tsv"], peptidome.binary, L)
+    f = ctx.filter(merged["tsv"], peptidome)        # the peptidome handle: its keys go to the GPU as they are
     t["filter_s"] = time.perf_counter() - t0
     stats.update(filter_rows=f.rows, filter_kept=f.kept, filter_removed=f.removed, filter_groups=f.groups)
     t["total_s"] = sum(v for k, v in t.items() if k != "generate_s")
