@@ -171,6 +171,10 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* stats);
 /* Copy the results back and produce the reference's three output streams (replaces the rest of
  * print_haplotypes + phase_gene: :604-880, :1345-1941, src/common.rs:376-568). */
 int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out);
+/* The same with a choice of streams (MP_STREAM_* mask): the text of a stream that is not asked for is never produced and reads as
+ * empty. `normal` feeding build_reference needs the FASTA only - its TSV is 85 % of the bytes the consumer writes. */
+enum { MP_STREAM_FASTA = 1, MP_STREAM_NORMAL_FASTA = 2, MP_STREAM_TSV = 4, MP_STREAM_ALL = 7 };
+int mp_batch_results_select(mp_ctx* ctx, mp_batch* batch, uint32_t streams, mp_results** out);
 void mp_batch_free(mp_batch* batch);
 
 /* Convenience: create + run + results for all genes (what `microphaser somatic` does). */

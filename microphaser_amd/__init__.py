@@ -18,6 +18,7 @@ CLI_PATH = os.path.join(LIB_DIR, "microphaser")
 
 MODE_SOMATIC = 0
 MODE_NORMAL = 1  # `microphaser normal` (src/normal_microphasing.rs): fasta + tsv, no normal_fasta
+STREAM_FASTA, STREAM_NORMAL_FASTA, STREAM_TSV, STREAM_ALL = 1, 2, 4, 7   # mp_batch_results_select
 
 
 def build(verbose=False):
@@ -176,6 +177,7 @@ def lib():
         "mp_batch_create": (i32, [vp, vp, i32, u64, u32, u32, pp]),
         "mp_batch_run": (i32, [vp, vp, ctypes.POINTER(RunStats)]),
         "mp_batch_results": (i32, [vp, vp, pp]),
+        "mp_batch_results_select": (i32, [vp, vp, u32, pp]),
         "mp_batch_free": (None, [vp]),
         "mp_phase_dataset": (i32, [vp, vp, i32, u64, pp]),
         "mp_results_fasta": (vp, [vp, ctypes.POINTER(ctypes.c_size_t)]),
@@ -216,7 +218,7 @@ C_ABI_SYMBOLS = [
     "mp_batch_results", "mp_batch_free", "mp_phase_dataset", "mp_results_fasta", "mp_results_normal_fasta",
     "mp_results_tsv", "mp_results_windows", "mp_results_free",
     "mp_build_reference", "mp_peptides_fasta", "mp_peptides_binary", "mp_peptides_keys", "mp_peptides_count", "mp_peptides_free",
-    "mp_filter", "mp_filter_buffers", "mp_filter_peptides", "mp_filtered_fasta", "mp_filtered_normal_fasta", "mp_filtered_tsv", "mp_filtered_removed_tsv",
+    "mp_filter", "mp_filter_buffers", "mp_filter_peptides", "mp_batch_results_select", "mp_filtered_fasta", "mp_filtered_normal_fasta", "mp_filtered_tsv", "mp_filtered_removed_tsv",
     "mp_filtered_removed_fasta", "mp_filtered_count", "mp_filtered_free",
     "mp_synth_gene_costs", "mp_dataset_from_arrays", "mp_dataset_to_arrays", "mp_gene_batch_free", "mp_dataset_gene_costs",
     "mp_batch_create_genes", "mp_results_gene_offsets", "mp_translate", "mp_peptides_union", "mp_build_reference_buffer", "mp_peptidome_from_buffer",
@@ -503,9 +505,10 @@ class Batch:
         self.ctx._check(lib().mp_batch_run(self.ctx._h, self._h, ctypes.byref(st)))
         return st
 
-    def results(self):
+    def results(self, streams=STREAM_ALL):
+        """The output streams; `streams` (STREAM_FASTA | STREAM_NORMAL_FASTA | STREAM_TSV) leaves the ones nobody reads unwritten."""
         h = ctypes.c_void_p()
-        self.ctx._check(lib().mp_batch_results(self.ctx._h, self._h, ctypes.byref(h)))
+        self.ctx._check(lib().mp_batch_results_select(self.ctx._h, self._h, streams, ctypes.byref(h)))
         return Results(h)
 
     def close(self):

@@ -243,7 +243,8 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
     });
 }
 
-int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
+int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) { return mp_batch_results_select(ctx, batch, MP_STREAM_ALL, out); }
+int mp_batch_results_select(mp_ctx* ctx, mp_batch* batch, uint32_t streams, mp_results** out) {
     PhaseTimer phase_timer("batch_results");
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
@@ -255,8 +256,8 @@ int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out) {
         if (std::getenv("MP_DEBUG"))
             std::fprintf(stderr, "[mp]   download %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count());
         std::unique_ptr<mp_results> r(new mp_results());
-        if (batch->batch.normal) consume_batch_normal(batch->batch, hr, r->out);
-        else consume_batch(batch->batch, hr, r->out);
+        if (batch->batch.normal) consume_batch_normal(batch->batch, hr, r->out, streams);
+        else consume_batch(batch->batch, hr, r->out, streams);
         *out = r.release();
     });
 }

@@ -331,17 +331,17 @@ struct ConsumerHooks {
                 if (emit) {  // :839-875
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
+                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
-                        write_fasta(out.fasta, idstr, rseq, this_window_len);
+                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq, this_window_len);
                     }
                     if (germ_len != 0) {
                         if (splice_pos == 1) {
                             if (splice_gap > germ_len) throw Error("reference would panic: slice index out of range");
-                            write_fasta(out.normal_fasta, idstr, rgerm + splice_gap, germ_len - splice_gap);
+                            if (out.streams & STREAM_NORMAL_FASTA) write_fasta(out.normal_fasta, idstr, rgerm + splice_gap, germ_len - splice_gap);
                         } else if (splice_pos == 0) {
                             if (this_window_len > germ_len) throw Error("reference would panic: slice index out of range");
-                            write_fasta(out.normal_fasta, idstr, rgerm, this_window_len);
+                            if (out.streams & STREAM_NORMAL_FASTA) write_fasta(out.normal_fasta, idstr, rgerm, this_window_len);
                         }
                     }
                     // the row is written field by field (no copy through the record)
@@ -510,10 +510,10 @@ struct ConsumerHooks {
                     out_record.id = haplotype_id(reinterpret_cast<const uint8_t*>(out_mt.data()), out_mt.size(), out_record.transcript,
                                                  std::get<0>(kv.first), out_record.strand.empty() ? '?' : out_record.strand[0]);
                     if (out_mt.size() < window_len) throw Error("reference would panic: slice index out of range");
-                    write_fasta(out.fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), size_t(window_len));
+                    if (out.streams & STREAM_FASTA) write_fasta(out.fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), size_t(window_len));
                     if (!out_wt.empty()) {
                         if (out_wt.size() < window_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.normal_fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_wt.data()), size_t(window_len));
+                        if (out.streams & STREAM_NORMAL_FASTA) write_fasta(out.normal_fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_wt.data()), size_t(window_len));
                     }
                     write_tsv_record(out, out_record);
                 }
@@ -665,10 +665,10 @@ struct NormalConsumerHooks {
                 if (!eg.is_short) {  // :629-644
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
+                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
                         if (wl > seq_len) throw Error("reference would panic: slice index out of range");
-                        write_fasta(out.fasta, idstr, rseq, size_t(wl));
+                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq, size_t(wl));
                     }
                     write_normal_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, offset, frame, freq, nrows, rec->nvar, rec->nsom, n_sites,
                                             n_som_sites, strand_s, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
@@ -745,7 +745,7 @@ struct NormalConsumerHooks {
                 NormalRecord& rec = kv.second;
                 rec.id = haplotype_id(out_seq.data(), out_seq.size(), rec.transcript, kv.first.first, rec.strand.empty() ? '?' : rec.strand[0]);
                 if (out_seq.size() < window_len) throw Error("reference would panic: slice index out of range");
-                write_fasta(out.fasta, kv.second.id, out_seq.data(), size_t(window_len));
+                if (out.streams & STREAM_FASTA) write_fasta(out.fasta, kv.second.id, out_seq.data(), size_t(window_len));
                 write_normal_tsv_record(out, kv.second);
             }
         }
@@ -753,11 +753,14 @@ struct NormalConsumerHooks {
 };
 
 void reserve_streams(SomaticOutput& p, size_t recs) {
-    p.tsv.reserve(recs * 340); p.fasta.reserve(recs * 52); p.normal_fasta.reserve(recs * 52);
+    if (p.streams & STREAM_TSV) p.tsv.reserve(recs * 340);
+    if (p.streams & STREAM_FASTA) p.fasta.reserve(recs * 52);
+    if (p.streams & STREAM_NORMAL_FASTA) p.normal_fasta.reserve(recs * 52);
     advise_huge(p.tsv.data(), p.tsv.capacity());
 }
 void reserve_streams(NormalOutput& p, size_t recs) {
-    p.tsv.reserve(recs * 320); p.fasta.reserve(recs * 56);
+    if (p.streams & STREAM_TSV) p.tsv.reserve(recs * 320);
+    if (p.streams & STREAM_FASTA) p.fasta.reserve(recs * 56);
     advise_huge(p.tsv.data(), p.tsv.capacity()); advise_huge(p.fasta.data(), p.fasta.capacity());
 }
 const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
@@ -848,12 +851,13 @@ void assemble(std::vector<Out>& parts, PhasedStreams& out, size_t nthreads) {
 }
 
 template <class Hooks, class Out>
-void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out) {
+void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out, uint32_t streams) {
     size_t nthreads = host_threads();
     const size_t ng = b.genes.size();
     if (nthreads > ng) nthreads = ng ? ng : 1;
     if (nthreads <= 1) {
         std::vector<Out> one(1);
+        one[0].streams = streams;
         consume_range<Hooks>(b, res, 0, ng, one[0]);
         assemble(one, out, 1);
         return;
@@ -875,6 +879,7 @@ void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out)
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<Out> parts(nthreads);
+    for (Out& p : parts) p.streams = streams;
     std::vector<std::string> errors(nthreads);
     std::vector<std::thread> th;
     // Reserve each range's streams up front (an estimate from the records the device produced, shared out by planned steps; pages
@@ -902,14 +907,14 @@ void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out)
 
 }  // namespace
 
-void consume_batch(const Batch& b, const HostResults& res, PhasedStreams& out) {
+void consume_batch(const Batch& b, const HostResults& res, PhasedStreams& out, uint32_t streams) {
     if (b.normal) throw Error("internal error: somatic consumer on a normal-mode batch");
-    consume_sharded<ConsumerHooks, SomaticOutput>(b, res, out);
+    consume_sharded<ConsumerHooks, SomaticOutput>(b, res, out, streams);
 }
 
-void consume_batch_normal(const Batch& b, const HostResults& res, PhasedStreams& out) {
+void consume_batch_normal(const Batch& b, const HostResults& res, PhasedStreams& out, uint32_t streams) {
     if (!b.normal) throw Error("internal error: normal consumer on a somatic-mode batch");
-    consume_sharded<NormalConsumerHooks, NormalOutput>(b, res, out);
+    consume_sharded<NormalConsumerHooks, NormalOutput>(b, res, out, streams);
 }
 
 }  // namespace mp

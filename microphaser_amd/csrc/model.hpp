@@ -200,9 +200,12 @@ struct IDRecord {
 };
 
 // The three output streams of `microphaser somatic` (stdout FASTA, --normal-output FASTA, --tsv).
-struct GeneEnds { uint64_t fasta, normal_fasta, tsv; };   // sizes of the three streams after a gene has been written
+struct GeneEnds { uint64_t fasta, normal_fasta, tsv; };
+// Which streams a caller wants (mp_batch_results_select): the text of a stream whose bit is clear is never produced.
+enum : uint32_t { STREAM_FASTA = 1, STREAM_NORMAL_FASTA = 2, STREAM_TSV = 4, STREAM_ALL = 7 };   // sizes of the three streams after a gene has been written
 struct SomaticOutput {
     std::string fasta, normal_fasta, tsv;
+    uint32_t streams = STREAM_ALL;
     bool tsv_header_written = false;
     uint64_t n_windows = 0;  // main-ORF print_haplotypes invocations (the benchmark unit)
     std::vector<GeneEnds> gene_ends;   // filled by the device consumer only (one entry per gene of its range)
@@ -219,6 +222,7 @@ struct NormalRecord {
 };
 struct NormalOutput {
     std::string fasta, tsv;
+    uint32_t streams = STREAM_ALL;
     bool tsv_header_written = false;
     uint64_t n_windows = 0;
     std::vector<GeneEnds> gene_ends;

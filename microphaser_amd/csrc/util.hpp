@@ -175,6 +175,7 @@ inline void write_tsv_fields(SomaticOutput& o, const std::string& id, const std:
                              const std::string& variant_sites, const std::string& somatic_positions, const std::string& somatic_aa_change,
                              const std::string& germline_positions, const std::string& germline_aa_change, const std::string& normal_sequence,
                              const std::string& mutant_sequence) {
+    if (!(o.streams & STREAM_TSV)) return;
     std::string& t = o.tsv;
     if (!o.tsv_header_written) { t += idrecord_header(); o.tsv_header_written = true; }
     auto S = [&](const std::string& f) { tsv_field(t, f); t.push_back('\t'); };
@@ -200,6 +201,7 @@ inline void write_normal_tsv_fields(NormalOutput& o, const std::string& id, cons
                                     uint32_t nvar, uint32_t nsomatic, uint32_t nvariant_sites, uint32_t nsomvariant_sites, const std::string& strand,
                                     const std::string& variant_sites, const std::string& somatic_positions, const std::string& somatic_aa_change,
                                     const std::string& germline_positions, const std::string& germline_aa_change, const char* peptide, size_t peptide_len) {
+    if (!(o.streams & STREAM_TSV)) return;
     std::string& t = o.tsv;
     if (!o.tsv_header_written) {
         t += "id\ttranscript\tgene_id\tgene_name\tchrom\toffset\tframe\tfreq\tdepth\tnvar\tnsomatic\tnvariant_sites\t"

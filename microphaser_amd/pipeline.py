@@ -12,7 +12,7 @@ exome whose genes are dealt to the ranks by cost.
 """
 import numpy as np
 
-from . import MODE_NORMAL, MODE_SOMATIC
+from . import MODE_NORMAL, MODE_SOMATIC, STREAM_FASTA
 from .shard import gather_shards, merge_by_gene, shard_of, union_keys
 
 
@@ -20,7 +20,7 @@ def normal_peptidome_keys(ctx, ds, local_genes, peptide_len):
     """This rank's share of the normal peptidome: `normal` on its genes, every window translated and de-duplicated on the GPU."""
     nb = ds.batch_genes(local_genes, window_len=3 * peptide_len, mode=MODE_NORMAL)
     nb.run()
-    nres = nb.results()
+    nres = nb.results(STREAM_FASTA)                # build_reference reads the FASTA only: the TSV text is not produced
     pep = ctx.peptidome(nres.fasta, peptide_len)   # keys only (no translated FASTA text)
     return pep.keys_np, nres
 

@@ -385,6 +385,21 @@ def test_gpu_config_e_pipeline_matches_oracle(ctx, tmp_path):
     assert (f2.fasta, f2.tsv, f2.removed_tsv) == (f.fasta, f.tsv, f.removed_tsv)
 
 
+def test_gpu_results_stream_selection(ctx):
+    """mp_batch_results_select: a stream that is not asked for is empty, the others are byte-identical to the full result."""
+    import microphaser_amd as m
+    ds = ctx.synth(99, 20, gene_streams=True)
+    for mode in (m.MODE_SOMATIC, m.MODE_NORMAL):
+        b = ds.batch(mode=mode)
+        b.run()
+        full = b.results()
+        fa = b.results(m.STREAM_FASTA)
+        assert fa.fasta == full.fasta and fa.tsv == b"" and fa.normal_fasta == b"" and fa.windows == full.windows and len(full.tsv) > 1000
+        tsv = b.results(m.STREAM_TSV | m.STREAM_NORMAL_FASTA)
+        assert tsv.tsv == full.tsv and tsv.normal_fasta == full.normal_fasta and tsv.fasta == b""
+        assert tsv.gene_offsets(2) == full.gene_offsets(2) and fa.gene_offsets(0) == full.gene_offsets(0)
+
+
 def test_gpu_filter_host_legs_threaded_quoted_and_by_handle(ctx, tmp_path, monkeypatch):
     """`filter` on a TSV large enough for the threaded host legs (the text is cut at line breaks and parsed / written by all host
     threads): byte-identical to the oracle's sequential filter and to the same call on one thread; the peptidome handed over as the

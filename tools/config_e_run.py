@@ -47,7 +47,7 @@ def main():
         t0 = time.perf_counter()
         b = ds.batch_genes(genes, window_len=3 * L, mode=m.MODE_NORMAL)
         st = b.run()
-        res = b.results()
+        res = b.results(m.STREAM_FASTA)       # build_reference reads the FASTA only
         fa = res.fasta
         stats["normal_windows"] += res.windows
         stats["normal_fasta_bytes"] += len(fa)
