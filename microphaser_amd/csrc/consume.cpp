@@ -20,84 +20,85 @@
 #include <thread>
 #include <tuple>
 
+#include "hostsha.hpp"
+#include "rowfmt.hpp"
 #include "util.hpp"
 
 namespace mp {
 
+#ifdef MP_PROFILE   // development build only (-DMP_PROFILE): cycle counts of the consumer's sections, printed at exit
+struct ProfAcc { uint64_t cyc[8] = {0}; uint64_t n[8] = {0}; ~ProfAcc() { static const char* nm[8] = {"walk", "print", "merge", "print.rows", "merge.update", "merge.emit", "", ""}; for (int i = 0; i < 6; i++) std::fprintf(stderr, "[prof] %-14s %10.1f ms %10llu calls\n", nm[i], double(cyc[i]) / 2.0e6 /* ~GHz-agnostic: printed as cycles/2e6 */, (unsigned long long)n[i]); } };
+static ProfAcc g_prof;
+struct ProfScope { int k; uint64_t t0; explicit ProfScope(int k_) : k(k_), t0(__builtin_ia32_rdtsc()) {} ~ProfScope() { g_prof.cyc[k] += __builtin_ia32_rdtsc() - t0; g_prof.n[k]++; } };
+#define PROF(k) ProfScope prof_scope_##k(k)
+#else
+#define PROF(k) do {} while (0)
+#endif
+
 namespace {
 
-std::vector<std::string> split_bar(const std::string& s) {
-    std::vector<std::string> out;
-    size_t a = 0;
-    for (;;) {
-        size_t b = s.find('|', a);
-        if (b == std::string::npos) { out.push_back(s.substr(a)); break; }
-        out.push_back(s.substr(a, b - a));
-        a = b + 1;
+// One '|'-separated list, read in place: item(c) for c = 0, 1, 2, ... in order (what indexing the reference's split('|') vector gives)
+struct BarList {
+    std::string_view s;
+    size_t at = 0;        // start of the current item
+    bool valid = true;    // split("") has one (empty) item
+    explicit BarList(std::string_view s_) : s(s_) {}
+    std::string_view item() const {
+        const size_t e = s.find('|', at);
+        return s.substr(at, e == std::string_view::npos ? std::string_view::npos : e - at);
     }
-    return out;
-}
-std::string join_bar(const std::vector<std::string>& v) {
-    std::string s;
-    for (size_t i = 0; i < v.size(); i++) { if (i) s += "|"; s += v[i]; }
-    return s;
+    void next() {
+        const size_t e = s.find('|', at);
+        if (e == std::string_view::npos) valid = false; else at = e + 1;
+    }
+};
+inline uint64_t leading_u64(std::string_view p) {   // strtoull of a decimal field
+    uint64_t v = 0;
+    std::from_chars(p.data(), p.data() + p.size(), v);
+    return v;
 }
 
-// IDRecord::update (reference: src/common.rs:376-526)
+// IDRecord::update (reference: src/common.rs:376-526), written into `r` (every field is set; r may hold an earlier record).
 // with_id = false leaves the id (a SHA-1 over the formatted sequence) to the caller: the splice-side merge only needs it for the
 // records it finally writes, a fraction of those it builds.
-IDRecord record_update(const IDRecord& self, const IDRecord& rec, uint64_t offset, uint64_t frame, double freq,
-                       const std::string& wt_seq, const std::string& mt_seq, uint64_t wlen, bool with_id = true) {
-    IDRecord r;
+void record_update(IDRecord& r, const IDRecord& self, const IDRecord& rec, uint64_t offset, uint64_t frame, double freq, std::string_view wt_seq,
+                   std::string_view mt_seq, uint64_t wlen, bool with_id = true) {
     if (with_id)
-        r.id = haplotype_id(reinterpret_cast<const uint8_t*>(mt_seq.data()), mt_seq.size(), self.transcript, offset,
-                            self.strand.empty() ? '?' : self.strand[0]);
-    auto num = [](const std::string& p) { return uint64_t(std::strtoull(p.c_str(), nullptr, 10)); };
-    auto at = [](const std::vector<std::string>& v, size_t c) -> const std::string& {
-        if (c >= v.size()) throw Error("reference would panic: index out of bounds (aa_change)");
-        return v[c];
-    };
+        haplotype_id_into(r.id, reinterpret_cast<const uint8_t*>(mt_seq.data()), mt_seq.size(), self.transcript, offset,
+                          self.strand.empty() ? '?' : self.strand[0]);
+    else
+        r.id.clear();
     const bool fwd = self.strand == "Forward";
-    std::vector<std::string> s_p, g_p, s_aa, g_aa;
     uint32_t nvariants = 0, nsomatic = 0;
-    {
-        auto aa = split_bar(self.somatic_aa_change);
-        size_t c = 0;
-        for (const auto& p : split_bar(self.somatic_positions)) {
+    // the positions of a list that are still inside the merged window, with their protein changes, joined by '|' (a list ends at its
+    // first empty item)
+    auto take = [&](std::string& out_p, std::string& out_aa, bool& first, const std::string& positions, const std::string& aa_changes, auto&& active,
+                    bool somatic) {
+        BarList pos(positions), aa(aa_changes);
+        for (; pos.valid; pos.next(), aa.next()) {
+            const std::string_view p = pos.item();
             if (p.empty()) break;
-            bool active = fwd ? (self.offset + offset <= num(p)) : (self.offset + wlen - offset >= num(p));
-            if (active) { s_p.push_back(p); s_aa.push_back(at(aa, c)); nsomatic++; nvariants++; }
-            c++;
+            if (!active(leading_u64(p))) continue;
+            if (!aa.valid) throw Error("reference would panic: index out of bounds (aa_change)");
+            const std::string_view a = aa.item();
+            if (!first) { out_p.push_back('|'); out_aa.push_back('|'); }
+            out_p.append(p.data(), p.size());
+            out_aa.append(a.data(), a.size());
+            first = false;
+            if (somatic) nsomatic++;
+            nvariants++;
         }
-    }
-    {
-        auto aa = split_bar(rec.somatic_aa_change);
-        size_t c = 0;
-        for (const auto& p : split_bar(rec.somatic_positions)) {
-            if (p.empty()) break;
-            bool active = fwd ? (rec.offset + offset >= num(p)) : (rec.offset + wlen - 3 - offset <= num(p));
-            if (active) { s_p.push_back(p); s_aa.push_back(at(aa, c)); nsomatic++; nvariants++; }
-            c++;
-        }
-    }
-    {
-        auto aa = split_bar(self.germline_aa_change);
-        size_t c = 0;
-        for (const auto& p : split_bar(self.germline_positions)) {
-            if (p.empty()) break;
-            if (self.offset + offset <= num(p)) { g_p.push_back(p); g_aa.push_back(at(aa, c)); nvariants++; }
-            c++;
-        }
-    }
-    {
-        auto aa = split_bar(rec.germline_aa_change);
-        size_t c = 0;
-        for (const auto& p : split_bar(rec.germline_positions)) {
-            if (p.empty()) break;
-            if (rec.offset >= num(p) - offset) { g_p.push_back(p); g_aa.push_back(at(aa, c)); nvariants++; }
-            c++;
-        }
-    }
+    };
+    r.somatic_positions.clear(); r.somatic_aa_change.clear(); r.germline_positions.clear(); r.germline_aa_change.clear();
+    bool first_s = true, first_g = true;
+    take(r.somatic_positions, r.somatic_aa_change, first_s, self.somatic_positions, self.somatic_aa_change,
+         [&](uint64_t n) { return fwd ? (self.offset + offset <= n) : (self.offset + wlen - offset >= n); }, true);
+    take(r.somatic_positions, r.somatic_aa_change, first_s, rec.somatic_positions, rec.somatic_aa_change,
+         [&](uint64_t n) { return fwd ? (rec.offset + offset >= n) : (rec.offset + wlen - 3 - offset <= n); }, true);
+    take(r.germline_positions, r.germline_aa_change, first_g, self.germline_positions, self.germline_aa_change,
+         [&](uint64_t n) { return self.offset + offset <= n; }, false);
+    take(r.germline_positions, r.germline_aa_change, first_g, rec.germline_positions, rec.germline_aa_change,
+         [&](uint64_t n) { return rec.offset >= n - offset; }, false);
     r.transcript = self.transcript; r.gene_id = self.gene_id; r.gene_name = self.gene_name; r.chrom = self.chrom;
     r.offset = fwd ? self.offset + offset : rec.offset + wlen + 3 - offset;
     r.frame = frame;
@@ -108,24 +109,25 @@ IDRecord record_update(const IDRecord& self, const IDRecord& rec, uint64_t offse
     r.nvariant_sites = self.nvariant_sites + rec.nvariant_sites;
     r.nsomvariant_sites = self.nsomvariant_sites + rec.nsomvariant_sites;
     r.strand = self.strand;
-    std::string vr = self.variant_sites + "|" + rec.variant_sites;
-    if (!vr.empty() && vr.front() == '|') vr.erase(vr.begin());
-    if (!vr.empty() && vr.back() == '|') vr.pop_back();
-    r.variant_sites = vr;
-    r.somatic_positions = join_bar(s_p); r.somatic_aa_change = join_bar(s_aa);
-    r.germline_positions = join_bar(g_p); r.germline_aa_change = join_bar(g_aa);
-    r.normal_sequence = wt_seq;
-    r.mutant_sequence = mt_seq;
-    return r;
+    {   // self.variant_sites + "|" + rec.variant_sites, without a leading / trailing '|'
+        std::string& vr = r.variant_sites;
+        vr.clear();
+        vr += self.variant_sites;
+        vr.push_back('|');
+        vr += rec.variant_sites;
+        if (!vr.empty() && vr.front() == '|') vr.erase(vr.begin());
+        if (!vr.empty() && vr.back() == '|') vr.pop_back();
+    }
+    r.normal_sequence.assign(wt_seq.data(), wt_seq.size());
+    r.mutant_sequence.assign(mt_seq.data(), mt_seq.size());
 }
 
-// IDRecord::add_freq (reference: src/common.rs:528-568)
-IDRecord record_add_freq(const IDRecord& self, double freq) {
-    IDRecord r = self;
-    r.nvar = self.nvar == 0 ? self.nvar : (freq > 0.0 ? self.nvar - 1 : self.nvar);
-    r.nsomatic = r.nvar < self.nsomatic ? self.nsomatic - 1 : self.nsomatic;
-    r.freq = self.freq > 0.5 ? self.freq : self.freq + freq;
-    return r;
+// IDRecord::add_freq (reference: src/common.rs:528-568), in place
+void record_add_freq(IDRecord& r, double freq) {
+    const uint32_t nvar = r.nvar == 0 ? r.nvar : (freq > 0.0 ? r.nvar - 1 : r.nvar);
+    r.nsomatic = nvar < r.nsomatic ? r.nsomatic - 1 : r.nsomatic;
+    r.nvar = nvar;
+    r.freq = r.freq > 0.5 ? r.freq : r.freq + freq;
 }
 
 // MP_TRACE=<file>: one line per print_haplotypes call / merge (debugging aid, compared with the oracle's trace by tools/dbg_trace_case.py)
@@ -139,7 +141,7 @@ struct ConsumerHooks {
     const Gene& gene;
     const Transcript& transcript;
     const TxDev& T;
-    SomaticOutput& out;
+    SomaticText& out;
     uint64_t window_len;
     size_t next_step = 0, cur_step = 0;
     bool is_fwd;
@@ -163,6 +165,7 @@ struct ConsumerHooks {
 
     std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame_in, FsFreq fsf,
                                                  bool is_first_exon_window) {
+        PROF(1);
         const Step& st = b.steps[cur_step];
         if (!(st.flags & SF_PRINT)) throw Error("internal error: print_haplotypes at a step the planner did not schedule");
         const WinStatic& ws = b.wins[st.win];
@@ -258,7 +261,7 @@ struct ConsumerHooks {
             const uint64_t normal_window_len = indel ? (germ_len < wl ? germ_len : wl) : this_window_len;
             // peptides are only materialised when something can observe them
             const bool emit_pre = (n_somatic > 0 || has_frameshift) && !eg.is_short && germ_ne_seq && (!stop_gain || has_frameshift);
-            std::string normal_peptide, neopeptide;
+            std::string_view normal_peptide, neopeptide;   // slices of the device record
             const bool need_strings = rec && (indel || boundary || emit_pre);
             if ((indel || boundary || emit_pre) && !rec)
                 throw Error("internal error: missing haplotype record (window sso " + std::to_string(ws.sso) + ", hap " + std::to_string(key.hap) +
@@ -267,7 +270,7 @@ struct ConsumerHooks {
             if (need_strings) {
                 auto sl = [](const uint8_t* p, uint64_t n, uint64_t a, uint64_t e) {
                     if (a > e || e > n) throw Error("reference would panic: slice index out of range");
-                    return std::string(reinterpret_cast<const char*>(p) + a, e - a);
+                    return std::string_view(reinterpret_cast<const char*>(p) + a, size_t(e - a));
                 };
                 if (germ_len != 0) {
                     if (splice_pos == 1) normal_peptide = sl(rgerm, germ_len, splice_gap, germ_len);
@@ -294,30 +297,32 @@ struct ConsumerHooks {
             // 970028, 970791). So every window of such a stretch keeps its records.
             const bool keep_all = (ws.need_recs & WS_ALL_IDS) && rec;
             if (boundary || emit || keep_all) {
-                std::string sites, som_pos, som_pc, germ_pos, germ_pc;
+                PROF(3);
+                // the row's list fields; the buffers live as long as the consumer thread (a row that is only written never allocates)
+                static thread_local std::string sites, som_pos, som_pc, germ_pos, germ_pc, idstr;
+                sites.clear(); som_pos.clear(); som_pc.clear(); germ_pos.clear(); germ_pc.clear();
                 uint32_t n_sites = 0, n_som_sites = 0;
-                auto add = [](std::string& s, const std::string& x) { if (!s.empty()) s += "|"; s += x; };
+                auto add = [](std::string& s, uint64_t x) { if (!s.empty()) s.push_back('|'); append_u64(s, x); };
                 bool f_sp = true, f_gp = true;
                 for (uint32_t c = 0; c < ncols; c++) {  // :733-759
                     const Variant& v = *variants[c];
                     if (c < rec->prof_len && ((rec->prof_set >> c) & 1)) {
                         if (!v.is_germline) {
-                            add(som_pos, std::to_string(v.pos + 1));
-                            if (!f_sp) som_pc += "|";
+                            add(som_pos, v.pos + 1);
+                            if (!f_sp) som_pc.push_back('|');
                             som_pc += v.prot_change; f_sp = false;
                         } else {
-                            add(germ_pos, std::to_string(v.pos + 1));
-                            if (!f_gp) germ_pc += "|";
+                            add(germ_pos, v.pos + 1);
+                            if (!f_gp) germ_pc.push_back('|');
                             germ_pc += v.prot_change; f_gp = false;
                         }
                     }
                     if (c == 0 || v.pos != variants[c - 1]->pos) {
                         n_sites++;
-                        add(sites, std::to_string(v.pos + 1));
+                        add(sites, v.pos + 1);
                         if (!v.is_germline) n_som_sites++;
                     }
                 }
-                std::string idstr;
                 if (gs.flags & GS_ID_VALID) {
                     static const char HEX[] = "0123456789abcdef";
                     char idb[16];
@@ -325,28 +330,28 @@ struct ConsumerHooks {
                     idb[15] = strand[0];
                     idstr.assign(idb, 16);
                 } else {
-                    idstr = haplotype_id(rseq, seq_len, transcript.id, offset, strand[0]);
+                    haplotype_id_into(idstr, rseq, seq_len, transcript.id, offset, strand[0]);
                 }
                 const uint64_t roffset = splice_pos == 0 ? offset + 1 : offset + 1 + splice_gap;
                 if (emit) {  // :839-875
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
+                        if (out.streams & STREAM_FASTA) put_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
-                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq, this_window_len);
+                        if (out.streams & STREAM_FASTA) put_fasta(out.fasta, idstr, rseq, this_window_len);
                     }
                     if (germ_len != 0) {
                         if (splice_pos == 1) {
                             if (splice_gap > germ_len) throw Error("reference would panic: slice index out of range");
-                            if (out.streams & STREAM_NORMAL_FASTA) write_fasta(out.normal_fasta, idstr, rgerm + splice_gap, germ_len - splice_gap);
+                            if (out.streams & STREAM_NORMAL_FASTA) put_fasta(out.normal_fasta, idstr, rgerm + splice_gap, germ_len - splice_gap);
                         } else if (splice_pos == 0) {
                             if (this_window_len > germ_len) throw Error("reference would panic: slice index out of range");
-                            if (out.streams & STREAM_NORMAL_FASTA) write_fasta(out.normal_fasta, idstr, rgerm, this_window_len);
+                            if (out.streams & STREAM_NORMAL_FASTA) put_fasta(out.normal_fasta, idstr, rgerm, this_window_len);
                         }
                     }
                     // the row is written field by field (no copy through the record)
-                    write_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, roffset, frame, frame_frequency, wd.nrows, n_variants,
-                                     n_somatic, n_sites, n_som_sites, strand_s, sites, som_pos, som_pc, germ_pos, germ_pc, normal_peptide, neopeptide);
+                    put_tsv_row(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, roffset, frame, frame_frequency, wd.nrows, n_variants,
+                                n_somatic, n_sites, n_som_sites, strand_s, sites, som_pos, som_pc, germ_pos, germ_pc, normal_peptide, neopeptide);
                 }
                 // The record is kept for every window that is marked as feeding a merge; an emitted window keeps it too where a merge can
                 // reach a window the planner's marks miss: window lengths that are not a multiple of 3, or an indel / frameshift context
@@ -355,7 +360,7 @@ struct ConsumerHooks {
                 if (boundary || keep_all || window_len % 3 != 0) {
                     hs.filled = true;
                     IDRecord& r = hs.make().record;
-                    r.id = std::move(idstr);
+                    r.id = idstr;
                     r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
                     r.offset = roffset;
                     r.frame = frame;
@@ -364,8 +369,8 @@ struct ConsumerHooks {
                     r.nvar = n_variants; r.nsomatic = n_somatic;
                     r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
                     r.strand = strand_s;
-                    r.variant_sites = std::move(sites); r.somatic_positions = std::move(som_pos); r.somatic_aa_change = std::move(som_pc);
-                    r.germline_positions = std::move(germ_pos); r.germline_aa_change = std::move(germ_pc);
+                    r.variant_sites = sites; r.somatic_positions = som_pos; r.somatic_aa_change = som_pc;
+                    r.germline_positions = germ_pos; r.germline_aa_change = germ_pc;
                     // the carried-over record holds the UNSLICED sequences (:807-832)
                     r.normal_sequence.assign(reinterpret_cast<const char*>(rgerm), germ_len);
                     r.mutant_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);
@@ -379,6 +384,7 @@ struct ConsumerHooks {
     // splice-side merge (reference: src/microphasing.rs:1505-1908)
     void splice_merge(const ExonGeom& eg, const StepGeom& sg, uint64_t exon_rest, std::map<uint64_t, uint64_t>& frameshifts,
                       FsFreq& fsf, std::vector<HapSeq>& hap_vec, std::vector<HapSeq>& prev_hap_vec) {
+        PROF(2);
         const uint64_t offset = sg.offset;
         const std::vector<HapSeq>& first_hap_vec = is_fwd ? hap_vec : prev_hap_vec;
         const std::vector<HapSeq>& sec_hap_vec = is_fwd ? prev_hap_vec : hap_vec;
@@ -393,8 +399,8 @@ struct ConsumerHooks {
                     }
                     throw Error("internal error: splice-side merge over a window whose records were not requested from the device" + where);
                 }
-        using MKey = std::tuple<uint64_t, std::string, std::string>;
-        std::map<MKey, std::tuple<std::string, IDRecord, std::string>> output_map;
+        using MKey = std::tuple<uint64_t, std::string, std::string>;   // (offset, mutant window, wild-type window)
+        std::map<MKey, IDRecord> output_map;
         std::vector<HapSeq> new_hap_vec;
         const double eps = std::numeric_limits<double>::epsilon();
         if (const char* tr = trace_path()) {
@@ -404,6 +410,15 @@ struct ConsumerHooks {
             for (const auto& h : sec_hap_vec) std::fprintf(tf, "  S %.17g %s %s\n", h.get().record.freq, h.get().record.mutant_sequence.c_str(), h.get().record.normal_sequence.c_str());
             std::fclose(tf);
         }
+        // the frameshifts that reach this splice side (the same for every pair of haplotypes)
+        static thread_local std::vector<std::pair<uint64_t, uint64_t>> active;
+        active.clear();
+        if (is_fwd) {
+            for (auto it = frameshifts.begin(); it != frameshifts.end() && it->first < offset; ++it) active.push_back(*it);
+        } else {
+            for (auto it = frameshifts.lower_bound(offset + eg.ewl); it != frameshifts.end(); ++it) active.push_back(*it);
+        }
+        static thread_local std::string new_wt, new_mts[3];
         for (const HapSeq& hapseq : first_hap_vec) {
             const IDRecord& record = hapseq.get().record;
             const std::string& wt = record.normal_sequence;
@@ -412,34 +427,30 @@ struct ConsumerHooks {
                 const IDRecord& prev = prev_hapseq.get().record;
                 const std::string& pwt = prev.normal_sequence;
                 const std::string& pmt = prev.mutant_sequence;
-                std::string new_wt = pwt + wt;
-                std::vector<std::string> new_mts;
+                auto cat = [](std::string& dst, const std::string& a, const std::string& b) { dst.clear(); dst += a; dst += b; };
+                cat(new_wt, pwt, wt);
+                size_t n_mts = 0;
                 if (wt != mt) {
-                    new_mts.push_back(pwt + mt);
-                    if (pwt != pmt) { new_mts.push_back(pmt + wt); new_mts.push_back(pmt + mt); }
+                    cat(new_mts[n_mts++], pwt, mt);
+                    if (pwt != pmt) { cat(new_mts[n_mts++], pmt, wt); cat(new_mts[n_mts++], pmt, mt); }
                 } else {
-                    new_mts.push_back(pmt + mt);
+                    cat(new_mts[n_mts++], pmt, mt);
                 }
                 const double merged = std::fabs(record.freq - prev.freq) < eps ? record.freq : record.freq * prev.freq;
                 if (eg.is_short && !eg.is_last) {
                     HapSeq nh;
                     nh.filled = true;
-                    nh.make().record = record_update(prev, record, 0, record.frame, merged, new_wt, new_wt, window_len, false);   // carried, never written
+                    record_update(nh.make().record, prev, record, 0, record.frame, merged, new_wt, new_wt, window_len, false);   // carried, never written
                     new_hap_vec.push_back(std::move(nh));
                 }
-                for (const std::string& new_mt : new_mts) {
+                for (size_t m = 0; m < n_mts; m++) {
+                    const std::string& new_mt = new_mts[m];
                     if (eg.is_short && !eg.is_last) {
                         HapSeq nh;
                         nh.filled = true;
-                        nh.make().record = record_update(prev, record, 0, record.frame, merged, new_wt, new_mt, window_len, false);
+                        record_update(nh.make().record, prev, record, 0, record.frame, merged, new_wt, new_mt, window_len, false);
                         new_hap_vec.push_back(std::move(nh));
                         continue;
-                    }
-                    std::vector<std::pair<uint64_t, uint64_t>> active;
-                    if (is_fwd) {
-                        for (auto it = frameshifts.begin(); it != frameshifts.end() && it->first < offset; ++it) active.push_back(*it);
-                    } else {
-                        for (auto it = frameshifts.lower_bound(offset + eg.ewl); it != frameshifts.end(); ++it) active.push_back(*it);
                     }
                     for (const auto& pf : active) {
                         const uint64_t pos = pf.first, frameshift = pf.second;
@@ -484,15 +495,17 @@ struct ConsumerHooks {
                                 if (is_fwd) splice_offset += 3; else end_offset += 3;
                                 continue;
                             }
-                            const std::string out_wt = wt_p ? std::string(wt_p, wl_) : std::string();
-                            const std::string out_mt(mt_p, wl_);
+                            PROF(4);
                             const uint64_t out_offset = is_fwd ? splice_offset : uint64_t(end_offset);
-                            IDRecord out_record = is_fwd ? record_update(prev, record, out_offset, frameshift, out_freq, out_wt, out_mt, window_len, false)
-                                                         : record_update(record, prev, out_offset, frameshift, out_freq, out_wt, out_mt, window_len, false);
-                            MKey id_tuple{out_offset, out_mt, out_wt};
-                            auto fit = output_map.find(id_tuple);
-                            const double old_freq = fit == output_map.end() ? 0.0 : std::get<1>(fit->second).freq;
-                            output_map[id_tuple] = std::make_tuple(out_mt, record_add_freq(out_record, old_freq), out_wt);
+                            // output_map[(offset, mt, wt)] = update(...).add_freq(frequency of the record it replaces)
+                            const auto ins = output_map.try_emplace(MKey{out_offset, std::string(mt_p, wl_), wt_p ? std::string(wt_p, wl_) : std::string()});
+                            IDRecord& out_record = ins.first->second;
+                            const double old_freq = ins.second ? 0.0 : out_record.freq;
+                            const std::string& out_mt = std::get<1>(ins.first->first);
+                            const std::string& out_wt = std::get<2>(ins.first->first);
+                            if (is_fwd) record_update(out_record, prev, record, out_offset, frameshift, out_freq, out_wt, out_mt, window_len, false);
+                            else record_update(out_record, record, prev, out_offset, frameshift, out_freq, out_wt, out_mt, window_len, false);
+                            record_add_freq(out_record, old_freq);
                             if (is_fwd) splice_offset += 3; else end_offset += 3;
                         }
                     }
@@ -502,20 +515,21 @@ struct ConsumerHooks {
         if (eg.is_short && !eg.is_last) {
             prev_hap_vec = std::move(new_hap_vec);
         } else {
+            PROF(5);
             for (auto& kv : output_map) {
-                const std::string& out_mt = std::get<0>(kv.second);
-                IDRecord& out_record = std::get<1>(kv.second);
-                const std::string& out_wt = std::get<2>(kv.second);
+                const std::string& out_mt = std::get<1>(kv.first);
+                IDRecord& out_record = kv.second;
+                const std::string& out_wt = std::get<2>(kv.first);
                 if (out_mt != out_wt) {
-                    out_record.id = haplotype_id(reinterpret_cast<const uint8_t*>(out_mt.data()), out_mt.size(), out_record.transcript,
-                                                 std::get<0>(kv.first), out_record.strand.empty() ? '?' : out_record.strand[0]);
+                    haplotype_id_into(out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), out_mt.size(), out_record.transcript,
+                                      std::get<0>(kv.first), out_record.strand.empty() ? '?' : out_record.strand[0]);
                     if (out_mt.size() < window_len) throw Error("reference would panic: slice index out of range");
-                    if (out.streams & STREAM_FASTA) write_fasta(out.fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), size_t(window_len));
+                    if (out.streams & STREAM_FASTA) put_fasta(out.fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_mt.data()), size_t(window_len));
                     if (!out_wt.empty()) {
                         if (out_wt.size() < window_len) throw Error("reference would panic: slice index out of range");
-                        if (out.streams & STREAM_NORMAL_FASTA) write_fasta(out.normal_fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_wt.data()), size_t(window_len));
+                        if (out.streams & STREAM_NORMAL_FASTA) put_fasta(out.normal_fasta, out_record.id, reinterpret_cast<const uint8_t*>(out_wt.data()), size_t(window_len));
                     }
-                    write_tsv_record(out, out_record);
+                    put_tsv_row(out, out_record);
                 }
             }
             if (eg.is_short) prev_hap_vec = std::move(new_hap_vec);
@@ -531,31 +545,33 @@ struct ConsumerHooks {
 // the host keeps frameshifts, hap_vec / prev_hap_vec and the (sequence-concatenating) splice-side merge.
 namespace {
 
-// IDRecord::update / add_freq of the normal mode (reference: src/normal_microphasing.rs:105-146, :148-179)
-NormalRecord nrecord_update(const NormalRecord& self, const NormalRecord& rec, uint64_t offset, const std::vector<uint8_t>& seq, bool with_id = true) {
-    NormalRecord r = self;
-    if (with_id) r.id = haplotype_id(seq.data(), seq.size(), self.transcript, offset, self.strand.empty() ? '?' : self.strand[0]);
-    else r.id.clear();   // the caller sets it on the records it writes
-    r.somatic_positions = self.somatic_positions + rec.somatic_positions;
-    r.somatic_aa_change = self.somatic_aa_change + rec.somatic_aa_change;
-    r.germline_positions = self.germline_positions + rec.germline_positions;
-    r.germline_aa_change = self.germline_aa_change + rec.germline_aa_change;
+// IDRecord::update / add_freq of the normal mode (reference: src/normal_microphasing.rs:105-146, :148-179), written into `r`
+// (every field is set; r may hold an earlier record). with_id = false: the caller sets the id on the records it writes.
+void nrecord_update(NormalRecord& r, const NormalRecord& self, const NormalRecord& rec, uint64_t offset, const uint8_t* seq, size_t seq_len,
+                    bool with_id = true) {
+    if (with_id) haplotype_id_into(r.id, seq, seq_len, self.transcript, offset, self.strand.empty() ? '?' : self.strand[0]);
+    else r.id.clear();
+    auto cat = [](std::string& dst, const std::string& x, const std::string& y) { dst.clear(); dst += x; dst += y; };
+    r.transcript = self.transcript; r.gene_id = self.gene_id; r.gene_name = self.gene_name; r.chrom = self.chrom;
+    r.frame = self.frame; r.depth = self.depth; r.strand = self.strand;
+    cat(r.somatic_positions, self.somatic_positions, rec.somatic_positions);
+    cat(r.somatic_aa_change, self.somatic_aa_change, rec.somatic_aa_change);
+    cat(r.germline_positions, self.germline_positions, rec.germline_positions);
+    cat(r.germline_aa_change, self.germline_aa_change, rec.germline_aa_change);
     r.offset = offset + self.offset;
     r.freq = self.freq * rec.freq;
     r.nvar = self.nvar + rec.nvar;
     r.nsomatic = self.nsomatic + rec.nsomatic;
     r.nvariant_sites = self.nvariant_sites + rec.nvariant_sites;
     r.nsomvariant_sites = self.nsomvariant_sites + rec.nsomvariant_sites;
-    r.variant_sites = self.variant_sites + rec.variant_sites;
-    r.peptide_sequence.assign(reinterpret_cast<const char*>(seq.data()), seq.size());
-    return r;
+    cat(r.variant_sites, self.variant_sites, rec.variant_sites);
+    r.peptide_sequence.assign(reinterpret_cast<const char*>(seq), seq_len);
 }
-NormalRecord nrecord_add_freq(const NormalRecord& self, double freq) {
-    NormalRecord r = self;
-    if (freq > 0.0) r.nvar = self.nvar - 1u;  // u32 wrap-around at nvar == 0, as the reference's release build does (:150)
-    if (r.nvar < self.nsomatic) r.nsomatic = self.nsomatic - 1;
-    r.freq = self.freq + freq;
-    return r;
+void nrecord_add_freq(NormalRecord& r, double freq) {
+    const uint32_t nsomatic = r.nsomatic;
+    if (freq > 0.0) r.nvar = r.nvar - 1u;  // u32 wrap-around at nvar == 0, as the reference's release build does (:150)
+    if (r.nvar < nsomatic) r.nsomatic = nsomatic - 1;
+    r.freq = r.freq + freq;
 }
 
 struct NormalConsumerHooks {
@@ -566,7 +582,7 @@ struct NormalConsumerHooks {
     const Gene& gene;
     const Transcript& transcript;
     const TxDev& T;
-    NormalOutput& out;
+    NormalText& out;
     uint64_t window_len;
     size_t next_step = 0, cur_step = 0;
     bool is_fwd;
@@ -598,7 +614,10 @@ struct NormalConsumerHooks {
         if (frame == 0) out.n_windows++;
         const std::vector<Variant>& gvars = gh.input->variants;
         const uint32_t ncols = ws.ncols;
-        std::vector<const Variant*> variants(ncols);
+        const Variant* variants_few[64];
+        std::vector<const Variant*> variants_many;
+        const Variant** variants = variants_few;
+        if (ncols > 64) { variants_many.resize(ncols); variants = variants_many.data(); }
         for (uint32_t j = 0; j < ncols; j++) variants[j] = &gvars[b.win_cols[ws.col_off + (is_fwd ? j : ncols - 1 - j)].f];
         const char* strand = is_fwd ? "Forward" : "Reverse";
         static const std::string kForward("Forward"), kReverse("Reverse");
@@ -637,7 +656,8 @@ struct NormalConsumerHooks {
                 else { pep_lo = 0; pep_hi = seq_len; }
                 check(pep_lo, pep_hi);
                 if (!(gs.flags & GS_ID_VALID)) throw Error("internal error: haplotype id was not computed on the device");
-                std::string idstr;
+                // the row's id and list fields; the buffers live as long as the consumer thread
+                static thread_local std::string idstr, somatic_positions, somatic_aa_change, germline_positions, germline_aa_change, variant_sites;
                 {
                     static const char HEX[] = "0123456789abcdef";
                     char idb[16];
@@ -645,47 +665,48 @@ struct NormalConsumerHooks {
                     idb[15] = strand[0];
                     idstr.assign(idb, 16);
                 }
-                std::string somatic_positions, somatic_aa_change, germline_positions, germline_aa_change, variant_sites;
-                auto add = [](std::string& s, const std::string& x, bool& first) { if (!first) s += "|"; s += x; first = false; };
+                somatic_positions.clear(); somatic_aa_change.clear(); germline_positions.clear(); germline_aa_change.clear(); variant_sites.clear();
+                auto add = [](std::string& s, const std::string& x, bool& first) { if (!first) s.push_back('|'); s += x; first = false; };
+                auto addn = [](std::string& s, uint64_t x, bool& first) { if (!first) s.push_back('|'); append_u64(s, x); first = false; };
                 bool f1 = true, f2 = true, f3 = true, f4 = true, f5 = true;
                 uint32_t n_sites = 0, n_som_sites = 0;
                 for (uint32_t c = 0; c < ncols; c++) {  // :531-557 (0-based positions; profile index = visit order)
                     if (c >= rec->prof_len) break;
                     const Variant& v = *variants[c];
                     if ((rec->prof_set >> c) & 1) {
-                        if ((prof_som >> c) & 1) { add(somatic_positions, std::to_string(v.pos), f1); add(somatic_aa_change, v.prot_change, f2); }
-                        else { add(germline_positions, std::to_string(v.pos), f3); add(germline_aa_change, v.prot_change, f4); }
+                        if ((prof_som >> c) & 1) { addn(somatic_positions, v.pos, f1); add(somatic_aa_change, v.prot_change, f2); }
+                        else { addn(germline_positions, v.pos, f3); add(germline_aa_change, v.prot_change, f4); }
                     }
                     if (c == 0 || v.pos != variants[c - 1]->pos) {
                         n_sites++;
-                        add(variant_sites, std::to_string(v.pos), f5);
+                        addn(variant_sites, v.pos, f5);
                         if (!v.is_germline) n_som_sites++;
                     }
                 }
                 if (!eg.is_short) {  // :629-644
                     if (splice_pos == 1) {
                         if (splice_gap > seq_len) throw Error("reference would panic: slice index out of range");
-                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
+                        if (out.streams & STREAM_FASTA) put_fasta(out.fasta, idstr, rseq + splice_gap, seq_len - splice_gap);
                     } else if (splice_pos == 0) {
                         if (wl > seq_len) throw Error("reference would panic: slice index out of range");
-                        if (out.streams & STREAM_FASTA) write_fasta(out.fasta, idstr, rseq, size_t(wl));
+                        if (out.streams & STREAM_FASTA) put_fasta(out.fasta, idstr, rseq, size_t(wl));
                     }
-                    write_normal_tsv_fields(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, offset, frame, freq, nrows, rec->nvar, rec->nsom, n_sites,
+                    put_normal_tsv_row(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, offset, frame, freq, nrows, rec->nvar, rec->nsom, n_sites,
                                             n_som_sites, strand_s, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
-                                            germline_aa_change, reinterpret_cast<const char*>(rseq) + pep_lo, size_t(pep_hi - pep_lo));
+                                            germline_aa_change, std::string_view(reinterpret_cast<const char*>(rseq) + pep_lo, size_t(pep_hi - pep_lo)));
                 }
                 {   // the record is kept for every window of a regular exon: `normal` merges reach further back than the planner's marks
                     hs.filled = true;
-                    NormalRecord& r = hs.make().nrecord;
-                    r.id = std::move(idstr);
-                    r.somatic_positions = std::move(somatic_positions); r.somatic_aa_change = std::move(somatic_aa_change);
-                    r.germline_positions = std::move(germline_positions); r.germline_aa_change = std::move(germline_aa_change);
-                    r.variant_sites = std::move(variant_sites);
+                    NormalRecord& r = hs.nmake().nrecord;
+                    r.id = idstr;
+                    r.somatic_positions = somatic_positions; r.somatic_aa_change = somatic_aa_change;
+                    r.germline_positions = germline_positions; r.germline_aa_change = germline_aa_change;
+                    r.variant_sites = variant_sites;
                     r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
                     r.offset = offset; r.frame = frame; r.freq = freq; r.depth = nrows;
                     r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
                     r.strand = strand_s;
-                    hs.make().sequence.assign(rseq, rseq + seq_len);
+                    hs.nmake().sequence.assign(rseq, rseq + seq_len);
                     r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);  // carried record: unsliced (:618-625)
                 }
             }
@@ -705,34 +726,38 @@ struct NormalConsumerHooks {
         using Bytes = std::vector<uint8_t>;
         std::map<std::pair<uint64_t, Bytes>, NormalRecord> output_map;
         std::vector<HapSeq> new_hap_vec;
+        static thread_local Bytes joined;   // prev sequence + this sequence
         for (const HapSeq& hapseq : first_hap_vec) {
+            const NormalRecord& record = hapseq.nget().nrecord;
             for (const HapSeq& prev_hapseq : sec_hap_vec) {
-                Bytes prev_sequence = prev_hapseq.get().sequence;
-                const NormalRecord& prev_record = prev_hapseq.get().nrecord;
-                prev_sequence.insert(prev_sequence.end(), hapseq.get().sequence.begin(), hapseq.get().sequence.end());
+                const NormalRecord& prev_record = prev_hapseq.nget().nrecord;
+                joined.assign(prev_hapseq.nget().sequence.begin(), prev_hapseq.nget().sequence.end());
+                joined.insert(joined.end(), hapseq.nget().sequence.begin(), hapseq.nget().sequence.end());
                 if (eg.is_short) {
                     HapSeq nh;
-                    nh.make().sequence = prev_sequence;
+                    nh.nmake().sequence = joined;
                     nh.filled = true;
-                    nh.make().nrecord = nrecord_update(prev_record, hapseq.get().nrecord, 0, prev_sequence, false);   // carried, never written
+                    nrecord_update(nh.nmake().nrecord, prev_record, record, 0, joined.data(), joined.size(), false);   // carried, never written
                     new_hap_vec.push_back(std::move(nh));
                 }
                 uint64_t splice_offset = 3;
                 if (!is_fwd && exon_rest < 3) splice_offset += exon_rest;
                 size_t end_offset = 3;
                 if (sg.is_last_exon_window) end_offset = 0;
-                if (uint64_t(prev_sequence.size()) < 2 * window_len) {
+                if (uint64_t(joined.size()) < 2 * window_len) {
                     if (is_fwd) splice_offset = 0; else end_offset = 0;
                 }
                 for (;;) {
-                    if (end_offset > prev_sequence.size()) throw Error("reference would panic: attempt to subtract with overflow (merge)");
-                    if (!(splice_offset + window_len <= uint64_t(prev_sequence.size() - end_offset))) break;
-                    Bytes out_seq(prev_sequence.begin() + long(splice_offset), prev_sequence.begin() + long(splice_offset + window_len));
-                    NormalRecord out_record = nrecord_update(prev_record, hapseq.get().nrecord, splice_offset, out_seq, false);
-                    auto key = std::make_pair(splice_offset, out_seq);
-                    auto fit = output_map.find(key);
-                    const double old_freq = fit == output_map.end() ? 0.0 : fit->second.freq;
-                    output_map[key] = nrecord_add_freq(out_record, old_freq);
+                    if (end_offset > joined.size()) throw Error("reference would panic: attempt to subtract with overflow (merge)");
+                    if (!(splice_offset + window_len <= uint64_t(joined.size() - end_offset))) break;
+                    // output_map[(offset, window)] = update(...).add_freq(frequency of the record it replaces)
+                    const auto ins = output_map.try_emplace(std::make_pair(splice_offset, Bytes(joined.begin() + long(splice_offset),
+                                                                                                 joined.begin() + long(splice_offset + window_len))));
+                    NormalRecord& out_record = ins.first->second;
+                    const double old_freq = ins.second ? 0.0 : out_record.freq;
+                    const Bytes& out_seq = ins.first->first.second;
+                    nrecord_update(out_record, prev_record, record, splice_offset, out_seq.data(), out_seq.size(), false);
+                    nrecord_add_freq(out_record, old_freq);
                     splice_offset += 3;
                 }
             }
@@ -743,28 +768,28 @@ struct NormalConsumerHooks {
             for (auto& kv : output_map) {
                 const Bytes& out_seq = kv.first.second;
                 NormalRecord& rec = kv.second;
-                rec.id = haplotype_id(out_seq.data(), out_seq.size(), rec.transcript, kv.first.first, rec.strand.empty() ? '?' : rec.strand[0]);
+                haplotype_id_into(rec.id, out_seq.data(), out_seq.size(), rec.transcript, kv.first.first, rec.strand.empty() ? '?' : rec.strand[0]);
                 if (out_seq.size() < window_len) throw Error("reference would panic: slice index out of range");
-                if (out.streams & STREAM_FASTA) write_fasta(out.fasta, kv.second.id, out_seq.data(), size_t(window_len));
-                write_normal_tsv_record(out, kv.second);
+                if (out.streams & STREAM_FASTA) put_fasta(out.fasta, kv.second.id, out_seq.data(), size_t(window_len));
+                put_normal_tsv_row(out, kv.second);
             }
         }
     }
 };
 
-void reserve_streams(SomaticOutput& p, size_t recs) {
+void reserve_streams(SomaticText& p, size_t recs) {
     if (p.streams & STREAM_TSV) p.tsv.reserve(recs * 340);
     if (p.streams & STREAM_FASTA) p.fasta.reserve(recs * 52);
     if (p.streams & STREAM_NORMAL_FASTA) p.normal_fasta.reserve(recs * 52);
     advise_huge(p.tsv.data(), p.tsv.capacity());
 }
-void reserve_streams(NormalOutput& p, size_t recs) {
+void reserve_streams(NormalText& p, size_t recs) {
     if (p.streams & STREAM_TSV) p.tsv.reserve(recs * 320);
     if (p.streams & STREAM_FASTA) p.fasta.reserve(recs * 56);
     advise_huge(p.tsv.data(), p.tsv.capacity()); advise_huge(p.fasta.data(), p.fasta.capacity());
 }
-const std::string* normal_stream(const SomaticOutput& p) { return &p.normal_fasta; }
-const std::string* normal_stream(const NormalOutput&) { return nullptr; }
+const TextBuf* normal_stream(const SomaticText& p) { return &p.normal_fasta; }
+const TextBuf* normal_stream(const NormalText&) { return nullptr; }
 
 template <class Hooks, class Out>
 void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1, Out& out) {
@@ -775,10 +800,11 @@ void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1,
         for (uint32_t k = 0; k < gh.n_tx; k++) {
             const TxDev& T = b.tx[gh.tx_off + k];
             const Transcript& t = gi.gene.transcripts[gh.tx_src[k]];
+            PROF(0);
             Hooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
             walk_transcript(gi.gene, t, vi, gh.max_read_len, b.window_len, hooks);
         }
-        const std::string* nf = normal_stream(out);
+        const TextBuf* nf = normal_stream(out);
         out.gene_ends.push_back(GeneEnds{out.fasta.size(), nf ? nf->size() : 0, out.tsv.size()});
     }
 }
@@ -811,11 +837,11 @@ void assemble(std::vector<Out>& parts, PhasedStreams& out, size_t nthreads) {
     for (Out& p : parts) {
         out.n_windows += p.n_windows;
         fa.push_back({p.fasta.data(), p.fasta.size()});
-        const std::string* n = normal_stream(p);
+        const TextBuf* n = normal_stream(p);
         if (n) nfa.push_back({n->data(), n->size()});
         size_t skip = 0;
         if (!p.tsv.empty()) {
-            const size_t hl = p.tsv.find('\n') + 1;
+            const size_t hl = size_t(static_cast<const char*>(std::memchr(p.tsv.data(), '\n', p.tsv.size())) - p.tsv.data()) + 1;
             skip = header ? hl : 0;
             if (!header) header_len = hl;
             tsv.push_back({p.tsv.data() + skip, p.tsv.size() - skip});
@@ -909,12 +935,12 @@ void consume_sharded(const Batch& b, const HostResults& res, PhasedStreams& out,
 
 void consume_batch(const Batch& b, const HostResults& res, PhasedStreams& out, uint32_t streams) {
     if (b.normal) throw Error("internal error: somatic consumer on a normal-mode batch");
-    consume_sharded<ConsumerHooks, SomaticOutput>(b, res, out, streams);
+    consume_sharded<ConsumerHooks, SomaticText>(b, res, out, streams);
 }
 
 void consume_batch_normal(const Batch& b, const HostResults& res, PhasedStreams& out, uint32_t streams) {
     if (!b.normal) throw Error("internal error: normal consumer on a somatic-mode batch");
-    consume_sharded<NormalConsumerHooks, NormalOutput>(b, res, out, streams);
+    consume_sharded<NormalConsumerHooks, NormalText>(b, res, out, streams);
 }
 
 }  // namespace mp

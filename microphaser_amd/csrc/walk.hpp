@@ -27,18 +27,20 @@ using FsFreq = std::map<uint64_t, std::pair<double, bool>>;  // frameshift_frequ
 struct HapSeq {  // reference: HaplotypeSeq (microphasing.rs:141-145); record carries the unsliced sequences
     // The record types hold two dozen strings; most haplotypes of most windows never get one (nothing can observe them), and the
     // consumer creates a HapSeq per haplotype per window - so the payload is allocated only when a record is actually built.
-    struct Payload {
-        IDRecord record;
-        // `normal` mode (normal_microphasing.rs:182-186): the sequence bytes + its own record type
+    struct Payload { IDRecord record; };
+    struct NormalPayload {   // `normal` mode (normal_microphasing.rs:182-186): the sequence bytes + its own record type
         std::vector<uint8_t> sequence;
         NormalRecord nrecord;
     };
     std::unique_ptr<Payload> p;
+    std::unique_ptr<NormalPayload> np;
     bool filled = false;   // consumer: the record was built (the planner marked the window as carried or it is emitted)
     uint32_t win = 0xFFFFFFFFu;   // consumer: window the haplotype came from (diagnostics)
     uint64_t frame = 0;
     Payload& make() { if (!p) p.reset(new Payload()); return *p; }
     const Payload& get() const { static const Payload empty; return p ? *p : empty; }
+    NormalPayload& nmake() { if (!np) np.reset(new NormalPayload()); return *np; }
+    const NormalPayload& nget() const { static const NormalPayload empty; return np ? *np : empty; }
 };
 
 struct ExonGeom {
