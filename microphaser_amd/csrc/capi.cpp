@@ -258,6 +258,7 @@ int mp_batch_results_select(mp_ctx* ctx, mp_batch* batch, uint32_t streams, mp_r
         std::unique_ptr<mp_results> r(new mp_results());
         if (batch->batch.normal) consume_batch_normal(batch->batch, hr, r->out, streams);
         else consume_batch(batch->batch, hr, r->out, streams);
+        release_later(std::move(hr));
         *out = r.release();
     });
 }

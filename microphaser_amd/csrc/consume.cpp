@@ -864,16 +864,21 @@ void assemble(std::vector<Out>& parts, PhasedStreams& out, size_t nthreads) {
     auto work = [&] {
         for (size_t i; (i = next.fetch_add(1)) < tasks.size();) std::memcpy(tasks[i].dst, tasks[i].src, tasks[i].n);
     };
+    const auto t_copy = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     const size_t nt = std::max<size_t>(1, std::min(nthreads, tasks.size()));
     for (size_t k = 1; k < nt; k++) th.emplace_back(work);
     work();
     for (auto& x : th) x.join();
     th.clear();
-    auto release = [&] { for (size_t i; (i = next_free.fetch_add(1)) < parts.size();) parts[i] = Out(); };
-    for (size_t k = 1; k < std::min(nthreads, parts.size()); k++) th.emplace_back(release);
-    release();
-    for (auto& x : th) x.join();
+    const auto t_release = std::chrono::steady_clock::now();
+    (void)next_free;
+    release_later(std::move(parts));
+    parts.clear();
+    if (std::getenv("MP_DEBUG"))
+        std::fprintf(stderr, "[mp]   assemble: %zu copy tasks %.1f ms, release of the pieces %.1f ms\n", tasks.size(),
+                     std::chrono::duration<double, std::milli>(t_release - t_copy).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_release).count());
 }
 
 template <class Hooks, class Out>

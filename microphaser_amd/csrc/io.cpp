@@ -19,7 +19,7 @@ namespace mp {
 
 void advise_huge(const void* p, size_t bytes) {
 #ifdef MADV_HUGEPAGE
-    if (bytes < (size_t(32) << 20)) return;
+    if (bytes < (size_t(4) << 20)) return;
     const uintptr_t two_mb = uintptr_t(1) << 21;
     const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + two_mb - 1) & ~(two_mb - 1), e = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(two_mb - 1);
     if (e > a) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);

@@ -12,6 +12,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mp {
@@ -73,8 +74,16 @@ enum CigarOp : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, 
 // seq is BAM 4-bit packed (two bases per byte, high nibble first), qual is raw phred.
 // std::vector whose resize() leaves trivially-constructible elements uninitialised: the big host arrays are sized once and then
 // filled (and their pages first touched) by all host threads, instead of being zero-filled by one.
+void advise_huge(const void* p, size_t bytes);
 template <class T> struct DefaultInitAlloc : std::allocator<T> {
     template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    // a large array asks for transparent huge pages before it is touched: its page faults - and, when it is given back, the page-table
+    // teardown under the process-wide mm lock - shrink by a factor of 512
+    T* allocate(size_t n) {
+        T* p = std::allocator<T>::allocate(n);
+        advise_huge(p, n * sizeof(T));
+        return p;
+    }
     template <class U, class... A> void construct(U* p, A&&... a) {
         if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
         else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
@@ -86,6 +95,13 @@ template <class T> using PodVec = std::vector<T, DefaultInitAlloc<T>>;
 // size) are first touched by many threads at once: ask for transparent huge pages so that this costs thousands of page faults, not
 // millions. A hint only; no effect where the kernel does not offer it.
 void advise_huge(const void* p, size_t bytes);
+
+// Giving gigabytes of scratch back to the OS (the planner's sub-batches, the consumer's pieces, the downloaded results) is page-table
+// work under the process-wide mm lock: it is taken off the caller's path - the object is moved to a thread that destroys it.
+template <class T> void release_later(T&& obj) {
+    auto* held = new std::decay_t<T>(std::move(obj));
+    std::thread([held] { delete held; }).detach();
+}
 
 struct ReadStore {
     PodVec<int32_t> tid;

@@ -789,9 +789,8 @@ struct MergeTasks {
         for (size_t t = 0; t < parts.size(); t++) {
             const size_t n = at[t + 1] - at[t], o = at[t];
             run.push_back([&dst, &parts, m, fix, t, n, o] {
-                V& src = parts[t].*m;
+                V& src = parts[t].*m;   // (the sources are given back later, off this path: release_later)
                 for (size_t i = 0; i < n; i++) { dst[o + i] = std::move(src[i]); fix(dst[o + i], t); }
-                V().swap(src);
             });
         }
     }
@@ -808,13 +807,13 @@ struct MergeTasks {
             run.push_back([&dst, &parts, m, t, o] {
                 V& src = parts[t].*m;
                 if (!src.empty()) std::memcpy(static_cast<void*>(dst.data() + o), src.data(), src.size() * sizeof(T));
-                V().swap(src);
             });
         }
     }
 };
 
 void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
+    const auto t_merge0 = std::chrono::steady_clock::now();
     std::vector<PartOff> o(parts.size() + 1, PartOff{});
     for (size_t t = 0; t < parts.size(); t++) {
         const Batch& s = parts[t];
@@ -868,9 +867,23 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
     std::vector<std::function<void()>>& tasks = mt.run;
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
+    const auto t_run = std::chrono::steady_clock::now();
+    std::vector<double> busy(nthreads, 0.0);
     for (size_t k = 0; k < std::min(nthreads, tasks.size()); k++)
-        th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < tasks.size();) tasks[i](); });
+        th.emplace_back([&, k] {
+            const auto a = std::chrono::steady_clock::now();
+            for (size_t i; (i = next.fetch_add(1)) < tasks.size();) tasks[i]();
+            busy[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+        });
     for (auto& x : th) x.join();
+    if (std::getenv("MP_DEBUG")) {
+        double lo = 1e30, hi = 0;
+        for (size_t k = 0; k < std::min(nthreads, tasks.size()); k++) { lo = std::min(lo, busy[k]); hi = std::max(hi, busy[k]); }
+        std::fprintf(stderr, "[mp]   merge: set-up %.1f ms, %zu copy tasks %.1f ms (threads busy %.1f .. %.1f ms)\n",
+                     std::chrono::duration<double, std::milli>(t_run - t_merge0).count(), tasks.size(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(), lo, hi);
+    }
+    release_later(std::move(parts));
     parts.clear();
 }
 }  // namespace
