@@ -82,7 +82,7 @@ struct Batch {
     // consumer raises the message only if the real walk reaches it
     std::vector<std::pair<uint32_t, std::string>> tx_errors;
     // ---- sizing
-    uint32_t seq_cap = 48;                // HapRec sequence capacity of this batch (SEQ_CAPS)
+    uint32_t seq_cap = SEQ_CAPS[0];       // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks
     uint32_t max_rows_bound = 0;          // upper bound on simultaneously live rows (+pending) of any transcript
     uint64_t n_main_windows = 0;          // main-ORF printing steps in the plan (speculative upper bound)

@@ -2447,11 +2447,12 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
 // K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
 // id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
 constexpr uint32_t K3B_BUF_WORDS = 48;   // three SHA-1 blocks per thread (a 27..31-nt window + an id of <= 17 characters always fits)
+constexpr uint32_t K3B_THREADS = 192;    // three waves share the byte_text table: 39.7 KB of LDS per workgroup -> 4 workgroups = 12 waves per CU
 template <int SEQ_CAP>
-__global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d) {
-    __shared__ uint32_t lds_blk[64 * (K3B_BUF_WORDS + 1)];   // odd stride: bank-conflict free
+__global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) {
+    __shared__ uint32_t lds_blk[K3B_THREADS * (K3B_BUF_WORDS + 1)];   // odd stride: bank-conflict free
     __shared__ uint64_t byte_text[256];   // decimal text of a byte value followed by ", ", packed big-endian: text << 8 | length
-    for (uint32_t v = threadIdx.x; v < 256; v += 64) {
+    for (uint32_t v = threadIdx.x; v < 256; v += K3B_THREADS) {
         uint64_t txt;
         uint32_t n;
         if (v >= 100) { txt = (uint64_t('0' + v / 100) << 16) | (uint64_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10); n = 3; }
@@ -2462,11 +2463,11 @@ __global__ __launch_bounds__(64) void k3b_haplotype_ids(DeviceBatch d) {
     }
     __syncthreads();
     const uint64_t n_recs = d.want_prefix[NPART];   // known on the device only (k_partition_prefix after K3)
-    for (uint64_t tile = blockIdx.x; tile * 64 < n_recs; tile += gridDim.x) {
-    const uint64_t li = tile * 64 + threadIdx.x;   // index into the dense lists of records that need an id
+    for (uint64_t tile = blockIdx.x; tile * K3B_THREADS < n_recs; tile += gridDim.x) {
+    const uint64_t li = tile * K3B_THREADS + threadIdx.x;   // index into the dense lists of records that need an id
     uint32_t wp;       // li-th wanted record overall -> list wp, offset woff
     uint64_t woff;
-    locate_in_parts(d.want_prefix, li, tile * 64, li < n_recs, wp, woff);
+    locate_in_parts(d.want_prefix, li, tile * K3B_THREADS + (threadIdx.x & ~63u), li < n_recs, wp, woff);
     if (li >= n_recs) continue;
     const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + woff];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
@@ -2690,7 +2691,8 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStr
     dim3 grid(uint32_t(std::min<uint64_t>((max_group_slots + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull))), block(K3_THREADS);
     if (d.normal) {
         switch (d.seq_cap) {
-            case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d); break;
+            case 32: hipLaunchKernelGGL(k3_window_seq_normal<32>, grid, block, 0, stream, d); break;
+        case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d); break;
             case 112: hipLaunchKernelGGL(k3_window_seq_normal<112>, grid, block, 0, stream, d); break;
             case 240: hipLaunchKernelGGL(k3_window_seq_normal<240>, grid, block, 0, stream, d); break;
             default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
@@ -2699,6 +2701,7 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStr
         return;
     }
     switch (d.seq_cap) {
+        case 32: hipLaunchKernelGGL(k3_window_seq<32>, grid, block, 0, stream, d); break;
         case 48: hipLaunchKernelGGL(k3_window_seq<48>, grid, block, 0, stream, d); break;
         case 112: hipLaunchKernelGGL(k3_window_seq<112>, grid, block, 0, stream, d); break;
         case 240: hipLaunchKernelGGL(k3_window_seq<240>, grid, block, 0, stream, d); break;
@@ -2709,8 +2712,9 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStr
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {
     if (max_recs == 0) return;
-    dim3 grid(uint32_t(std::min<uint64_t>((max_recs + 63) / 64, 0x7FFFFFFFull))), block(64);
+    dim3 grid(uint32_t(std::min<uint64_t>((max_recs + K3B_THREADS - 1) / K3B_THREADS, 0x7FFFFFFFull))), block(K3B_THREADS);
     switch (d.seq_cap) {
+        case 32: hipLaunchKernelGGL(k3b_haplotype_ids<32>, grid, block, 0, stream, d); break;
         case 48: hipLaunchKernelGGL(k3b_haplotype_ids<48>, grid, block, 0, stream, d); break;
         case 112: hipLaunchKernelGGL(k3b_haplotype_ids<112>, grid, block, 0, stream, d); break;
         case 240: hipLaunchKernelGGL(k3b_haplotype_ids<240>, grid, block, 0, stream, d); break;

@@ -190,9 +190,9 @@ struct PlannerHooksT {
         b.wins.back().need_recs = uint8_t(((NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0) | (walk_prefix << WS_PREFIX_SHIFT));  // `normal` emits every haplotype
         if (NORMAL) max_len += 1;  // the unconditional trailing base (src/normal_microphasing.rs:476)
         if (b.wins.back().need_recs & WS_MASK) b.steps[cur_step].flags |= SF_NEED_RECS;
-        if (max_len > SEQ_CAPS[2])
+        if (max_len > SEQ_CAP_MAX)
             throw Error("window at " + std::to_string(st.sso) + " can build a sequence of " + std::to_string(max_len) +
-                        " nt; this build supports at most " + std::to_string(SEQ_CAPS[2]) + " (very long indel in a window)");
+                        " nt; this build supports at most " + std::to_string(SEQ_CAP_MAX) + " (very long indel in a window)");
         max_seq_len = std::max<uint64_t>(max_seq_len, max_len);
     }
 
@@ -739,7 +739,7 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
                 hooks.finish();
                 td.n_steps = uint32_t(b.steps.size()) - td.step_off;
                 b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
-                while (b.seq_cap < hooks.max_seq_len) b.seq_cap = b.seq_cap == SEQ_CAPS[0] ? SEQ_CAPS[1] : SEQ_CAPS[2];
+                b.seq_cap = std::max(b.seq_cap, seq_cap_for(hooks.max_seq_len));
             };
             if (normal) {
                 PlannerHooksT<true> hooks{b, gh, gi.variants, fwd2rev, t.strand == FORWARD, uint32_t(b.tx.size())};

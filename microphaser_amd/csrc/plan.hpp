@@ -212,7 +212,9 @@ struct HapRecHdr {
     uint32_t want_id;    // 1: K3b computes id60
 };
 static_assert(sizeof(HapRecHdr) == 32, "HapRecHdr layout");
-constexpr uint32_t SEQ_CAPS[3] = {48, 112, 240};
+constexpr uint32_t SEQ_CAPS[4] = {32, 48, 112, 240};   // 32: a 27-nt window without indels -> 96-byte records
+constexpr uint32_t SEQ_CAP_MAX = SEQ_CAPS[3];
+inline uint32_t seq_cap_for(uint64_t max_len) { for (uint32_t c : SEQ_CAPS) if (max_len <= c) return c; return SEQ_CAP_MAX; }
 inline uint32_t hap_rec_stride(uint32_t cap) { return 32u + 2u * cap; }
 
 }  // namespace mp
