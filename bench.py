@@ -17,7 +17,9 @@ phases them with no data-path collective. value = windows of the whole exome / s
 time -> "scaling": "strong". N=1 runs the same exome on one GPU.
 
 The JSON line also carries
-  roofline                 - the dominant kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak
+  roofline                 - the dominant unit's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak (a unit = one kernel, or the
+                             three window kernels that run concurrently, priced together over the phase's wall time)
+  roofline_units, pass_hbm_frac, valu_issue - the same for every unit, for the whole pass, and the pass's VALU issue rate vs the chip's
   cpu_baseline             - the CPU oracle (single thread, like the reference) on a bounded sample of the workload
   cpu_baseline_all_cores   - the same oracle with the sample's genes sharded over all host cores
   end_to_end               - plan+pack+H2D, pass, D2H+consume wall times of rank 0 and the in-memory end-to-end rate
@@ -39,6 +41,7 @@ CONFIGS = {
     "D": (5005, 500, 500.0, 1.35),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_PER_S = 256 * 4 * 0.5 * 2.4e9   # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (same guide)
 
 
 def effective_cores():
@@ -197,25 +200,43 @@ def main():
                 "k2a_admission": (k2a / steps, st.bytes_k2a), "k2l_window_lanes": (k2l / steps, st.bytes_k2l),
                 "k2w_window_rows": (k2w / steps, st.bytes_k2w),
                 "k3_window_seq": (k3 / steps, st.bytes_k3), "k3b_haplotype_ids": (k3b / steps, st.bytes_k3b)}
-        dom = max(kern, key=lambda k: kern[k][0])
-        dom_ms, dom_bytes = kern[dom]
+        # Roofline units: kernels that run one after the other on the launch stream, except the window phase - k2l (two launches) and k2w are
+        # launched side by side on separate streams, so their HIP-event intervals overlap (each spans most of the phase); the phase is
+        # priced as ONE unit: the three launches' bytes over the phase's wall time (first start to last end, HIP events)
+        units = {"k1_pileup_bits": kern["k1_pileup_bits"] + (["k1_pileup_bits"],),
+                 "k2a_admission": kern["k2a_admission"] + (["k2a_admission"],),
+                 "k2_window_phase (k2l_window_lanes<6> | k2l_window_lanes<8> | k2w_window_rows, concurrent)":
+                     (k2win / steps, st.bytes_k2l + st.bytes_k2w, ["k2l_window_lanes", "k2w_window_rows"]),
+                 "k3_window_seq": kern["k3_window_seq"] + (["k3_window_seq"],),
+                 "k3b_haplotype_ids": kern["k3b_haplotype_ids"] + (["k3b_haplotype_ids"],)}
+        if k2win <= 0:   # no window-parallel work in this batch: the sequential replay is the K2 unit
+            del units["k2_window_phase (k2l_window_lanes<6> | k2l_window_lanes<8> | k2w_window_rows, concurrent)"]
+            units["k2_window_replay"] = kern["k2_window_replay"] + (["k2_window_replay"],)
+        dom = max(units, key=lambda k: units[k][0])
+        dom_ms, dom_bytes, dom_kernels = units[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes of this very command, so
-        # they come from the committed summary of those passes (tools/pmc_summary.py), only when it is for this workload
+        # HBM bytes per launch and instruction counts from the PMC counters: they need separate rocprofv3 --pmc passes of this very
+        # command, so they come from the committed summary of those passes (tools/pmc_summary.py), only when it is for this workload
         traffic, traffic_src, traffic_note = None, None, None
+        valu = {}
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_config%s.json" % args.config)), reverse=True):
             try:
                 pt = json.load(open(path))
             except (OSError, ValueError):
                 continue
-            hit = [k for k in pt if k.split("<")[0] == dom]
-            if hit and not args.transcripts and world == 1 and "fetch_bytes_raw" in pt[hit[0]]:
-                e = pt[hit[0]]
-                traffic = e["fetch_bytes_raw"] + e.get("write_bytes", 0.0)
+            if args.transcripts or world != 1:
+                break
+            hit = [k for k in pt if k.split("<")[0] in dom_kernels and "fetch_bytes_raw" in pt[k]]
+            if hit:
+                traffic = sum(pt[k]["fetch_bytes_raw"] + pt[k].get("write_bytes", 0.0) for k in hit)
                 traffic_src = os.path.relpath(path, ROOT)
-                traffic_note = ("FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch; with the gfx950 correction for wide streaming reads "
-                                "(FETCH_SIZE counts them at half, MI355X_MICROARCH.md HBM section) the read side is at most %.3g bytes" % e.get("fetch_bytes_x2", 0.0))
+                traffic_note = ("FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch, summed over %s; with the gfx950 correction for wide streaming reads "
+                                "(FETCH_SIZE counts them at half, MI355X_MICROARCH.md HBM section) the read side is at most %.3g bytes"
+                                % (", ".join(hit), sum(pt[k].get("fetch_bytes_x2", 0.0) for k in hit)))
+                for k, e in pt.items():
+                    if "SQ_INSTS_VALU" in e:
+                        valu[k.split("<")[0]] = valu.get(k.split("<")[0], 0.0) + e["SQ_INSTS_VALU"]
                 break
         t_pass = elapsed_max / steps
         out = {
@@ -231,8 +252,16 @@ def main():
                        "transcripts_rank0": int(st.n_transcripts), "window_len": 27, "sharding": "genes (LPT on cost), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms, "rocprof_kernels": dom_kernels,
                          "limiter": "instruction issue / latency, not HBM (integer and bitset work: see DESIGN.md section 4 and profiles/)"},
+            "roofline_units": {k: {"ms": v[0], "algorithmic_bytes": int(v[1]), "hbm_frac": (v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else 0.0)}
+                               for k, v in units.items()},
+            "pass_hbm_frac": sum(v[1] for v in units.values()) / t_pass / 1e9 / HBM_PEAK_GBS,
+            "valu_issue": None if not valu else {
+                "wave_instructions_per_pass": int(sum(valu.values())), "source": traffic_src,
+                "peak_per_s": VALU_PEAK_PER_S, "pass_frac": sum(valu.values()) / t_pass / VALU_PEAK_PER_S,
+                "note": "SQ_INSTS_VALU of every kernel of one pass (committed PMC summary) over the live pass time, against 256 CUs x 4 SIMDs x "
+                        "one wave64 VALU instruction per 2 cycles x 2.4 GHz: the pass is integer / bitset work bound by instruction issue and latency"},
             "kernels_ms": {k: v[0] for k, v in kern.items()},
             "kernels_note": "k2l_window_lanes (its two launches) and k2w_window_rows run side by side on separate streams after k2a (and k2_window_replay beside k2a): "
                             "their intervals overlap; k2_window_phase_ms is the wall time of that phase",

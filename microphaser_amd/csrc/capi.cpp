@@ -142,7 +142,8 @@ int mp_batch_create(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window
             uint64_t wsteps = 0, simple = 0, nostop = 0;
             for (const ExonW& e : b->batch.exons_w) wsteps += e.n_steps;
             for (const WinStatic& w : b->batch.wins) { simple += (w.flags & WSF_SIMPLE) ? 1 : 0; nostop += (w.flags & WSF_NOSTOP) ? 1 : 0; }
-            std::fprintf(stderr, "[mp] windows: %zu, simple %llu, no-stop %llu\n", b->batch.wins.size(), (unsigned long long)simple, (unsigned long long)nostop);
+            std::fprintf(stderr, "[mp] windows: %zu, simple %llu, no-stop %llu; record capacity %u nt (records of %u bytes)\n", b->batch.wins.size(),
+                         (unsigned long long)simple, (unsigned long long)nostop, b->batch.seq_cap, hap_rec_stride(b->batch.seq_cap));
             std::fprintf(stderr, "[mp] plan: %zu transcripts, %zu steps, %zu windows; sequential replay: %zu segments (longest %u steps); "
                          "window-parallel: %zu exons, %llu steps, %zu work items, %llu admission entries\n", b->batch.tx.size(),
                          b->batch.steps.size(), b->batch.wins.size(), b->batch.segs.size(), mx, b->batch.exons_w.size(),

@@ -183,9 +183,17 @@ struct PlannerHooksT {
             if (v.kind == VK_INS) max_len += v.len;
             if (v.kind == VK_DEL) max_len += v.len;
             if (v.kind != VK_SNV) non_snv = true;
-            // the inner loop of the walk has no window bound: a run of adjacent columns starting at the window's last base is
-            // applied past window_end, one more base each (stale columns of '-' exons and `normal` epochs sit there)
-            if (v.pos >= uint64_t(st.sso) + st.wlen) max_len += 1;
+        }
+        {   // the inner loop of the walk has no window bound: a run of ADJACENT columns starting at the window's last base is applied past
+            // window_end, one more base each (stale columns of '-' exons and `normal` epochs sit there) - so only the columns at
+            // window_end, window_end + 1, ... without a gap can add a base (K3 flags a record that outgrows its capacity all the same)
+            const uint64_t wend = uint64_t(st.sso) + st.wlen;
+            for (uint64_t p = wend;; p++) {
+                uint32_t here = 0;
+                for (uint32_t c : cols) here += vars[c].pos == p;
+                if (!here) break;
+                max_len += here;
+            }
         }
         b.wins.back().need_recs = uint8_t(((NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0) | (walk_prefix << WS_PREFIX_SHIFT));  // `normal` emits every haplotype
         if (NORMAL) max_len += 1;  // the unconditional trailing base (src/normal_microphasing.rs:476)
