@@ -258,7 +258,8 @@ class Context:
 
     def load(self, bam, vcf, fasta, gtf, unsupported_allele_warning_only=False):
         h = ctypes.c_void_p()
-        self._check(lib().mp_dataset_load(self._h, bam.encode(), vcf.encode(), fasta.encode(), gtf.encode(),
+        # gtf = None: the annotation is read from stdin, as the reference's sub-commands take it
+        self._check(lib().mp_dataset_load(self._h, bam.encode(), vcf.encode(), fasta.encode(), gtf.encode() if gtf is not None else None,
                                           int(unsupported_allele_warning_only), ctypes.byref(h)))
         return Dataset(self, h)
 

@@ -153,3 +153,18 @@ def test_translate_needs_a_gpu(built):
     import microphaser_amd as m
     with pytest.raises(m.MicrophaserError, match="no CPU fallback"):
         m.Context(-1).translate(b"ATGGCC", [0], 2)
+
+
+def test_gtf_on_stdin_like_the_reference_cli(built):
+    """mp_dataset_load with gtf = NULL reads the annotation from stdin (`microphaser somatic ... < genes.gtf`)."""
+    import subprocess
+    import sys
+    p = fixture_paths("test_forward")
+    code = ("import sys; sys.path.insert(0, %r)\nimport microphaser_amd as m\n"
+            "ds = m.Context(-1).load(%r, %r, %r, None)\nprint(ds.num_genes, ds.num_reads)\n" % (ROOT, p["bam"], p["vcf"], p["fasta"]))
+    with open(p["gtf"], "rb") as g:
+        r = subprocess.run([sys.executable, "-c", code], stdin=g, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import microphaser_amd as m
+    ds = m.Context(-1).load(p["bam"], p["vcf"], p["fasta"], p["gtf"])
+    assert r.stdout.split() == [str(ds.num_genes), str(ds.num_reads)]
