@@ -109,6 +109,7 @@ class IndexedFasta : public RefSource {
     // bio::io::fasta::IndexedReader::fetch + read: [start, stop), case preserved.
     void fetch(const std::string& chrom, uint64_t start, uint64_t stop, std::vector<uint8_t>& out) const override;
     bool has(const std::string& chrom) const { return idx_.count(chrom) != 0; }
+    void preload() const { ensure_loaded(); }   // read the file now (fetch does it on first use otherwise)
 
   private:
     struct Entry { uint64_t len, offset, line_bases, line_bytes, region_start, region_len; };

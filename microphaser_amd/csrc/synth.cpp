@@ -407,10 +407,12 @@ void dataset_load_files(const std::string& bam, const std::string& vcf, const st
     // the three inputs are independent: read them concurrently (the BAM inflate and the VCF text parse dominate)
     std::string err_bam, err_vcf;
     std::thread t_bam([&] { try { const auto t0 = clk(); load_bam(bam, ds.bam); ms_bam = since(t0); } catch (const std::exception& e) { err_bam = e.what(); if (err_bam.empty()) err_bam = "error"; } });
-    std::thread t_vcf([&] { try { const auto t0 = clk(); load_vcf(vcf, ds.vcf); ms_vcf = since(t0); } catch (const std::exception& e) { err_vcf = e.what(); if (err_vcf.empty()) err_vcf = "error"; } });
+    std::thread t_vcf([&] { try { const auto t0 = clk(); load_vcf(vcf, ds.vcf); ds.vcf.build_index(); ms_vcf = since(t0); } catch (const std::exception& e) { err_vcf = e.what(); if (err_vcf.empty()) err_vcf = "error"; } });
     std::string err_fa;
     try {
-        ds.fasta = std::make_shared<IndexedFasta>(fasta);
+        auto fa = std::make_shared<IndexedFasta>(fasta);
+        fa->preload();   // the per-gene fetches that follow read from memory: bring the file in while the BAM / VCF threads work
+        ds.fasta = fa;
         std::ostringstream ss;
         ss << gtf.rdbuf();
         ds.gtf = ss.str();
