@@ -188,11 +188,16 @@ struct PlannerHooksT {
             // window_end, one more base each (stale columns of '-' exons and `normal` epochs sit there) - so only the columns at
             // window_end, window_end + 1, ... without a gap can add a base (K3 flags a record that outgrows its capacity all the same)
             const uint64_t wend = uint64_t(st.sso) + st.wlen;
-            for (uint64_t p = wend;; p++) {
-                uint32_t here = 0;
-                for (uint32_t c : cols) here += vars[c].pos == p;
-                if (!here) break;
-                max_len += here;
+            bool at_last_base = false;
+            for (uint32_t c : cols) at_last_base |= vars[c].pos + 1 == wend;
+            if (at_last_base) {   // a set SNV at the last base moves the cursor to window_end: the run there, then one reference base
+                max_len += 1;
+                for (uint64_t p = wend;; p++) {
+                    uint32_t here = 0;
+                    for (uint32_t c : cols) here += vars[c].pos == p;
+                    if (!here) break;
+                    max_len += here;
+                }
             }
         }
         b.wins.back().need_recs = uint8_t(((NORMAL || non_snv || fs_seen) ? WS_ALL_IDS : 0) | (walk_prefix << WS_PREFIX_SHIFT));  // `normal` emits every haplotype
