@@ -227,7 +227,7 @@ def main():
                 continue
             if args.transcripts or world != 1:
                 break
-            hit = [k for k in pt if k.split("<")[0] in dom_kernels and "fetch_bytes_raw" in pt[k]]
+            hit = [k for k in pt if any(k.split("<")[0].startswith(x) for x in dom_kernels) and "fetch_bytes_raw" in pt[k]]   # (k2w_window_rows[_multi|_deep])
             if hit:
                 traffic = sum(pt[k]["fetch_bytes_raw"] + pt[k].get("write_bytes", 0.0) for k in hit)
                 traffic_src = os.path.relpath(path, ROOT)
