@@ -695,24 +695,31 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
     for (uint32_t k = A.step_first + threadIdx.x; k < A.step_first + A.n_steps; k += 64) {
         const uint32_t gi = rbase + k;
         const uint32_t start = d.r_pos[gi], end = d.r_end[gi], rvl = d.r_varlo[gi];
-        uint64_t dirty[W];   // low quality, or support of a start-loss variant
+        uint64_t dirty[W], sup[W];   // dirty: low quality, or support of a start-loss variant
 #pragma unroll
-        for (int w = 0; w < W; w++)
-            dirty[w] = d.r_lq[uint64_t(gi) * W + w] | (d.r_sup[uint64_t(gi) * W + w] & bit_range(e.sl_f_lo, e.sl_f_hi, rvl + 64u * w));
+        for (int w = 0; w < W; w++) {
+            sup[w] = d.r_sup[uint64_t(gi) * W + w];
+            dirty[w] = d.r_lq[uint64_t(gi) * W + w] | (sup[w] & bit_range(e.sl_f_lo, e.sl_f_hi, rvl + 64u * w));
+        }
         AdmEntry out;
         out.ord = 0xFFFFFFFFu;
         out.seen_lo = 0;
         auto try_step = [&](uint32_t si) -> bool {   // push_read at step si (after shrink_left, before extend_right)
-            const Step st = d.steps[si];
-            if (end < st.sso + uint32_t(st.wlen) || start > st.sso) return false;
+            // everything the decision needs is fetched in ONE round of loads and the decision itself is branch-free: with an early
+            // return after the window test the compiler fetches the column fields only afterwards - a second dependent round trip
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + si);
+            const uint32_t s_sso = sp[0], s_col_hi = sp[2], s_w4 = sp[4], s_w5 = sp[5];   // [4]: cand_n | wlen << 16 | n_del << 24; [5]: n_add | ...
             const uint32_t nc = d.step_ncols[si];
-            const uint32_t tlo = st.col_hi - nc, thi = st.col_hi - st.n_add;
+            const uint32_t s_wlen = (s_w4 >> 16) & 0xFFu, s_nadd = s_w5 & 0xFFu;
+            const uint32_t tlo = s_col_hi - nc, thi = s_col_hi - s_nadd;
             uint32_t flo, fhi;
             tr_to_f(e, is_rev, tlo, thi, flo, fhi);
-            if (mask_hits<W>(dirty, flo, fhi, rvl)) return false;
-            out.ord = si;
-            out.seen_lo = tlo;
-            return true;
+            const bool encloses = !(end < s_sso + s_wlen) & !(start > s_sso);
+            const bool clean = !mask_hits<W>(dirty, flo, fhi, rvl);
+            const bool ok = encloses & clean;
+            out.ord = ok ? si : out.ord;
+            out.seen_lo = ok ? tlo : out.seen_lo;
+            return ok;
         };
         if (!is_rev) {
             if (start >= e.first_key_lo && start <= sso0) {
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
                 a.bad_from = bad_from;
                 a.rvl = rvl;
                 d.rr_a[uint64_t(e.adm_off) + k] = a;
-                d.rr_sup[uint64_t(e.adm_off) + k] = d.r_sup[gi];
+                d.rr_sup[uint64_t(e.adm_off) + k] = sup[0];
             }
         }
     }
