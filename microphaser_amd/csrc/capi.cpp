@@ -238,17 +238,18 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 st->k2l_ms = t.k2l_ms; st->n_windows_lane = lane_wins; st->n_windows_wave = wave_wins;
                 // the lane kernel writes a Group per group; window / record index / K3-list entry only for the groups it hands on to K3
                 const uint64_t listed_l = t.n_k3 > (t.n_groups - groups_l) ? t.n_k3 - (t.n_groups - groups_l) : 0;
-                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * sizeof(Group) + listed_l * 12;
+                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * sizeof(Group) + listed_l * 16;
                 st->bytes_k2w = wave_steps * (sizeof(Step) + 7) + uint64_t(double(b.n_adm) * wave_share) * (read_bytes + sizeof(AdmEntry)) +
-                                wave_wins * sizeof(WinDyn) + (groups_w - groups_l) * (sizeof(Group) + 8);
+                                wave_wins * sizeof(WinDyn) + (groups_w - groups_l) * (sizeof(Group) + 16);
                 st->bytes_k2seq = seq_steps * sizeof(Step) + (b.steps.empty() ? 0 : uint64_t(double(b.r_pos.size()) * double(seq_steps) / double(b.steps.size()))) * read_bytes +
-                                  seq_wins * sizeof(WinDyn) + groups_seq * (sizeof(Group) + 8);
+                                  seq_wins * sizeof(WinDyn) + groups_seq * (sizeof(Group) + 16);
                 st->bytes_k2 = st->bytes_k2a + st->bytes_k2l + st->bytes_k2w + st->bytes_k2seq;
             }
             st->n_groups_k3 = t.n_k3;
             // K3 looks at the listed groups only; their windows' static records / reference bytes / columns are shared out by the listed share
             const double k3_share = t.n_groups ? double(t.n_k3) / double(t.n_groups) : 0.0;
-            st->bytes_k3 = t.n_k3 * (4 + sizeof(Group) + 4 + 4 + sizeof(GroupSum)) +
+            st->bytes_k3 = t.n_k3 * (16 + 8 + sizeof(GroupSum)) +   // item, haplotype word, summary
+                          
                            uint64_t(k3_share * double(b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols)) + t.n_recs * hap_rec_stride(b.seq_cap);
             st->bytes_k3b = t.n_recs * (32 + b.seq_cap + 8);
             st->hbm_bytes = dev.hbm_bytes();

@@ -57,7 +57,7 @@ void DeviceContext::free_outputs() {
     out_allocs_.clear();
     hbm_bytes_ -= out_bytes_;
     out_bytes_ = 0;
-    d_.groups = nullptr; d_.g_win = nullptr; d_.g_rec = nullptr; d_.k3_list = nullptr; d_.gsum = nullptr; d_.recs = nullptr; d_.want_recs = nullptr;
+    d_.groups = nullptr; d_.k3_items = nullptr; d_.gsum = nullptr; d_.recs = nullptr; d_.want_recs = nullptr;
 }
 
 void DeviceContext::free_batch() {
@@ -184,9 +184,7 @@ void DeviceContext::alloc_outputs() {
     rec_cap_ = uint64_t(NPART) << rlog_;
     auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); out_bytes_ += bytes; return p; };
     d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
-    d_.g_win = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
-    d_.g_rec = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
-    d_.k3_list = static_cast<uint32_t*>(oalloc(group_cap_ * 4));
+    d_.k3_items = static_cast<uint4*>(oalloc(group_cap_ * sizeof(uint4)));
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
     d_.recs = static_cast<uint8_t*>(oalloc(rec_cap_ * d_.rec_stride));
     d_.want_recs = static_cast<uint32_t*>(oalloc(rec_cap_ * 4));

@@ -185,10 +185,10 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t lane) { 
 constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: one emit call)
 
 // K2 -> K3: the group slots K3 has to look at are appended to a dense list per output allocator (list p lives at
-// k3_list[p << group_part_log2 ...], its length in cursors[p * 32 + 8]); one wave-aggregated atomic per call. The lane-per-window
+// k3_items[p << group_part_log2 ...], its length in cursors[p * 32 + 8]); one wave-aggregated atomic per call. The lane-per-window
 // kernel settles most groups itself (no somatic column set, simple window without a possible stop: GroupSum = {GS_VALID}) and lists
 // only the rest, so K3 runs over ~1/5 of the groups instead of all of them and no longer scans (or needs cleared) unused slots.
-__device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, bool on, uint64_t slot) {
+__device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, bool on, uint64_t slot, uint32_t win, uint32_t rec) {
     const uint64_t m = __ballot(on);
     if (!m) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -196,7 +196,9 @@ __device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, 
     unsigned long long base = 0;
     if (lane == leader) base = atomicAdd(d.cursors + part * 32 + 8, (unsigned long long)__popcll(m));
     const uint64_t b0 = (uint64_t(rdlane(uint32_t(base >> 32), leader)) << 32) | rdlane(uint32_t(base), leader);
-    if (on) d.k3_list[(uint64_t(part) << d.group_part_log2) + b0 + lanes_below(m, lane)] = uint32_t(slot);   // (a list is as long as its slots at most)
+    // one 16-byte item per listed group: its slot, its window and the record slot K2 reserved (0xFFFFFFFF = none) - K3 fetches the
+    // window's static record straight from the item, without a hop through per-group arrays (a list is as long as its slots at most)
+    if (on) d.k3_items[(uint64_t(part) << d.group_part_log2) + b0 + lanes_below(m, lane)] = make_uint4(uint32_t(slot), win, rec, 0u);
 }
 
 template <int RPL>
@@ -537,10 +539,8 @@ __global__ __launch_bounds__(64) void k2_window_replay(DeviceBatch d) {
                     if (on && can_write) {
                         Group G; G.hap = key; G.count = cnt; G.aux = ka;
                         d.groups[gi] = G;
-                        d.g_win[gi] = win;
-                        d.g_rec[gi] = rec;
                     }
-                    k3_enqueue(d, part, on && can_write, gi);
+                    k3_enqueue(d, part, on && can_write, gi, win, rec);
                 };
                 if constexpr (RPL == 1) {
                     // <= 64 rows: (1) leader loop - pick any remaining row, ballot the rows with the same key (its count),
@@ -969,11 +969,8 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                             const bool settled = trivial && !need;   // what K3 would find: valid, no stop, mutant == germline, no record
                             Group G; G.hap = key; G.count = cnt; G.aux = settled ? GROUP_SETTLED : 0u;
                             d.groups[gslot] = G;
-                            if (!settled) {   // the rest is for K3 only
-                                d.g_win[gslot] = win;
-                                d.g_rec[gslot] = (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu;
-                                d.k3_list[lslot++] = uint32_t(gslot);
-                            }
+                            if (!settled)   // the rest is for K3 only: one item (k3_enqueue's layout)
+                                d.k3_items[lslot++] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
                         }
                         gslot++;
                         rslot += need ? 1u : 0u;
@@ -1189,12 +1186,10 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
                 if (on && can_write) {
                     Group G; G.hap = key; G.count = cnt_s; G.aux = 0;
                     d.groups[gbase + rank] = G;
-                    d.g_win[gbase + rank] = win;
-                    d.g_rec[gbase + rank] = rec;
                 }
                 // (settling the trivial groups here as K2l does - one more dependent load per window for the window's flag - cost this
                 //  kernel more than it saved K3: measured 0.53 -> 0.59 ms against no change in K3)
-                k3_enqueue(d, part, on && can_write, gbase + rank);
+                k3_enqueue(d, part, on && can_write, gbase + rank, win, rec);
             }
             if (lane == 0) {
                 WinDyn wd;
@@ -1380,10 +1375,8 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
                 if (on && can_write) {
                     Group G; G.hap = key; G.count = cnt; G.aux = 0;
                     d.groups[gi] = G;
-                    d.g_win[gi] = win;
-                    d.g_rec[gi] = rec;
                 }
-                k3_enqueue(d, part, on && can_write, gi);
+                k3_enqueue(d, part, on && can_write, gi, win, rec);
             };
             // ---- count phase of print_haplotypes (:383-411): the haplotype words of the rows that are not bad are compacted into
             // LDS, sorted (bitonic, one wave, 32-bit keys when the window has at most 32 columns) and run-length counted - ascending
@@ -1596,10 +1589,8 @@ __global__ __launch_bounds__(64) void k2w_window_rows_deep(DeviceBatch d) {
             if (on && can_write) {
                 Group G; G.hap = key; G.count = cnt; G.aux = 0;
                 d.groups[gbase + g] = G;
-                d.g_win[gbase + g] = win;
-                d.g_rec[gbase + g] = rec;
             }
-            k3_enqueue(d, part, on && can_write, gbase + g);
+            k3_enqueue(d, part, on && can_write, gbase + g, win, rec);
         }
         if (lane == 0) {
             WinDyn wd;
@@ -1895,11 +1886,9 @@ __global__ __launch_bounds__(64) void k2n_window_replay(DeviceBatch d) {
                         for (uint32_t j = 0; j < ng; j++) rank += skey[j] < key ? 1u : 0u;
                         Group G; G.hap = key; G.count = scnt[g]; G.aux = 0;
                         d.groups[gbase + rank] = G;
-                        d.g_win[gbase + rank] = win;
-                        const uint64_t rec = rec_pos + rank;
-                        d.g_rec[gbase + rank] = rec < rpart_hi ? uint32_t(rec) : 0xFFFFFFFFu;
                     }
-                    k3_enqueue(d, part, g < ng, gbase + g);   // (the slots [gbase, gbase + ng) in any order)
+                    // (the slots [gbase, gbase + ng) in any order; slot gbase + x owns record rec_pos + x)
+                    k3_enqueue(d, part, g < ng, gbase + g, win, rec_pos + g < rpart_hi ? uint32_t(rec_pos + g) : 0xFFFFFFFFu);
                 }
                 rec_pos += ng;
                 chunk_pos += ng;
@@ -2073,15 +2062,17 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
     const uint64_t li = tile * K3_THREADS + tid;   // index into the K2 kernels' lists of group slots (k3_enqueue)
     const uint64_t lpos = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // (wave-level: every lane takes part)
-    const uint64_t g = li < n_slots ? d.k3_list[lpos] : 0;
+    // the item K2 listed: group slot, window, reserved record slot (one 16-byte load, at a clamped index for the lanes past the end)
+    const uint4 item = d.k3_items[li < n_slots ? lpos : 0];
+    const uint64_t g = li < n_slots ? item.x : 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
     uint8_t* germ = seq + SEQ_CAP;
-    const uint32_t w = li < n_slots ? d.g_win[g] : 0xFFFFFFFFu;
-    // the other two per-slot loads do not depend on the window: issue them now (unused slots hold defined junk)
-    const uint64_t hap_pre = li < n_slots ? d.groups[g].hap : 0;
-    const uint32_t rec_pre = li < n_slots ? d.g_rec[g] : 0xFFFFFFFFu;
+    const uint32_t w = li < n_slots ? item.y : 0xFFFFFFFFu;
+    const uint32_t rec_pre = li < n_slots ? item.z : 0xFFFFFFFFu;
+    // the haplotype word is fetched beside the window's static record (both addresses come from the item)
+    const uint64_t hap_pre = d.groups[g].hap;
     const bool live = w != 0xFFFFFFFFu;
     uint32_t sumflags = 0;
     bool need_rec = false;
@@ -2319,7 +2310,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
 // ('+') / LAST ('-') codon of the peptide slice. germ_len is 0; the germ area's first 8 bytes hold the somatic subset of
 // the variant profile.
 template <int SEQ_CAP>
-__device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_slots, uint64_t g, bool valid, uint32_t& recidx) {
+__device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_slots, uint64_t g, uint32_t item_win, uint32_t item_rec, bool valid,
+                                            uint32_t& recidx) {
     constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
     const uint32_t tid = threadIdx.x;
     recidx = 0;
@@ -2327,7 +2319,7 @@ __device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
     uint8_t* seq = refb + K3_REFCAP;
     uint32_t* germ_dw = slot + (K3_REFCAP + SEQ_CAP) / 4;
-    const uint32_t w = valid ? d.g_win[g] : 0xFFFFFFFFu;
+    const uint32_t w = valid ? item_win : 0xFFFFFFFFu;
     if (w == 0xFFFFFFFFu) return 0;
     const WinStatic ws = d.wins[w];
     const uint32_t vbase = ws.vbase;
@@ -2413,7 +2405,7 @@ __device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_
     if (nhi - nlo >= 3) stop = is_rev ? stop_codon_at(seq, nhi - 3, false) : stop_codon_at(seq, nlo, true);
     const bool skipped = stop && ws.splice_pos != 2;   // :503-507: such a haplotype produces nothing
     uint32_t sumflags = GS_VALID | (stop ? GS_STOP : 0) | (insertion ? GS_INSERTION : 0) | (ns > uint32_t(SEQ_CAP) ? uint32_t(GS_BROKE) : 0u);
-    const uint32_t slot_idx = d.g_rec[g];
+    const uint32_t slot_idx = item_rec;
     if (slot_idx != 0xFFFFFFFFu) {
         uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
         germ_dw[0] = uint32_t(prof_som); germ_dw[1] = uint32_t(prof_som >> 32);
@@ -2444,9 +2436,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
         const uint64_t li = tile * K3_THREADS + threadIdx.x;
         const uint64_t lpos = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // (wave-level: every lane takes part)
-    const uint64_t g = li < n_slots ? d.k3_list[lpos] : 0;   // the K2 kernels' lists of group slots
+        const uint4 item = d.k3_items[li < n_slots ? lpos : 0];   // the K2 kernels' lists: group slot, window, record slot
         uint32_t recidx;
-        const uint32_t sumflags = k3n_one<SEQ_CAP>(d, lds_slots, g, li < n_slots, recidx);
+        const uint32_t sumflags = k3n_one<SEQ_CAP>(d, lds_slots, item.x, item.y, item.z, li < n_slots, recidx);
         append_wanted(d, (sumflags & GS_ID_VALID) != 0, recidx);   // wave-level: every lane takes part
     }
 }

@@ -63,9 +63,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     // K2 output
     WinDyn* win_dyn;
     Group* groups;
-    uint32_t* g_win;              // window of each group slot (0xFFFFFFFF = unused slot)
-    uint32_t* g_rec;              // HapRec slot reserved for the group by K2 (0xFFFFFFFF = none)
-    uint32_t* k3_list;            // K2 -> K3: NPART dense lists of the group slots K3 has to look at (kernels.hip k3_enqueue)
+    uint4* k3_items;              // K2 -> K3: NPART dense lists of 16-byte items {group slot, window, record slot K2 reserved or 0xFFFFFFFF, 0} (kernels.hip k3_enqueue)
     uint32_t* want_recs;          // K3: NPART dense lists of the records that need a SHA-1 id (K3b runs over them)
     const unsigned long long* want_prefix;   // after K3: [p] = number of entries in the lists < p (NPART + 1 entries)
     // Output slots are handed out by NPART independent allocators (a wave uses allocator blockIdx & (NPART - 1)), each with
