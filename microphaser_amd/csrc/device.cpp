@@ -154,9 +154,6 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);
     d_.win_dyn = static_cast<WinDyn*>(dalloc(size_t(d_.n_wins) * sizeof(WinDyn))); allocs_.push_back(d_.win_dyn);
     d_.cursors = static_cast<unsigned long long*>(dalloc((NPART * 32 + 16) * 8)); allocs_.push_back(d_.cursors);
-    part_prefix_ = static_cast<unsigned long long*>(dalloc(2 * (NPART + 1) * 8)); allocs_.push_back(part_prefix_);
-    d_.part_prefix = part_prefix_;
-    d_.want_prefix = part_prefix_ + (NPART + 1);
     d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
@@ -198,7 +195,7 @@ void DeviceContext::run(RunTiming& t) {
     HIP_OK(hipSetDevice(device_));
     t = RunTiming();
     // One pass = one stream of launches with a single host synchronisation at its end: the counts the later kernels need (used group
-    // slots, records that want an id) stay on the device (k_partition_prefix). Only then are the allocators' cursors and the error
+    // slots, records that want an id) stay on the device (the allocators' cursors, read by K3 / K3b themselves). Only then are the cursors and the error
     // word read; an overflow grows the buffers (or the rows per lane) and runs the pass again.
     for (int attempt = 0; attempt < 8; attempt++) {
         t.attempts = uint32_t(attempt + 1);
@@ -234,10 +231,8 @@ void DeviceContext::run(RunTiming& t) {
         // (their grids cover an upper bound of the counts: the previous pass's counts of this batch plus a margin, else an estimate)
         const uint64_t slot_bound = last_slots_ ? last_k3_ + last_k3_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 8 + 65536);
         const uint64_t want_bound = last_slots_ ? last_want_ + last_want_ / 16 + 4096 : std::min<uint64_t>(rec_cap_, uint64_t(d_.n_wins) * 2 + 65536);
-        launch_partition_prefix(d_, false, stream_);
         launch_k3_window_seq(d_, slot_bound, stream_);
         HIP_OK(hipEventRecord(ev_[3], stream_));
-        launch_partition_prefix(d_, true, stream_);
         launch_k3b_haplotype_ids(d_, want_bound, stream_);
         HIP_OK(hipEventRecord(ev_[4], stream_));
         std::vector<unsigned long long> cur(NPART * 32);

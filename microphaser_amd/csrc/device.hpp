@@ -71,7 +71,6 @@ class DeviceContext {
     uint64_t group_cap_ = 0, rec_cap_ = 0;          // NPART << log2
     uint32_t glog_ = 12, rlog_ = 12;                // log2 of one allocator's sub-range
     uint64_t used_g_[NPART] = {0}, used_r_[NPART] = {0};   // slots used by each allocator in the last run()
-    unsigned long long* part_prefix_ = nullptr;
     int rpl_ = 1;
     uint32_t max_rows_bound_ = 0;
     uint64_t last_slots_ = 0, last_recs_ = 0, last_want_ = 0, last_k3_ = 0;

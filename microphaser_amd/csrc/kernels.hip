@@ -1919,31 +1919,6 @@ __device__ __forceinline__ uint8_t to_lower(uint8_t c) { return is_upper(c) ? ui
 __device__ __forceinline__ uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? uint8_t(c - 32) : c; }
 __device__ __forceinline__ uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
-// li-th used entry overall -> (allocator p, offset): the used entries of allocator p are counted by prefix[p] .. prefix[p + 1].
-// Every lane holds one of the NPART = 64 prefix values, so the search is one load + one ballot per wave; lanes of a wave
-// that straddles an allocator boundary move on with readlanes.
-__device__ __forceinline__ void locate_in_parts(const unsigned long long* prefix, uint64_t li, uint64_t wave_first, bool valid,
-                                                uint32_t& part, uint64_t& offset) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t pre = prefix[lane];
-    const uint32_t p0 = uint32_t(__popcll(__ballot(pre <= wave_first))) - 1u;   // prefix[0] = 0: at least one lane votes
-    auto pre_of = [&](uint32_t q) { return (uint64_t(rdlane(uint32_t(pre >> 32), q)) << 32) | rdlane(uint32_t(pre), q); };
-    part = p0;
-    uint64_t base = pre_of(p0);
-    for (uint32_t q = p0 + 1; q < NPART; q++) {
-        const uint64_t nb = pre_of(q);
-        if (__ballot(valid && li >= nb) == 0) break;
-        if (li >= nb) { part = q; base = nb; }
-    }
-    offset = li - base;
-}
-__device__ __forceinline__ uint64_t slot_of(const DeviceBatch& d, uint64_t li, uint64_t wave_first, bool valid) {
-    uint32_t p;
-    uint64_t off;
-    locate_in_parts(d.part_prefix, li, wave_first, valid, p, off);
-    return (uint64_t(p) << d.group_part_log2) + off;
-}
-
 // K3 -> K3b: the records that need a SHA-1 id are appended to a dense list, one wave-aggregated atomic per wave on the
 // wave's own allocator (same NPART scheme as the output slots; list p lives at want_recs[p << rec_part_log2 ...]).
 __device__ __forceinline__ void append_wanted(const DeviceBatch& d, bool want, uint32_t rec_slot) {
@@ -1951,7 +1926,7 @@ __device__ __forceinline__ void append_wanted(const DeviceBatch& d, bool want, u
     if (!m) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t leader = uint32_t(__builtin_ctzll(m));
-    const uint32_t part = blockIdx.x & (NPART - 1);
+    const uint32_t part = (blockIdx.x + blockIdx.y) & (NPART - 1);
     unsigned long long base = 0;
     if (lane == leader) base = atomicAdd(d.cursors + part * 32 + 24, (unsigned long long)__popcll(m));
     const uint64_t b0 = (uint64_t(rdlane(uint32_t(base >> 32), leader)) << 32) | rdlane(uint32_t(base), leader);
@@ -2057,13 +2032,15 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
     const uint32_t tid = threadIdx.x;
-    // the number of used group slots is only known on the device (k_partition_prefix after K2): a fixed grid walks them in turn
-    const uint64_t n_slots = d.part_prefix[NPART];
+    // blockIdx.y = the output allocator whose list this workgroup walks; the list's length is only known on the device - one scalar
+    // load of its cursor (no prefix table, no search) - and the grid's x extent covers the host's upper bound of it
+    const uint32_t lpart = blockIdx.y;
+    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + 8], 1ull << d.group_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
-    const uint64_t li = tile * K3_THREADS + tid;   // index into the K2 kernels' lists of group slots (k3_enqueue)
-    const uint64_t lpos = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // (wave-level: every lane takes part)
+    const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue)
+    const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + li;
     // the item K2 listed: group slot, window, reserved record slot (one 16-byte load, at a clamped index for the lanes past the end)
-    const uint4 item = d.k3_items[li < n_slots ? lpos : 0];
+    const uint4 item = d.k3_items[li < n_slots ? lpos : (uint64_t(lpart) << d.group_part_log2)];
     const uint64_t g = li < n_slots ? item.x : 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
@@ -2432,11 +2409,12 @@ __device__ __forceinline__ uint32_t k3n_one(const DeviceBatch& d, uint32_t* lds_
 template <int SEQ_CAP>
 __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d) {
     __shared__ uint32_t lds_slots[K3_THREADS * K3Cfg<SEQ_CAP>::SLOT_DW];
-    const uint64_t n_slots = d.part_prefix[NPART];
+    const uint32_t lpart = blockIdx.y;   // (as in k3_window_seq: one allocator's list per grid row)
+    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + 8], 1ull << d.group_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
         const uint64_t li = tile * K3_THREADS + threadIdx.x;
-        const uint64_t lpos = slot_of(d, li, tile * K3_THREADS, li < n_slots);   // (wave-level: every lane takes part)
-        const uint4 item = d.k3_items[li < n_slots ? lpos : 0];   // the K2 kernels' lists: group slot, window, record slot
+        const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + li;
+        const uint4 item = d.k3_items[li < n_slots ? lpos : (uint64_t(lpart) << d.group_part_log2)];   // the K2 kernels' lists: group slot, window, record slot
         uint32_t recidx;
         const uint32_t sumflags = k3n_one<SEQ_CAP>(d, lds_slots, item.x, item.y, item.z, li < n_slots, recidx);
         append_wanted(d, (sumflags & GS_ID_VALID) != 0, recidx);   // wave-level: every lane takes part
@@ -2461,14 +2439,12 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) 
         byte_text[v] = (txt << 8) | (n + 2);
     }
     __syncthreads();
-    const uint64_t n_recs = d.want_prefix[NPART];   // known on the device only (k_partition_prefix after K3)
+    const uint32_t wp = blockIdx.y;      // the list of wanted records this workgroup walks; its length: one scalar load (known on the device only)
+    const uint64_t n_recs = min((unsigned long long)d.cursors[wp * 32 + 24], 1ull << d.rec_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3B_THREADS < n_recs; tile += gridDim.x) {
-    const uint64_t li = tile * K3B_THREADS + threadIdx.x;   // index into the dense lists of records that need an id
-    uint32_t wp;       // li-th wanted record overall -> list wp, offset woff
-    uint64_t woff;
-    locate_in_parts(d.want_prefix, li, tile * K3B_THREADS + (threadIdx.x & ~63u), li < n_recs, wp, woff);
+    const uint64_t li = tile * K3B_THREADS + threadIdx.x;   // index into this list
     if (li >= n_recs) continue;
-    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + woff];
+    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + li];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
     // everything the id needs sits in the record K3 wrote (header: sequence length, window offset, transcript; then the sequence):
     // one contiguous read instead of record -> window -> transcript hops, issued at once
@@ -2546,24 +2522,6 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) 
     rec[2] = uint32_t(id60);
     rec[3] = uint32_t(id60 >> 32);
     }   // tiles of this wave
-}
-
-// The output allocators' cursors (kernels.hpp NPART) -> exclusive prefix sums, on the device: K3 / K3b walk the used slots of
-// all allocators as one dense index space without the host having to read the cursors in the middle of a pass.
-// which = 8: lengths of the K2 kernels' lists of group slots for K3 -> part_prefix; which = 24: lengths of K3's wanted lists -> want_prefix.
-__global__ __launch_bounds__(64) void k_partition_prefix(DeviceBatch d, uint32_t which, unsigned long long* out, uint64_t part_size) {
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long used = min((unsigned long long)d.cursors[lane * 32 + which], (unsigned long long)part_size);   // an overflowing allocator: flagged elsewhere
-    uint32_t lo = uint32_t(used), hi = uint32_t(used >> 32);
-    unsigned long long incl = used;
-#pragma unroll
-    for (uint32_t off = 1; off < 64; off <<= 1) {
-        const uint32_t ulo = __shfl_up(uint32_t(incl), off), uhi = __shfl_up(uint32_t(incl >> 32), off);
-        if (lane >= off) incl += (uint64_t(uhi) << 32) | ulo;
-    }
-    (void)lo; (void)hi;
-    out[lane] = incl - used;
-    if (lane == 63) out[NPART] = incl;
 }
 
 // ====================================================================== launchers
@@ -2676,18 +2634,13 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipS
     }
 }
 
-static_assert(NPART == 64, "k_partition_prefix is one wave");
-void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t stream) {
-    if (want_lists) hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 24u, const_cast<unsigned long long*>(d.want_prefix), uint64_t(1) << d.rec_part_log2);
-    else hipLaunchKernelGGL(k_partition_prefix, dim3(1), dim3(64), 0, stream, d, 8u, const_cast<unsigned long long*>(d.part_prefix), uint64_t(1) << d.group_part_log2);
-    HIP_CHECK_LAUNCH();
-}
-
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStream_t stream) {
     if (max_group_slots == 0) return;
     // the grid covers the host's upper bound of the used slots (surplus waves find nothing and leave; were the bound too low, the
     // waves walk the rest in turn - slower, still complete)
-    dim3 grid(uint32_t(std::min<uint64_t>((max_group_slots + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull))), block(K3_THREADS);
+    // one grid row per allocator list; the lists fill evenly (allocator = workgroup index & 63 in the K2 kernels), a quarter more for the spread
+    const uint64_t per_list = max_group_slots / NPART + max_group_slots / (4 * NPART) + K3_THREADS;
+    dim3 grid(uint32_t(std::min<uint64_t>((per_list + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull)), NPART), block(K3_THREADS);
     if (d.normal) {
         switch (d.seq_cap) {
             case 32: hipLaunchKernelGGL(k3_window_seq_normal<32>, grid, block, 0, stream, d); break;
@@ -2711,7 +2664,8 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStr
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {
     if (max_recs == 0) return;
-    dim3 grid(uint32_t(std::min<uint64_t>((max_recs + K3B_THREADS - 1) / K3B_THREADS, 0x7FFFFFFFull))), block(K3B_THREADS);
+    const uint64_t per_list = max_recs / NPART + max_recs / (4 * NPART) + K3B_THREADS;
+    dim3 grid(uint32_t(std::min<uint64_t>((per_list + K3B_THREADS - 1) / K3B_THREADS, 0x7FFFFFFFull)), NPART), block(K3B_THREADS);
     switch (d.seq_cap) {
         case 32: hipLaunchKernelGGL(k3b_haplotype_ids<32>, grid, block, 0, stream, d); break;
         case 48: hipLaunchKernelGGL(k3b_haplotype_ids<48>, grid, block, 0, stream, d); break;

@@ -65,13 +65,11 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     Group* groups;
     uint4* k3_items;              // K2 -> K3: NPART dense lists of 16-byte items {group slot, window, record slot K2 reserved or 0xFFFFFFFF, 0} (kernels.hip k3_enqueue)
     uint32_t* want_recs;          // K3: NPART dense lists of the records that need a SHA-1 id (K3b runs over them)
-    const unsigned long long* want_prefix;   // after K3: [p] = number of entries in the lists < p (NPART + 1 entries)
     // Output slots are handed out by NPART independent allocators (a wave uses allocator blockIdx & (NPART - 1)), each with
     // its own cursors in their own 128-byte lines and its own power-of-two sub-range of the output arrays: slot =
     // (partition << log2 size) + offset. One shared cursor serialises in L2 at ~60 atomics/us - with one wave per run of
     // windows that alone would bound the replay.
     unsigned long long* cursors;  // [p * 32] group-slot cursor of partition p, [p * 32 + 8] length of its K3 list, [p * 32 + 16] record-slot cursor, [p * 32 + 24] length of K3's wanted list p
-    const unsigned long long* part_prefix;   // after K2: [p] = number of K3-list entries of partitions < p (NPART + 1 entries)
     uint32_t group_part_log2, rec_part_log2;
     uint64_t group_cap, rec_cap;  // NPART << log2
     uint32_t* err;                // sticky error word (WD_* bits)
@@ -89,9 +87,8 @@ void launch_k2_admission(const DeviceBatch& d, hipStream_t stream);     // K2a o
 void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream);   // K2w, after K2a
 // K2l, after K2a: the windows of winw; the <= 6-column and the 7-8-column launch are independent and may go to different streams
 void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide);
-// K3 / K3b read the number of used group slots / wanted records from the device (launch_partition_prefix first); the host only
-// passes an upper bound that sizes the fixed grid.
-void launch_partition_prefix(const DeviceBatch& d, bool want_lists, hipStream_t stream);
+// K3 / K3b: one grid row per output allocator; a row reads its list's length from the allocator's cursor on the device, the host only
+// passes an upper bound of the total that sizes the rows.
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStream_t stream);
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream);
 
