@@ -935,15 +935,16 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
             if (lane >= off) scan3 += up;
         }
         const uint32_t tot_3 = rdlane(scan3, 63);
-        unsigned long long gb = 0, rb = 0, lb = 0;
-        if (lane == 0) {
-            gb = atomicAdd(gcur, (unsigned long long)tot_g);
-            if (tot_r) rb = atomicAdd(rcur, (unsigned long long)tot_r);
-            if (tot_3) lb = atomicAdd(gcur + 8, (unsigned long long)tot_3);
+        // the tile's three allocations - group slots, record slots, K3 list entries - in ONE atomic instruction: lanes 0, 1, 2 each add
+        // to their own cursor (three in a row, each under its own condition, were three dependent round trips to L2)
+        unsigned long long got = 0;
+        if (lane < 3) {
+            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : gcur + 8;
+            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : tot_3));
         }
-        const uint64_t gbase = (uint64_t(rdlane(uint32_t(gb >> 32), 0)) << 32) | rdlane(uint32_t(gb), 0);
-        const uint64_t rbase = (uint64_t(rdlane(uint32_t(rb >> 32), 0)) << 32) | rdlane(uint32_t(rb), 0);
-        uint64_t lslot = gpart_lo + ((uint64_t(rdlane(uint32_t(lb >> 32), 0)) << 32) | rdlane(uint32_t(lb), 0)) + (scan3 - n3);
+        const uint64_t gbase = (uint64_t(rdlane(uint32_t(got >> 32), 0)) << 32) | rdlane(uint32_t(got), 0);
+        const uint64_t rbase = (uint64_t(rdlane(uint32_t(got >> 32), 1)) << 32) | rdlane(uint32_t(got), 1);
+        uint64_t lslot = gpart_lo + ((uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2)) + (scan3 - n3);
         const bool can_write = gbase + tot_g <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
