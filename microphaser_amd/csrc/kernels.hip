@@ -989,11 +989,13 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
 
-constexpr uint32_t K2W_ITEMS = 4;
+constexpr uint32_t K2W_ITEMS = 1;       // work items per wave: with the lane kernel taking most windows, the remaining items hold few windows each -
+                                        // one item per wave keeps four times as many waves in flight (window phase 1.14 -> 1.10 ms; four were
+                                        // right while K3 had to skip the unused tail of every wave's last slot chunk)
 constexpr uint32_t K2W_HIST_BITS = 6;   // windows with at most this many columns count their haplotypes in a 64-entry LDS table
 __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
-    constexpr uint32_t GROUP_CHUNK = 64, REC_CHUNK_W = 64;   // small chunks: 64 allocators share the atomics, and the unused
-                                                             // tail of a wave's last chunk is all the slack K3 has to skip
+    constexpr uint32_t GROUP_CHUNK = 64, REC_CHUNK_W = 64;   // small chunks: 64 allocators share the atomics; the unused tail of a
+                                                             // wave's last chunk is capacity only (K3 walks dense lists)
     const uint32_t lane = threadIdx.x;
     // this wave's output allocator (kernels.hpp NPART)
     const uint32_t part = blockIdx.x & (NPART - 1);
@@ -1005,7 +1007,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
     uint32_t sticky_err = 0;
     __shared__ __attribute__((aligned(16))) uint32_t hist[256];
     __shared__ uint2 glist[64];
-    // a wave takes K2W_ITEMS consecutive work items, so that one chunk tail is shared by ~100+ windows
+    // a wave takes K2W_ITEMS consecutive work items
     for (uint32_t item = blockIdx.x * K2W_ITEMS; item < min(d.n_wchunks, (blockIdx.x + 1) * K2W_ITEMS); item++) {
     const WChunk C = d.wchunks[item];
     const ExonW e = d.exons_w[C.exon];
