@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <thread>
 #include "capi_types.hpp"
 #include "kernels_pep.hpp"
 
@@ -267,21 +268,51 @@ int mp_peptides_union(mp_ctx* ctx, const uint64_t* const* keys, const uint64_t* 
         if (L == 0 || L > 12) throw Error("peptide length must be 1..12 for the device peptidome (5-bit residue keys in a u64)");
         std::unique_ptr<mp_peptides> p(new mp_peptides());
         p->res.peptide_len = L;
-        std::vector<uint64_t> acc, tmp;
-        for (uint32_t a = 0; a < n_arrays; a++) {   // pairwise merges of sorted distinct runs
-            const uint64_t* k = keys[a];
-            const uint64_t n = counts[a];
-            for (uint64_t i = 1; i < n; i++)
-                if (k[i] <= k[i - 1]) throw Error("mp_peptides_union: key arrays must be sorted and distinct");
-            tmp.clear();
-            tmp.reserve(acc.size() + n);
-            std::set_union(acc.begin(), acc.end(), k, k + n, std::back_inserter(tmp));
-            acc.swap(tmp);
-        }
-        p->res.keys.swap(acc);
+        // the key range is cut into one slice per host thread at pivots taken from the longest array; every thread checks its share of
+        // the inputs, merges the arrays' parts of its slice (sorted distinct runs: repeated two-way unions) and the slices - disjoint in
+        // key - are joined in order. 70 M keys from eight arrays: 2.6 s sequentially
+        uint32_t longest = 0;
+        for (uint32_t a = 0; a < n_arrays; a++) if (counts[a] > counts[longest]) longest = a;
+        const uint64_t n_long = n_arrays ? counts[longest] : 0;
+        const size_t parts = std::max<size_t>(1, std::min<size_t>(host_threads(), size_t(n_long / 65536 + 1)));
+        std::vector<uint64_t> pivot(parts + 1, 0);           // slice t takes the keys in [pivot[t], pivot[t + 1]); the last one is open
+        for (size_t t = 1; t < parts; t++) pivot[t] = keys[longest][n_long * t / parts];
+        std::vector<std::vector<uint64_t>> slice(parts);
+        std::vector<std::string> errors(parts);
+        std::vector<std::thread> th;
+        auto work = [&](size_t t) {
+            try {
+                std::vector<uint64_t> acc, tmp;
+                for (uint32_t a = 0; a < n_arrays; a++) {
+                    const uint64_t* k = keys[a];
+                    const uint64_t n = counts[a];
+                    const uint64_t* lo = t == 0 ? k : std::lower_bound(k, k + n, pivot[t]);
+                    const uint64_t* hi = t + 1 == parts ? k + n : std::lower_bound(k, k + n, pivot[t + 1]);
+                    for (const uint64_t* q = lo; q < hi; q++)   // (incl. the pair that straddles the slice's lower end)
+                        if (q > k && q[0] <= q[-1]) throw Error("mp_peptides_union: key arrays must be sorted and distinct");
+                    if (lo == hi) continue;
+                    if (acc.empty()) { acc.assign(lo, hi); continue; }
+                    tmp.resize(acc.size() + size_t(hi - lo));
+                    tmp.resize(size_t(std::set_union(acc.begin(), acc.end(), lo, hi, tmp.begin()) - tmp.begin()));
+                    acc.swap(tmp);
+                }
+                slice[t].swap(acc);
+            } catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+        };
+        for (size_t t = 1; t < parts; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (const std::string& e : errors) if (!e.empty()) throw Error(e);
+        std::vector<size_t> at(parts + 1, 0);
+        for (size_t t = 0; t < parts; t++) at[t + 1] = at[t] + slice[t].size();
+        p->res.keys.resize(at[parts]);
+        th.clear();
+        auto copy = [&](size_t t) { if (!slice[t].empty()) std::memcpy(p->res.keys.data() + at[t], slice[t].data(), slice[t].size() * 8); };
+        for (size_t t = 1; t < parts; t++) th.emplace_back(copy, t);
+        copy(0);
+        for (auto& x : th) x.join();
         p->res.n_peptides = p->res.keys.size();
-        p->bin = p->res.binary();
-        *out = p.release();
+        *out = p.release();   // (the bincode image is built on demand: mp_peptides_binary)
     });
 }
 

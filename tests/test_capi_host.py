@@ -168,3 +168,20 @@ def test_gtf_on_stdin_like_the_reference_cli(built):
     import microphaser_amd as m
     ds = m.Context(-1).load(p["bam"], p["vcf"], p["fasta"], p["gtf"])
     assert r.stdout.split() == [str(ds.num_genes), str(ds.num_reads)]
+
+
+def test_peptides_union_in_key_slices_matches_numpy(built):
+    """Arrays long enough for the sliced (multi-threaded) union: equal to numpy's union; an unsorted array is refused wherever the
+    bad pair sits."""
+    import numpy as np
+    import microphaser_amd as m
+    ctx = m.Context(-1)
+    rng = np.random.default_rng(5)
+    arrs = [np.unique(rng.integers(0, 1 << 44, size=n, dtype=np.uint64)) for n in (400000, 250000, 7, 130000)]
+    arrs += [np.zeros(0, dtype=np.uint64), np.array([5], dtype=np.uint64), arrs[0][::3].copy()]
+    u = ctx.peptides_union(arrs, 9)
+    assert np.array_equal(u.keys_np, np.unique(np.concatenate(arrs)))
+    bad = np.arange(1, 400000, dtype=np.uint64)
+    bad[300000] = bad[299999]
+    with pytest.raises(m.MicrophaserError, match="sorted and distinct"):
+        ctx.peptides_union([bad, np.arange(0, 10 ** 6, 3, dtype=np.uint64)], 9)
