@@ -1,6 +1,9 @@
 #!/bin/bash
 # Development aid: single-thread run of a -DMP_PROFILE build of the CLI on a synthetic exome (section cycle counts on stderr).
 #   tools/prof_consumer.sh <binary> [transcripts]
+# The binary: the CLI linked from the library's objects with consume.cpp compiled -DMP_PROFILE, e.g. in microphaser_amd/csrc:
+#   hipcc --offload-arch=gfx950 -std=c++17 -O3 -DMP_PROFILE -c consume.cpp -o /tmp/consume_prof.o && hipcc -O3 -std=c++17 -c cli.cpp -o /tmp/cli.o &&
+#   hipcc --offload-arch=gfx950 -o ../_lib/microphaser_prof /tmp/cli.o /tmp/consume_prof.o $(ls ../_lib/*.o | grep -v consume.o) -lz -lpthread
 set -e
 BIN=${1:-microphaser_amd/_lib/microphaser_prof}
 N=${2:-2000}
