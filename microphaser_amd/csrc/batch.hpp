@@ -39,9 +39,9 @@ struct Batch {
     PodVec<uint64_t> g_ref_off;
     // ---- reads (gene-major, start-sorted, mapq-filtered)
     PodVec<uint32_t> r_pos, r_end, r_lseq, r_ncig, r_dup, r_varlo;
-    PodVec<uint64_t> r_cigoff, r_seqoff, r_qualoff;
+    PodVec<uint64_t> r_cigoff, r_seqoff;   // r_seqoff: dword-aligned start of the read in seq_pool (low-quality bitmap, then 4-bit bases)
     PodVec<uint32_t> cigar_pool;
-    PodVec<uint8_t> seq_pool, qual_pool;
+    PodVec<uint8_t> seq_pool;
     PodVec<size_t> r_src;            // host-only: ReadStore index of each batch read
     // ---- variants
     PodVec<uint32_t> v_pos, v_info, v_len, v_insoff, v_rev2fwd;

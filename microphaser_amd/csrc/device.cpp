@@ -93,10 +93,8 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.r_varlo = up(b.r_varlo);
     d_.r_cigoff = up(b.r_cigoff);
     d_.r_seqoff = up(b.r_seqoff);
-    d_.r_qualoff = up(b.r_qualoff);
     d_.cigar_pool = up(b.cigar_pool);
     d_.seq_pool = up(b.seq_pool);
-    d_.qual_pool = up(b.qual_pool);
     d_.v_pos = up(b.v_pos);
     d_.v_info = up(b.v_info);
     d_.v_len = up(b.v_len);

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     const uint32_t rpos = d.r_pos[i], rend = d.r_end[i], lseq = d.r_lseq[i], ncig = d.r_ncig[i];
     const uint32_t lo = d.r_varlo[i];
     const uint32_t* cig = d.cigar_pool + d.r_cigoff[i];
-    const uint8_t* seq4 = d.seq_pool + d.r_seqoff[i];
-    const uint8_t* qual = d.qual_pool + d.r_qualoff[i];
+    const uint32_t* lowq = reinterpret_cast<const uint32_t*>(d.seq_pool + d.r_seqoff[i]);   // bit k: base quality at read offset k below 10
+    const uint8_t* seq4 = reinterpret_cast<const uint8_t*>(lowq + ((lseq + 31) >> 5));
     // a variant can be a (stale) column of a window the read encloses without lying inside the read's aligned span;
     // bad_quality still indexes the qualities by reference offset (:82-88): cover max(end, start + l_seq)
     const uint32_t cover_end = max(rend, rpos + lseq);
@@ -111,15 +111,17 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             info[r] = d.v_info[at];
         }
         bool cov[K1_ROUNDS], snv[K1_ROUNDS];
-        uint8_t qb[K1_ROUNDS], b4[K1_ROUNDS];
+        bool qb[K1_ROUNDS];
+        uint8_t b4[K1_ROUNDS];
         int rp[K1_ROUNDS];
         const uint32_t last_q = lseq ? lseq - 1 : 0;
-        uint8_t ql[K1_ROUNDS], sl[K1_ROUNDS];
+        uint32_t ql[K1_ROUNDS];
+        uint8_t sl[K1_ROUNDS];
 #pragma unroll
         for (uint32_t r = 0; r < K1_ROUNDS; r++) {   // second level: qualities and (single-M CIGARs: the common case) bases - all issued first
             if (!in[r]) { vpos[r] = 0xFFFFFFFFu; info[r] = 0; }
             const uint32_t relc = min(vpos[r] - rpos, last_q);
-            ql[r] = qual[relc];
+            ql[r] = lowq[relc >> 5];
             sl[r] = seq4[relc >> 1];
         }
 #pragma unroll
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             cov[r] = in[r] && vpos[r] < cover_end;
             snv[r] = cov[r] && (info[r] & VI_KIND_MASK) == 0;
             const uint32_t rel = vpos[r] - rpos;
-            qb[r] = (snv[r] && rel < lseq) ? ql[r] : uint8_t(255);   // the reference indexes the qualities by reference offset (:82-88)
+            qb[r] = snv[r] && rel < lseq && ((ql[r] >> (rel & 31u)) & 1u);   // the reference indexes the qualities by reference offset (:82-88)
             rp[r] = (snv[r] && simple && rel < (c0 >> 4)) ? int(rel) : -1;
             b4[r] = (rp[r] >= 0 && rel < lseq) ? sl[r] : uint8_t(0);
         }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
         for (uint32_t r = 0; r < K1_ROUNDS; r++) {
             bool s = false, q = false;
             if (snv[r]) {  // SNV (:97-112, :80-92)
-                q = !d.normal && qb[r] < 10;  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
+                q = !d.normal && qb[r];  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
                 if (!q) {
                     int p = rp[r];
                     uint8_t byte = b4[r];

@@ -14,9 +14,9 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint64_t* g_ref_off;
     // reads
     const uint32_t *r_gene, *r_pos, *r_end, *r_lseq, *r_ncig, *r_dup;
-    const uint64_t *r_cigoff, *r_seqoff, *r_qualoff;
+    const uint64_t *r_cigoff, *r_seqoff;
     const uint32_t* cigar_pool;
-    const uint8_t *seq_pool, *qual_pool;
+    const uint8_t* seq_pool;      // per read: low-quality bitmap (ceil(l_seq / 32) dwords), then the 4-bit packed bases (plan.cpp)
     // variants
     const uint32_t *v_pos, *v_info, *v_len, *v_insoff, *v_rev2fwd;
     const uint8_t* ins_pool;

@@ -14,6 +14,9 @@
 #include <thread>
 #include <type_traits>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "batch.hpp"
 
 namespace mp {
@@ -599,6 +602,26 @@ static void finalize_segments(Batch& b) {
     validate_segments(b);
 }
 
+// bit k of the appended dwords = quals[k] < 10 (k < n; the last dword is zero-padded)
+static void pack_low_quality(PodVec<uint8_t>& pool, const uint8_t* quals, uint32_t n) {
+    const size_t at = pool.size();
+    const uint32_t words = (n + 31) / 32;
+    pool.resize(at + size_t(words) * 4);
+    uint32_t k = 0;
+    for (uint32_t w = 0; w < words; w++) {
+        uint32_t bits = 0;
+#if defined(__SSE2__)
+        for (uint32_t h = 0; h < 2 && k + 16 <= n; h++, k += 16) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(quals + k));
+            const __m128i le9 = _mm_cmpeq_epi8(_mm_min_epu8(v, _mm_set1_epi8(9)), v);   // unsigned v <= 9
+            bits |= uint32_t(_mm_movemask_epi8(le9)) << (16 * h);
+        }
+#endif
+        for (; k < std::min(n, (w + 1) * 32); k++) bits |= uint32_t(quals[k] < 10) << (k & 31);
+        std::memcpy(pool.data() + at + size_t(w) * 4, &bits, 4);
+    }
+}
+
 static void build_batch_range(const GeneInput* const* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b, bool finalize) {
     const uint8_t mapq_min = normal ? 0 : 5;  // src/microphasing.rs:910 vs src/normal_microphasing.rs:676-684
     b = Batch();
@@ -611,11 +634,10 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
         size_t nr = 0, nref = 0, nv = 0;
         for (size_t g = 0; g < n_genes; g++) { nr += genes[g]->reads.size(); nref += genes[g]->refseq.size(); nv += genes[g]->variants.size(); }
         for (auto* v : {&b.r_pos, &b.r_end, &b.r_lseq, &b.r_ncig, &b.r_dup}) v->reserve(nr);
-        for (auto* v : {&b.r_cigoff, &b.r_seqoff, &b.r_qualoff}) v->reserve(nr);
+        for (auto* v : {&b.r_cigoff, &b.r_seqoff}) v->reserve(nr);
         b.r_src.reserve(nr);
         b.cigar_pool.reserve(nr * 2);
-        b.seq_pool.reserve(nr * 52);
-        b.qual_pool.reserve(nr * 102);
+        b.seq_pool.reserve(nr * 72);
         b.ref_pool.reserve(nref);
         for (auto* v : {&b.v_pos, &b.v_info, &b.v_len, &b.v_insoff, &b.v_rev2fwd}) v->reserve(nv);
         b.steps.reserve(nref);
@@ -647,11 +669,14 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
             b.r_ncig.push_back(rs.n_cigar[r]);
             b.r_cigoff.push_back(b.cigar_pool.size());
             b.cigar_pool.insert(b.cigar_pool.end(), rs.cigar(r), rs.cigar(r) + rs.n_cigar[r]);
+            // per read: the low-quality bitmap (bit k = base quality of read offset k below 10, the only thing bad_quality asks of the
+            // qualities, src/microphasing.rs:78-93; whole dwords), then the 4-bit packed bases, padded to a dword: K1's two gathers per
+            // variant land in one or two cache lines of the read instead of four, and 100 quality bytes per read never travel
             b.r_seqoff.push_back(b.seq_pool.size());
+            pack_low_quality(b.seq_pool, rs.qual(r), rs.l_seq[r]);
             const uint8_t* s4 = rs.seq_pool.data() + rs.seq_off[r];
             b.seq_pool.insert(b.seq_pool.end(), s4, s4 + (rs.l_seq[r] + 1) / 2);
-            b.r_qualoff.push_back(b.qual_pool.size());
-            b.qual_pool.insert(b.qual_pool.end(), rs.qual(r), rs.qual(r) + rs.l_seq[r]);
+            b.seq_pool.resize((b.seq_pool.size() + 3) & ~size_t(3));
             auto key = std::make_pair(rs.pos[r], std::string(rs.qname(r)));
             auto it = first_of.find(key);
             uint32_t dup;
@@ -835,7 +860,7 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
         n.g = c.g + s.genes.size(); n.r = c.r + s.r_pos.size(); n.v = c.v + s.v_pos.size(); n.ins = c.ins + s.ins_pool.size();
         n.t = c.t + s.tx.size(); n.s = c.s + s.steps.size(); n.w = c.w + s.wins.size(); n.wc = c.wc + s.win_cols.size();
         n.e = c.e + s.exons.size(); n.str = c.str + s.str_pool.size(); n.ref = c.ref + s.ref_pool.size();
-        n.cig = c.cig + s.cigar_pool.size(); n.seq = c.seq + s.seq_pool.size(); n.qual = c.qual + s.qual_pool.size();
+        n.cig = c.cig + s.cigar_pool.size(); n.seq = c.seq + s.seq_pool.size();
         b.mask_words = std::max(b.mask_words, s.mask_words);
         b.max_rows_bound = std::max(b.max_rows_bound, s.max_rows_bound);
         b.seq_cap = std::max(b.seq_cap, s.seq_cap);
@@ -847,7 +872,6 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
         throw Error("batch too large for 32-bit indices: split the batch by genes");
     using B = Batch;
     MergeTasks mt;   // largest arrays first
-    mt.add(b.qual_pool, parts, &B::qual_pool);
     mt.add(b.steps, parts, &B::steps, [&o](Step& st, size_t t) { if (st.win != 0xFFFFFFFFu) st.win += uint32_t(o[t].w); st.exon += uint32_t(o[t].e); });
     mt.add(b.seq_pool, parts, &B::seq_pool);
     mt.add(b.wins, parts, &B::wins, [&o](WinStatic& w, size_t t) {
@@ -857,7 +881,6 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
     mt.add(b.r_src, parts, &B::r_src);
     mt.add(b.r_cigoff, parts, &B::r_cigoff, [&o](uint64_t& x, size_t t) { x += o[t].cig; });
     mt.add(b.r_seqoff, parts, &B::r_seqoff, [&o](uint64_t& x, size_t t) { x += o[t].seq; });
-    mt.add(b.r_qualoff, parts, &B::r_qualoff, [&o](uint64_t& x, size_t t) { x += o[t].qual; });
     mt.add(b.step_rlo, parts, &B::step_rlo);
     mt.add(b.cigar_pool, parts, &B::cigar_pool);
     mt.add(b.r_pos, parts, &B::r_pos); mt.add(b.r_end, parts, &B::r_end); mt.add(b.r_lseq, parts, &B::r_lseq);
@@ -942,7 +965,7 @@ void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore&
 }
 
 uint64_t Batch::bytes_k1_in() const {
-    return r_pos.size() * (4 * 5 + 8 * 3) + cigar_pool.size() * 4 + seq_pool.size() + qual_pool.size() + v_pos.size() * 12;
+    return r_pos.size() * (4 * 5 + 8 * 2) + cigar_pool.size() * 4 + seq_pool.size() + v_pos.size() * 12;
 }
 uint64_t Batch::bytes_k1_out() const { return r_pos.size() * (4 + 16ull * mask_words); }
 

@@ -3,7 +3,7 @@
 // verbatim between host code and kernels.hip.
 //
 // Layout in HBM (all struct-of-arrays, gene-major):
-//   reads     : r_pos r_end r_lseq r_ncig r_cigoff r_seqoff r_qualoff r_dup   + cigar/seq/qual pools
+//   reads     : r_pos r_end r_lseq r_ncig r_cigoff r_seqoff r_dup   + cigar pool, seq pool (per read: low-quality bitmap + 4-bit bases)
 //   variants  : v_pos v_info v_len v_insoff (forward = ascending pos, ALT order within a pos)
 //               v_rev2fwd (transcription order of '-' strand genes -> forward index)   + ins pool
 //   refseq    : bytes of [gene.start, gene.end+100) per gene, case preserved
