@@ -77,14 +77,18 @@ void DeviceContext::upload(const Batch& b) {
 void DeviceContext::upload_impl(const Batch& b) {
     HIP_OK(hipSetDevice(device_));
     free_batch();
-    std::vector<uint32_t> r_gene(b.r_pos.size());
-    for (size_t g = 0; g + 1 < b.g_read_off.size(); g++)
-        for (uint32_t i = b.g_read_off[g]; i < b.g_read_off[g + 1]; i++) r_gene[i] = uint32_t(g);
+    // per read, for K1: the absolute index of the first variant at / after the read's start and the number of the gene's variants from
+    // there on - one load instead of the hops read -> gene -> variant range
+    PodVec<uint2> r_var(b.r_pos.size());
+    for (size_t g = 0; g + 1 < b.g_read_off.size(); g++) {
+        const uint32_t vb = b.g_var_off[g], nv = b.g_var_off[g + 1] - vb;
+        for (uint32_t i = b.g_read_off[g]; i < b.g_read_off[g + 1]; i++) r_var[i] = make_uint2(vb + b.r_varlo[i], nv - b.r_varlo[i]);
+    }
     d_.g_read_off = up(b.g_read_off);
     d_.g_var_off = up(b.g_var_off);
     d_.g_start = up(b.g_start);
     d_.g_ref_off = up(b.g_ref_off);
-    d_.r_gene = up(r_gene);
+    d_.r_var = up(r_var);
     d_.r_pos = up(b.r_pos);
     d_.r_end = up(b.r_end);
     d_.r_lseq = up(b.r_lseq);

@@ -72,18 +72,16 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     const uint64_t i_raw = t / K1_LANES;
     const bool valid = i_raw < d.n_reads;
     const uint32_t i = valid ? uint32_t(i_raw) : d.n_reads - 1;              // surplus groups shadow the last read (no stores)
-    const uint32_t g = d.r_gene[i];
-    const uint32_t vbase = d.g_var_off[g];
-    const uint32_t nv = d.g_var_off[g + 1] - vbase;
+    const uint2 rv = d.r_var[i];          // first variant at / after the read's start (absolute index), variants left in the gene
+    const uint32_t vfirst = rv.x;
     const uint32_t rpos = d.r_pos[i], rend = d.r_end[i], lseq = d.r_lseq[i], ncig = d.r_ncig[i];
-    const uint32_t lo = d.r_varlo[i];
     const uint32_t* cig = d.cigar_pool + d.r_cigoff[i];
     const uint32_t* lowq = reinterpret_cast<const uint32_t*>(d.seq_pool + d.r_seqoff[i]);   // bit k: base quality at read offset k below 10
     const uint8_t* seq4 = reinterpret_cast<const uint8_t*>(lowq + ((lseq + 31) >> 5));
     // a variant can be a (stale) column of a window the read encloses without lying inside the read's aligned span;
     // bad_quality still indexes the qualities by reference offset (:82-88): cover max(end, start + l_seq)
     const uint32_t cover_end = max(rend, rpos + lseq);
-    const uint32_t maxn = min(nv - lo, 64u * W);
+    const uint32_t maxn = min(rv.y, 64u * W);
     const uint32_t c0 = ncig > 0 ? cig[0] : 0;
     const bool simple = ncig == 1 && (c0 & 0xF) == 0;  // a single M op: read_pos(p) = p - start
     uint64_t sup[W], lq[W];
@@ -106,7 +104,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
         for (uint32_t r = 0; r < K1_ROUNDS; r++) {
             const uint32_t b = b0 + r * K1_LANES + sub;
             in[r] = more && b < maxn;
-            const uint32_t at = vbase + lo + min(b, last_b);
+            const uint32_t at = vfirst + min(b, last_b);
             vpos[r] = d.v_pos[at];
             info[r] = d.v_info[at];
         }
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             } else if (cov[r]) {  // insertion / deletion: any I / D op of exactly that length (:113-137)
                 const uint32_t b = b0 + r * K1_LANES + sub;
                 const uint32_t want = (info[r] & VI_KIND_MASK) == 1 ? 1u : 2u;
-                const uint32_t vlen = d.v_len[vbase + lo + b];
+                const uint32_t vlen = d.v_len[vfirst + b];
                 for (uint32_t c = 0; c < ncig; c++)
                     if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
             }

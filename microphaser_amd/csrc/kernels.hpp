@@ -13,7 +13,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint32_t *g_read_off, *g_var_off, *g_start;
     const uint64_t* g_ref_off;
     // reads
-    const uint32_t *r_gene, *r_pos, *r_end, *r_lseq, *r_ncig, *r_dup;
+    const uint2* r_var;           // per read: {absolute index of its first variant (g_var_off + r_varlo), variants of the gene from there on}
+    const uint32_t *r_pos, *r_end, *r_lseq, *r_ncig, *r_dup;
     const uint64_t *r_cigoff, *r_seqoff;
     const uint32_t* cigar_pool;
     const uint8_t* seq_pool;      // per read: low-quality bitmap (ceil(l_seq / 32) dwords), then the 4-bit packed bases (plan.cpp)
