@@ -62,7 +62,8 @@ __device__ __forceinline__ uint8_t decode_base4(uint32_t code) {  // BAM 4-bit c
     return uint8_t(((code & 8) ? hi : lo) >> (8 * (code & 7)));
 }
 
-constexpr uint32_t K1_LANES = 4;    // lanes per read (measured at config C: 1 lane 1.40 ms, 2: 1.07, 4: 1.10, 8: 1.31, 16: 1.71)
+constexpr uint32_t K1_LANES = 4;    // lanes per read (measured at config C: 1 lane 1.40 ms, 2: 1.07, 4: 1.10, 8: 1.31, 16: 1.71; with the
+                                    // batched rounds below - lanes x rounds = 2 x 12: 1.00 ms, 4 x 6: 0.75, 8 x 3: 0.88)
 constexpr uint32_t K1_SLICE = (1u << K1_LANES) - 1u;
 template <int W>
 __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {

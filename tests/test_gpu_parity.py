@@ -385,6 +385,33 @@ def test_gpu_config_e_pipeline_matches_oracle(ctx, tmp_path):
     assert (f2.fasta, f2.tsv, f2.removed_tsv) == (f.fasta, f.tsv, f.removed_tsv)
 
 
+def test_gpu_full_size_config_c_matches_the_oracle_verified_checksums(ctx):
+    """BASELINE config C at FULL size (20000 transcripts, 7.8 M windows, 8.8 M TSV rows, 3.5 GB of text): the oracle needs 80 s for it, so
+    the suite compares checksums - the md5 of the three streams recorded in the run in which `oracle_cli somatic` on the same exome
+    produced identical streams (tests/golden/config_c/checksums.json, tools/e2e_cli.py C --md5) - and two size-independent
+    property: a second pass over the resident batch gives the same bytes and window count."""
+    import hashlib
+    gold = json.load(open(os.path.join(GOLDEN, "config_c", "checksums.json")))
+    ds = ctx.synth(gold["seed"], gold["transcripts"], gold["depth"], gold["spacing"])
+    b = ds.batch()
+    b.run()
+    r = b.results()
+    md5 = {k: hashlib.md5(getattr(r, k)).hexdigest() for k in ("fasta", "normal_fasta", "tsv")}
+    assert md5 == gold["md5"]
+    assert r.tsv.count(b"\n") - 1 == gold["tsv_rows"]
+    n_windows = r.windows
+    r.close()
+    b.run()                       # idempotence: the pass again over the same resident inputs
+    r2 = b.results(m_stream_tsv())
+    assert hashlib.md5(r2.tsv).hexdigest() == gold["md5"]["tsv"] and r2.windows == n_windows and r2.fasta == b""
+    r2.close(); b.close()
+
+
+def m_stream_tsv():
+    import microphaser_amd as m
+    return m.STREAM_TSV
+
+
 def test_gpu_results_stream_selection(ctx):
     """mp_batch_results_select: a stream that is not asked for is empty, the others are byte-identical to the full result."""
     import microphaser_amd as m

@@ -37,4 +37,13 @@ if "--no-oracle" not in sys.argv:
     res["identical_outputs"] = all(open(out + "/g" + e, "rb").read() == open(out + "/o" + e, "rb").read() for e in (".fa", ".tsv", ".normal.fa"))
 windows = sum(1 for _ in open(out + "/g.tsv")) - 1
 res["tsv_rows"] = windows
+if "--md5" in sys.argv:   # checksums of the product's streams (golden values for the full-size test once the oracle run beside them agreed)
+    import hashlib
+    def md5(path):
+        h = hashlib.md5()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+    res["md5"] = {"fasta": md5(out + "/g.fa"), "normal_fasta": md5(out + "/g.normal.fa"), "tsv": md5(out + "/g.tsv")}
 print(json.dumps(res))
