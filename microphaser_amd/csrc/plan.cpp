@@ -410,29 +410,51 @@ static void merge_short_segments(Batch& b) {
 
 // The replay kernels trust the plan: check on the host that every segment's column arithmetic stays in range.
 static void validate_segments(const Batch& b) {
+    // (the per-segment walks read every step once: shared out over the host threads)
+    const size_t nparts = std::max<size_t>(1, std::min<size_t>(host_threads(), (b.segs.size() + b.exons_w.size()) / 256 + 1));
+    std::vector<uint64_t> covered_part(nparts, 0);
+    std::vector<std::string> errors(nparts);
+    auto check = [&](size_t t) {
+        try {
+            uint64_t covered = 0;
+            for (size_t i = b.segs.size() * t / nparts, e = b.segs.size() * (t + 1) / nparts; i < e; i++) {
+                const SegDev& g = b.segs[i];
+                if (g.tx >= b.tx.size() || uint64_t(g.step_off) + g.n_steps > b.steps.size()) throw Error("internal error: segment outside the plan");
+                uint32_t ncols = g.init_cols;
+                if (g.n_steps && g.init_cols + b.steps[g.step_off].n_add > b.steps[g.step_off].col_hi) throw Error("internal error: initial columns underflow");
+                for (uint32_t k = 0; k < g.n_steps; k++) {
+                    const Step& st = b.steps[g.step_off + k];
+                    if (st.n_del > ncols) throw Error("internal error: segment drops more columns than it holds");
+                    ncols = ncols - st.n_del + st.n_add;
+                    if (ncols > 63) throw Error("internal error: more than 63 live columns in a segment");
+                    if (st.n_add > st.col_hi) throw Error("internal error: column index underflow in the plan");
+                }
+                covered += g.n_steps;
+            }
+            for (size_t i = b.exons_w.size() * t / nparts, e = b.exons_w.size() * (t + 1) / nparts; i < e; i++) {
+                const ExonW& x = b.exons_w[i];
+                if (uint64_t(x.step_off) + x.n_steps > b.steps.size() || x.tx >= b.tx.size()) throw Error("internal error: window-parallel exon outside the plan");
+                covered += x.n_steps;
+            }
+            for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m, &b.wchunks_d})
+                for (size_t i = list->size() * t / nparts, e = list->size() * (t + 1) / nparts; i < e; i++) {
+                    const WChunk& c = (*list)[i];
+                    if (c.exon >= b.exons_w.size() || c.step_first < b.exons_w[c.exon].step_off ||
+                        uint64_t(c.step_first) + c.n_steps > uint64_t(b.exons_w[c.exon].step_off) + b.exons_w[c.exon].n_steps)
+                        throw Error("internal error: work item outside its exon");
+                }
+            covered_part[t] = covered;
+        } catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+    };
+    if (nparts == 1) check(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nparts; t++) th.emplace_back(check, t);
+        for (auto& x : th) x.join();
+    }
+    for (const std::string& e : errors) if (!e.empty()) throw Error(e);
     uint64_t covered = 0;
-    for (const SegDev& g : b.segs) {
-        if (g.tx >= b.tx.size() || uint64_t(g.step_off) + g.n_steps > b.steps.size()) throw Error("internal error: segment outside the plan");
-        uint32_t ncols = g.init_cols;
-        if (g.n_steps && g.init_cols + b.steps[g.step_off].n_add > b.steps[g.step_off].col_hi) throw Error("internal error: initial columns underflow");
-        for (uint32_t k = 0; k < g.n_steps; k++) {
-            const Step& st = b.steps[g.step_off + k];
-            if (st.n_del > ncols) throw Error("internal error: segment drops more columns than it holds");
-            ncols = ncols - st.n_del + st.n_add;
-            if (ncols > 63) throw Error("internal error: more than 63 live columns in a segment");
-            if (st.n_add > st.col_hi) throw Error("internal error: column index underflow in the plan");
-        }
-        covered += g.n_steps;
-    }
-    for (const ExonW& e : b.exons_w) {
-        if (uint64_t(e.step_off) + e.n_steps > b.steps.size() || e.tx >= b.tx.size()) throw Error("internal error: window-parallel exon outside the plan");
-        covered += e.n_steps;
-    }
-    for (const PodVec<WChunk>* list : {&b.wchunks, &b.wchunks_m, &b.wchunks_d})
-    for (const WChunk& c : *list)
-        if (c.exon >= b.exons_w.size() || c.step_first < b.exons_w[c.exon].step_off ||
-            uint64_t(c.step_first) + c.n_steps > uint64_t(b.exons_w[c.exon].step_off) + b.exons_w[c.exon].n_steps)
-            throw Error("internal error: work item outside its exon");
+    for (uint64_t c : covered_part) covered += c;
     if (!b.normal && (b.step_ncols.size() != b.steps.size() || b.step_rlo.size() != b.steps.size() || b.step_rn.size() != b.steps.size()))
         throw Error("internal error: step side arrays out of step with the plan");
     if (covered != b.steps.size()) throw Error("internal error: segments do not cover the plan");
@@ -520,6 +542,7 @@ static void route_lane_windows(Batch& b) {
 
 // Decide which single-exon segments go to the window-parallel replay (plan.hpp ExonW) and cut them into work items.
 static void route_window_parallel(Batch& b) {
+    const auto t_route0 = std::chrono::steady_clock::now();
     // packed somatic flags of all variants (K2w derives a window's somatic-column mask from it)
     b.v_sombits.assign(b.v_pos.size() / 64 + 2, 0);
     for (size_t v = 0; v < b.v_info.size(); v++)
@@ -536,7 +559,23 @@ static void route_window_parallel(Batch& b) {
     uint32_t max_rn_multi = 0;
     PodVec<SegDev> keep;
     constexpr uint32_t CHUNK_STEPS = 96;
-    for (size_t i = 0; i < b.segs.size(); i++) {
+    // The segments are independent: ranges of them are routed by all host threads (the per-exon scans over the steps - unit stride,
+    // which work items still hold a window for the wave kernels - touch all 26 M steps of a whole exome), each into its own lists with
+    // range-local exon indices and admission offsets; the lists are then joined in segment order and rebased.
+    struct Part {
+        PodVec<SegDev> keep;
+        PodVec<ExonW> exons;
+        PodVec<WChunk> achunks, wchunks, wchunks_m, wchunks_d;
+        uint64_t n_adm = 0;
+        uint32_t max_rn_multi = 0;
+        std::string error;
+    };
+    const size_t nparts = std::max<size_t>(1, std::min<size_t>(host_threads(), b.segs.size() / 256 + 1));
+    std::vector<Part> parts(nparts);
+    auto route_range = [&](size_t t) {
+      Part& P = parts[t];
+      try {
+        for (size_t i = b.segs.size() * t / nparts, i_end = b.segs.size() * (t + 1) / nparts; i < i_end; i++) {
         const SegDev& g = b.segs[i];
         const Batch::SegInfo& si = b.seg_info[i];
         const TxDev& T = b.tx[g.tx];
@@ -547,13 +586,13 @@ static void route_window_parallel(Batch& b) {
         if (ok && T.strand)   // `contains` (:281-294) can only hit when two reads of the range share a name
             for (uint32_t r = read_lo; r < read_hi && ok; r++) ok = !(b.r_dup[gh.read_off + r] >> 31);
         if (!ok && std::getenv("MP_DEBUG_SEG")) std::fprintf(stderr, "seq: tx %u steps %u n_exons %u cols_ok %d max_rn %u\n", g.tx, g.n_steps, si.n_exons, int(si.cols_ok), si.max_rn);
-        if (!ok) { keep.push_back(g); continue; }
+        if (!ok) { P.keep.push_back(g); continue; }
         ExonW e{};
         e.tx = g.tx; e.step_off = g.step_off; e.n_steps = g.n_steps;
         e.read_lo = read_lo; e.n_reads = read_hi - read_lo;
-        if (b.n_adm + e.n_reads > 0xFFFFFFF0ull) throw Error("batch too large for 32-bit admission-table offsets: split the batch by genes");
-        e.adm_off = uint32_t(b.n_adm);
-        b.n_adm += e.n_reads;
+        if (P.n_adm + e.n_reads > 0xFFFFFFF0ull) throw Error("batch too large for 32-bit admission-table offsets: split the batch by genes");
+        e.adm_off = uint32_t(P.n_adm);   // (range-local: rebased when the ranges are joined)
+        P.n_adm += e.n_reads;
         e.first_key_lo = si.first_key_lo; e.range = si.range; e.tr0 = si.tr0; e.f0 = si.f0;
         const uint32_t* vp = b.v_pos.data() + gh.var_off;
         e.sl_f_lo = e.sl_f_hi = 0;
@@ -570,12 +609,12 @@ static void route_window_parallel(Batch& b) {
             else { while (u < g.n_steps && b.steps[g.step_off + u].sso == e.sso1 + (u - 1)) u++; }
             e.unit_steps = u;
         }
-        const uint32_t ei = uint32_t(b.exons_w.size());
-        b.exons_w.push_back(e);
-        for (uint32_t k0 = 0; k0 < e.n_reads; k0 += 64) b.achunks.push_back(WChunk{ei, k0, std::min(64u, e.n_reads - k0), 0});
+        const uint32_t ei = uint32_t(P.exons.size());   // (range-local)
+        P.exons.push_back(e);
+        for (uint32_t k0 = 0; k0 < e.n_reads; k0 += 64) P.achunks.push_back(WChunk{ei, k0, std::min(64u, e.n_reads - k0), 0});
         const bool multi = si.max_rn > 63 || b.mask_words > 1;   // needs several reads per lane / two mask words (63: rows + the reference haplotype fit 64 lanes)
         const bool deep = si.max_rn > 512;                        // beyond the resident block of the multi kernel: rows are streamed
-        if (multi && !deep) max_rn_multi = std::max(max_rn_multi, si.max_rn);
+        if (multi && !deep) P.max_rn_multi = std::max(P.max_rn_multi, si.max_rn);
         // deep windows cost ~RPL x more each and there are few of them: smaller work items keep the chip full
         const uint32_t chunk = deep ? 6 : multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
         for (uint32_t s0 = 0; s0 < g.n_steps; s0 += chunk) {
@@ -583,23 +622,59 @@ static void route_window_parallel(Batch& b) {
             bool mine = !b.lane_on;   // a printing window the lane kernel does not take
             for (uint32_t k = 0; k < n && !mine; k++)
                 mine = (b.steps[g.step_off + s0 + k].flags & SF_PRINT) && !lane_window(b, g.step_off + s0 + k);
-            if (mine) (deep ? b.wchunks_d : multi ? b.wchunks_m : b.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0});
+            if (mine) (deep ? P.wchunks_d : multi ? P.wchunks_m : P.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0});
         }
+        }
+      } catch (const std::exception& e) { P.error = e.what(); if (P.error.empty()) P.error = "error"; }
+    };
+    if (nparts == 1) route_range(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nparts; t++) th.emplace_back(route_range, t);
+        for (auto& x : th) x.join();
+    }
+    for (const Part& P : parts) if (!P.error.empty()) throw Error(P.error);
+    for (Part& P : parts) {   // join in segment order: exon indices and admission offsets move by what came before
+        const uint32_t e0 = uint32_t(b.exons_w.size());
+        if (b.n_adm + P.n_adm > 0xFFFFFFF0ull) throw Error("batch too large for 32-bit admission-table offsets: split the batch by genes");
+        const uint32_t a0 = uint32_t(b.n_adm);
+        for (ExonW& e : P.exons) e.adm_off += a0;
+        b.exons_w.insert(b.exons_w.end(), P.exons.begin(), P.exons.end());
+        auto take = [&](PodVec<WChunk>& dst, PodVec<WChunk>& src) {
+            for (WChunk& c : src) c.exon += e0;
+            dst.insert(dst.end(), src.begin(), src.end());
+        };
+        take(b.achunks, P.achunks); take(b.wchunks, P.wchunks); take(b.wchunks_m, P.wchunks_m); take(b.wchunks_d, P.wchunks_d);
+        keep.insert(keep.end(), P.keep.begin(), P.keep.end());
+        b.n_adm += P.n_adm;
+        max_rn_multi = std::max(max_rn_multi, P.max_rn_multi);
     }
     b.rows_per_lane_w = 1;
     while (64u * b.rows_per_lane_w < max_rn_multi) b.rows_per_lane_w *= 2;
     b.segs.swap(keep);
     b.seg_info.clear();
+    const auto t_lanes = std::chrono::steady_clock::now();
     route_lane_windows(b);
+    if (std::getenv("MP_DEBUG"))
+        std::fprintf(stderr, "[mp]   routing: exons and work items %.1f ms, lane windows %.1f ms\n",
+                     std::chrono::duration<double, std::milli>(t_lanes - t_route0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lanes).count());
 }
 
 static void finalize_segments(Batch& b) {
+    const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+    const auto t0 = now();
     route_window_parallel(b);
+    const auto t1 = now();
     merge_short_segments(b);
     b.seg_order.resize(b.segs.size());
     std::iota(b.seg_order.begin(), b.seg_order.end(), 0u);
     std::stable_sort(b.seg_order.begin(), b.seg_order.end(), [&](uint32_t a, uint32_t c) { return b.segs[a].n_steps > b.segs[c].n_steps; });
+    const auto t2 = now();
     validate_segments(b);
+    if (dbg) std::fprintf(stderr, "[mp]   finalize: routing %.1f ms, segment order %.1f ms, validation %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
 }
 
 // bit k of the appended dwords = quals[k] < 10 (k < n; the last dword is zero-padded)
@@ -919,8 +994,7 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
                      std::chrono::duration<double, std::milli>(t_run - t_merge0).count(), tasks.size(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(), lo, hi);
     }
-    release_later(std::move(parts));
-    parts.clear();
+    // (the caller gives the emptied-out sub-batches back - later, off its path: release_later)
 }
 }  // namespace
 
@@ -961,6 +1035,7 @@ void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore&
     b.g_var_off.push_back(uint32_t(b.v_pos.size()));
     const auto t2 = now();
     finalize_segments(b);
+    release_later(std::move(parts));   // after the routing pass: unmapping 5 GB of sub-batches holds the mm lock its page faults wait on
     if (dbg) std::fprintf(stderr, "[mp]   plan on %zu threads %.1f ms, merge %.1f ms, finalize %.1f ms\n", nthreads, ms(t0, t1), ms(t1, t2), ms(t2, now()));
 }
 
