@@ -1,4 +1,8 @@
 #include "io.hpp"
+#include <cerrno>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <fcntl.h>
 
 #include <zlib.h>
 
@@ -34,18 +38,48 @@ namespace {
 
 struct FileBytes {
     PodVec<uint8_t> data;   // not zero-filled before the read
+    // Whole file into memory: a few threads pread their pieces (copying out of the page cache and first-touching the buffer is CPU
+    // work: one thread moves ~2.5 GB/s, and these are 0.4-0.8 GB files on the CLI's critical path)
     explicit FileBytes(const std::string& path) {
-        FILE* f = std::fopen(path.c_str(), "rb");
-        if (!f) throw Error("cannot open " + path);
-        std::fseek(f, 0, SEEK_END);
-        long n = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        data.resize(size_t(n));
-        if (n && std::fread(data.data(), 1, size_t(n), f) != size_t(n)) {
-            std::fclose(f);
-            throw Error("short read on " + path);
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error("cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {   // not a regular file (a pipe, /dev/stdin): read it sequentially
+            uint8_t buf[1 << 16];
+            for (;;) {
+                const ssize_t n = ::read(fd, buf, sizeof buf);
+                if (n < 0) { if (errno == EINTR) continue; ::close(fd); throw Error("read error on " + path); }
+                if (n == 0) break;
+                data.insert(data.end(), buf, buf + n);
+            }
+            ::close(fd);
+            return;
         }
-        std::fclose(f);
+        const size_t n = size_t(st.st_size);
+        data.resize(n);
+        constexpr size_t PIECE = size_t(32) << 20;
+        const size_t pieces = (n + PIECE - 1) / PIECE;
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(pieces, 6));
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        auto work = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < pieces;) {
+                size_t off = i * PIECE;
+                const size_t end = std::min(n, off + PIECE);
+                while (off < end) {
+                    const ssize_t got = ::pread(fd, data.data() + off, end - off, off_t(off));
+                    if (got < 0 && errno == EINTR) continue;
+                    if (got <= 0) { failed = true; return; }
+                    off += size_t(got);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nthreads; t++) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+        ::close(fd);
+        if (failed) throw Error("short read on " + path);
     }
 };
 
