@@ -704,6 +704,7 @@ void load_vcf(const std::string& path, VcfData& out) {
     std::vector<Piece> pieces(nt);
     run_threads(nt, [&](size_t t) {
         Piece& pc = pieces[t];
+        pc.records.reserve((cut[t + 1] - cut[t]) / 120 + 16);   // (a record line with its ANN string is ~150 bytes)
         std::string line;
         for (size_t at = cut[t]; at < cut[t + 1];) {
             const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(buf.data() + at, '\n', cut[t + 1] - at));
@@ -740,7 +741,11 @@ void load_vcf(const std::string& path, VcfData& out) {
             }
             VcfRecord r;
             r.chrom.assign(fb[0], fe[0]);
-            r.pos = std::strtoull(std::string(fb[1], fe[1]).c_str(), nullptr, 10) - 1;
+            {   // POS: leading decimal digits, like strtoull
+                uint64_t v = 0;
+                for (const char* q = fb[1]; q < fe[1] && *q >= '0' && *q <= '9'; q++) v = v * 10 + uint64_t(*q - '0');
+                r.pos = v - 1;
+            }
             r.ref.assign(fb[3], fe[3]);
             for (const char* a = fb[4];;) {   // ALT, comma separated (an empty field is one empty allele, like split())
                 const char* c = static_cast<const char*>(std::memchr(a, ',', size_t(fe[4] - a)));
@@ -763,9 +768,11 @@ void load_vcf(const std::string& path, VcfData& out) {
                 if (!c) break;
                 a = c + 1;
             }
-            bool seen = false;
-            for (const auto& c : pc.contigs) seen |= !c.second && c.first == r.chrom;
-            if (!seen) pc.contigs.emplace_back(r.chrom, false);
+            if (pc.records.empty() || pc.records.back().chrom != r.chrom) {   // (records of a contig come in a row: look only when it changes)
+                bool seen = false;
+                for (const auto& c : pc.contigs) seen |= !c.second && c.first == r.chrom;
+                if (!seen) pc.contigs.emplace_back(r.chrom, false);
+            }
             pc.records.push_back(std::move(r));
         }
     });
@@ -783,10 +790,15 @@ void load_vcf(const std::string& path, VcfData& out) {
 void VcfData::build_index() const {
     if (indexed) return;
     by_chrom.clear();
+    ContigIndex* ci = nullptr;
+    const std::string* last = nullptr;
     for (size_t i = 0; i < records.size(); i++) {
-        ContigIndex& ci = by_chrom[records[i].chrom];
-        if (!ci.recs.empty() && records[ci.recs.back()].pos > records[i].pos) ci.sorted = false;
-        ci.recs.push_back(i);
+        if (!last || records[i].chrom != *last) {   // (one map look-up per run of a contig's records, not per record)
+            ci = &by_chrom[records[i].chrom];
+            last = &records[i].chrom;
+        }
+        if (!ci->recs.empty() && records[ci->recs.back()].pos > records[i].pos) ci->sorted = false;
+        ci->recs.push_back(i);
     }
     indexed = true;
 }
