@@ -21,6 +21,7 @@ DeviceContext::DeviceContext(int device) : device_(device) {
     for (auto& ev : ev_) HIP_OK(hipEventCreate(&ev));
     for (auto& st : side_) HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto& ev : fork_) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&cleared_, hipEventDisableTiming));
     for (auto& ev : join_) HIP_OK(hipEventCreate(&ev));
 }
 
@@ -29,6 +30,7 @@ DeviceContext::~DeviceContext() {
     free_batch();
     for (auto& ev : ev_) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : fork_) if (ev) (void)hipEventDestroy(ev);
+    if (cleared_) (void)hipEventDestroy(cleared_);
     for (auto& ev : join_) if (ev) (void)hipEventDestroy(ev);
     for (auto& st : side_) if (st) (void)hipStreamDestroy(st);
     if (stream_) hipStreamDestroy(stream_);
@@ -156,7 +158,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.r_lq = static_cast<uint64_t*>(dalloc(size_t(d_.n_reads) * 8 * b.mask_words)); allocs_.push_back(d_.r_lq);
     d_.win_dyn = static_cast<WinDyn*>(dalloc(size_t(d_.n_wins) * sizeof(WinDyn))); allocs_.push_back(d_.win_dyn);
     d_.cursors = static_cast<unsigned long long*>(dalloc((NPART * 32 + 16) * 8)); allocs_.push_back(d_.cursors);
-    d_.err = static_cast<uint32_t*>(dalloc(4)); allocs_.push_back(d_.err);
+    d_.err = reinterpret_cast<uint32_t*>(d_.cursors + NPART * 32);   // the error word sits behind the cursors: one memset, one copy back per pass
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
     last_slots_ = last_recs_ = last_want_ = last_k3_ = 0;
@@ -202,13 +204,15 @@ void DeviceContext::run(RunTiming& t) {
     for (int attempt = 0; attempt < 8; attempt++) {
         t.attempts = uint32_t(attempt + 1);
         t.rows_per_lane = rpl_;
-        HIP_OK(hipMemsetAsync(d_.cursors, 0, (NPART * 32 + 16) * 8, stream_));
-        HIP_OK(hipMemsetAsync(d_.err, 0, 4, stream_));
-        HIP_OK(hipMemsetAsync(d_.win_dyn, 0, size_t(d_.n_wins) * sizeof(WinDyn), stream_));
-        HIP_OK(hipMemsetAsync(d_.tx_first_stop, 0xFF, size_t(d_.n_tx) * 4, stream_));
+        HIP_OK(hipMemsetAsync(d_.cursors, 0, (NPART * 32 + 16) * 8, stream_));   // (incl. the error word)
+        // the per-window / per-transcript outputs are cleared beside K1, which does not touch them (141 MB at config C)
+        HIP_OK(hipMemsetAsync(d_.win_dyn, 0, size_t(d_.n_wins) * sizeof(WinDyn), side_[0]));
+        HIP_OK(hipMemsetAsync(d_.tx_first_stop, 0xFF, size_t(d_.n_tx) * 4, side_[0]));
+        HIP_OK(hipEventRecord(cleared_, side_[0]));
         HIP_OK(hipEventRecord(ev_[0], stream_));
         launch_k1_pileup_bits(d_, stream_);
         HIP_OK(hipEventRecord(ev_[1], stream_));
+        HIP_OK(hipStreamWaitEvent(stream_, cleared_, 0));   // everything after K1 is ordered behind the clears (the side streams fork from here)
         // The launches of the window phase work on disjoint windows and are each bound by latency at modest occupancy, so they run side
         // by side: the sequential replay (needs K1 only) beside K2a; after K2a the two lane-per-window launches and the wave-per-window
         // kernels on three streams. Everything joins before K3. (The output allocators are shared: atomics.)
@@ -237,11 +241,10 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(ev_[3], stream_));
         launch_k3b_haplotype_ids(d_, want_bound, stream_);
         HIP_OK(hipEventRecord(ev_[4], stream_));
-        std::vector<unsigned long long> cur(NPART * 32);
-        uint32_t err = 0;
+        std::vector<unsigned long long> cur(NPART * 32 + 1);
         HIP_OK(hipMemcpyAsync(cur.data(), d_.cursors, cur.size() * 8, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(&err, d_.err, 4, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
+        const uint32_t err = uint32_t(cur[NPART * 32]);
         if (err & WD_ROW_OVERFLOW) {
             if (rpl_ >= 16) throw Error("more than 1024 simultaneously live reads in one window (depth too high for this build)");
             rpl_ *= 2;

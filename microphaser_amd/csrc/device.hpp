@@ -63,7 +63,7 @@ class DeviceContext {
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     hipStream_t side_[3] = {nullptr, nullptr, nullptr};   // the independent launches of the window phase run side by side (run())
-    hipEvent_t fork_[2] = {nullptr, nullptr}, join_[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_[2] = {nullptr, nullptr}, join_[3] = {nullptr, nullptr, nullptr}, cleared_ = nullptr;
     hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs_, out_allocs_;
     DeviceBatch d_{};
