@@ -1233,6 +1233,16 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
     constexpr uint32_t CAP = 64u * RPL;
     __shared__ uint64_t sk[CAP];              // the window's haplotype words, sorted
     __shared__ uint16_t starts[CAP + 2];      // first entry of every run of equal words
+    // windows of < 32 columns: the words are first de-duplicated in an LDS hash table (key / count; open addressing, the all-ones word
+    // is free), so that only the DISTINCT words - ~80 of ~370 at 500x - are sorted, as (word << 32 | count) pairs
+    constexpr uint32_t HT = 2 * CAP;          // slots: at most CAP distinct words, so the table is at most half full
+    static_assert((HT & (HT - 1)) == 0 && HT <= 65536, "hash table size");
+    __shared__ uint32_t tkey[HT], tcnt[HT];
+    __shared__ uint16_t dlist[CAP];           // the slots in use
+    __shared__ uint32_t n_dist;
+    for (uint32_t i = threadIdx.x; i < HT; i += 64) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0; }
+    if (threadIdx.x == 0) n_dist = 0;
+    __syncthreads();
     constexpr uint32_t GROUP_CHUNK = 64u * RPL + 64u, REC_CHUNK_W = 64;
     const uint32_t lane = threadIdx.x;
     const uint32_t part = blockIdx.x & (NPART - 1);
@@ -1426,8 +1436,50 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
                     emit(on, gbase + g, kh, kl, cnt);
                 }
             };
-            // 32-bit keys while the all-ones padding cannot be a haplotype word (at most 31 columns); a word has at most 63 bits
-            if (ncols < 32) count_sorted(reinterpret_cast<uint32_t*>(sk));
+            auto count_hashed = [&]() {
+                constexpr uint32_t HBITS = 31u - uint32_t(__builtin_clz(HT));   // log2(HT)
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    if (act[k]) {
+                        const uint32_t key = uint32_t(hap[k]);
+                        uint32_t h = (key * 0x9E3779B1u) >> (32u - HBITS);
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&tkey[h], 0xFFFFFFFFu, key);
+                            if (old == 0xFFFFFFFFu) dlist[atomicAdd(&n_dist, 1u)] = uint16_t(h);   // this lane claimed the slot: list it once
+                            if (old == 0xFFFFFFFFu || old == key) { atomicAdd(&tcnt[h], 1u); break; }
+                            h = (h + 1u) & (HT - 1u);
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t n = n_dist;
+                uint32_t N = 64;
+                while (N < n) N <<= 1;
+                for (uint32_t i = lane; i < N; i += 64) {   // the distinct words with their counts -> sk; their slots are free again
+                    uint64_t v = ~0ull;
+                    if (i < n) {
+                        const uint32_t h = dlist[i];
+                        v = (uint64_t(tkey[h]) << 32) | tcnt[h];
+                        tkey[h] = 0xFFFFFFFFu;
+                        tcnt[h] = 0;
+                    }
+                    sk[i] = v;
+                }
+                __syncthreads();
+                if (lane == 0) n_dist = 0;
+                bitonic_sort_wave<uint64_t>(sk, N, lane);   // ascending in the word (the high half); ends with a barrier
+                ng = n + lead;
+                for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+                    const uint32_t g = g0 + lane;
+                    const bool on = g < ng;
+                    uint32_t kl = 0, cnt = 0;
+                    if (on && g >= lead) { const uint64_t v = sk[g - lead]; kl = uint32_t(v >> 32); cnt = uint32_t(v); }
+                    emit(on, gbase + g, 0u, kl, cnt);
+                }
+            };
+            // < 32 columns: the all-ones word cannot be a haplotype word, so it marks free table slots / sort padding; wider windows sort
+            // all their 64-bit words (a word has at most 63 bits)
+            if (ncols < 32) count_hashed();
             else count_sorted(sk);
             __syncthreads();   // sk / starts are reused by the next window
             if (lane == 0) {
