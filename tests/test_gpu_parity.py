@@ -311,6 +311,12 @@ def test_gpu_cli_somatic_matches_reference_expected_output(built, tmp_path):
     assert r.stdout == exp["fa"]
     assert (tmp_path / "o.normal.fa").read_bytes() == exp["normal.fa"]
     assert (tmp_path / "o.tsv").read_bytes() == exp["tsv"]
+    # the CLI ends the process once its outputs are written; MP_CLEAN_EXIT=1 keeps the orderly teardown (same outputs, exit 0)
+    with open(p["gtf"], "rb") as g:
+        r2 = subprocess.run([PRODUCT_CLI, "somatic", p["bam"], "--variants", p["vcf"], "--ref", p["fasta"], "--tsv", str(tmp_path / "c.tsv"),
+                             "--normal-output", str(tmp_path / "c.normal.fa")], stdin=g, capture_output=True, env=dict(os.environ, MP_CLEAN_EXIT="1"))
+    assert r2.returncode == 0, r2.stderr.decode()
+    assert r2.stdout == exp["fa"] and (tmp_path / "c.tsv").read_bytes() == exp["tsv"]
 
 
 def test_gpu_cli_normal_matches_reference_expected_output(built, tmp_path):
