@@ -604,6 +604,74 @@ struct NormalConsumerHooks {
             throw Error("internal error: consumer and planner schedules diverged");
     }
 
+    struct RowLists {
+        std::string somatic_positions, somatic_aa_change, germline_positions, germline_aa_change, variant_sites;
+        uint32_t n_sites = 0, n_som_sites = 0;
+    };
+    // the '|'-joined list fields of one haplotype (:531-557: 0-based positions; the profile index is the visit order)
+    static void build_lists(const Variant* const* variants, uint32_t ncols, const HapRecHdr* rec, uint64_t prof_som, RowLists& L) {
+        L.somatic_positions.clear(); L.somatic_aa_change.clear(); L.germline_positions.clear(); L.germline_aa_change.clear(); L.variant_sites.clear();
+        L.n_sites = L.n_som_sites = 0;
+        auto add = [](std::string& s, const std::string& x, bool& first) { if (!first) s.push_back('|'); s += x; first = false; };
+        auto addn = [](std::string& s, uint64_t x, bool& first) { if (!first) s.push_back('|'); append_u64(s, x); first = false; };
+        bool f1 = true, f2 = true, f3 = true, f4 = true, f5 = true;
+        for (uint32_t c = 0; c < ncols; c++) {
+            if (c >= rec->prof_len) break;
+            const Variant& v = *variants[c];
+            if ((rec->prof_set >> c) & 1) {
+                if ((prof_som >> c) & 1) { addn(L.somatic_positions, v.pos, f1); add(L.somatic_aa_change, v.prot_change, f2); }
+                else { addn(L.germline_positions, v.pos, f3); add(L.germline_aa_change, v.prot_change, f4); }
+            }
+            if (c == 0 || v.pos != variants[c - 1]->pos) {
+                L.n_sites++;
+                addn(L.variant_sites, v.pos, f5);
+                if (!v.is_germline) L.n_som_sites++;
+            }
+        }
+    }
+    // the window's variants in print_haplotypes order (:373-379)
+    const Variant** window_variants(const WinStatic& ws, const Variant** few, std::vector<const Variant*>& many) const {
+        const std::vector<Variant>& gvars = gh.input->variants;
+        const uint32_t ncols = ws.ncols;
+        const Variant** variants = few;
+        if (ncols > 64) { many.resize(ncols); variants = many.data(); }
+        for (uint32_t j = 0; j < ncols; j++) variants[j] = &gvars[b.win_cols[ws.col_off + (is_fwd ? j : ncols - 1 - j)].f];
+        return variants;
+    }
+    // The record print_haplotypes builds for a haplotype (:559-625), for the windows a splice-side merge reads: from the device record
+    // and the values print() noted in the HapSeq.
+    void materialize(HapSeq& h) const {
+        if (h.np || h.lazy_rec == 0xFFFFFFFFu) return;
+        const WinStatic& ws = b.wins[h.win];
+        const Variant* few[64];
+        std::vector<const Variant*> many;
+        const Variant** variants = window_variants(ws, few, many);
+        const HapRecHdr* rec = res.rec(h.lazy_rec);
+        const uint8_t* rseq = res.rec_seq(h.lazy_rec);
+        uint64_t prof_som;
+        std::memcpy(&prof_som, res.rec_germ(h.lazy_rec), 8);
+        static thread_local RowLists L;
+        build_lists(variants, ws.ncols, rec, prof_som, L);
+        HapSeq::NormalPayload& P = h.nmake();
+        NormalRecord& r = P.nrecord;
+        {
+            static const char HEX[] = "0123456789abcdef";
+            char idb[16];
+            for (int k = 0; k < 15; k++) idb[k] = HEX[(rec->id60 >> (4 * (14 - k))) & 0xF];
+            idb[15] = is_fwd ? 'F' : 'R';
+            r.id.assign(idb, 16);
+        }
+        r.somatic_positions = L.somatic_positions; r.somatic_aa_change = L.somatic_aa_change;
+        r.germline_positions = L.germline_positions; r.germline_aa_change = L.germline_aa_change;
+        r.variant_sites = L.variant_sites;
+        r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
+        r.offset = ws.sso; r.frame = h.frame; r.freq = h.lazy_freq; r.depth = h.lazy_nrows;
+        r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = L.n_sites; r.nsomvariant_sites = L.n_som_sites;
+        r.strand = is_fwd ? "Forward" : "Reverse";
+        P.sequence.assign(rseq, rseq + rec->seq_len);
+        r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), rec->seq_len);  // carried record: unsliced (:618-625)
+    }
+
     // print_haplotypes (reference: src/normal_microphasing.rs:341-647)
     std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
         const Step& st = b.steps[cur_step];
@@ -612,13 +680,10 @@ struct NormalConsumerHooks {
         const WinDyn& wd = res.win_dyn[st.win];
         if (!(wd.flags & WD_DONE)) throw Error("internal error: window was not computed on the device");
         if (frame == 0) out.n_windows++;
-        const std::vector<Variant>& gvars = gh.input->variants;
         const uint32_t ncols = ws.ncols;
         const Variant* variants_few[64];
         std::vector<const Variant*> variants_many;
-        const Variant** variants = variants_few;
-        if (ncols > 64) { variants_many.resize(ncols); variants = variants_many.data(); }
-        for (uint32_t j = 0; j < ncols; j++) variants[j] = &gvars[b.win_cols[ws.col_off + (is_fwd ? j : ncols - 1 - j)].f];
+        const Variant** variants = window_variants(ws, variants_few, variants_many);
         const char* strand = is_fwd ? "Forward" : "Reverse";
         static const std::string kForward("Forward"), kReverse("Reverse");
         const std::string& strand_s = is_fwd ? kForward : kReverse;
@@ -656,32 +721,16 @@ struct NormalConsumerHooks {
                 else { pep_lo = 0; pep_hi = seq_len; }
                 check(pep_lo, pep_hi);
                 if (!(gs.flags & GS_ID_VALID)) throw Error("internal error: haplotype id was not computed on the device");
-                // the row's id and list fields; the buffers live as long as the consumer thread
-                static thread_local std::string idstr, somatic_positions, somatic_aa_change, germline_positions, germline_aa_change, variant_sites;
+                // the row's id and list fields; the buffers live as long as the consumer thread. The lists are only built for a row that
+                // is written to the TSV; the record a splice-side merge may ask for later is built then (materialize)
+                static thread_local std::string idstr;
+                static thread_local RowLists L;
                 {
                     static const char HEX[] = "0123456789abcdef";
                     char idb[16];
                     for (int k = 0; k < 15; k++) idb[k] = HEX[(rec->id60 >> (4 * (14 - k))) & 0xF];
                     idb[15] = strand[0];
                     idstr.assign(idb, 16);
-                }
-                somatic_positions.clear(); somatic_aa_change.clear(); germline_positions.clear(); germline_aa_change.clear(); variant_sites.clear();
-                auto add = [](std::string& s, const std::string& x, bool& first) { if (!first) s.push_back('|'); s += x; first = false; };
-                auto addn = [](std::string& s, uint64_t x, bool& first) { if (!first) s.push_back('|'); append_u64(s, x); first = false; };
-                bool f1 = true, f2 = true, f3 = true, f4 = true, f5 = true;
-                uint32_t n_sites = 0, n_som_sites = 0;
-                for (uint32_t c = 0; c < ncols; c++) {  // :531-557 (0-based positions; profile index = visit order)
-                    if (c >= rec->prof_len) break;
-                    const Variant& v = *variants[c];
-                    if ((rec->prof_set >> c) & 1) {
-                        if ((prof_som >> c) & 1) { addn(somatic_positions, v.pos, f1); add(somatic_aa_change, v.prot_change, f2); }
-                        else { addn(germline_positions, v.pos, f3); add(germline_aa_change, v.prot_change, f4); }
-                    }
-                    if (c == 0 || v.pos != variants[c - 1]->pos) {
-                        n_sites++;
-                        addn(variant_sites, v.pos, f5);
-                        if (!v.is_germline) n_som_sites++;
-                    }
                 }
                 if (!eg.is_short) {  // :629-644
                     if (splice_pos == 1) {
@@ -691,24 +740,18 @@ struct NormalConsumerHooks {
                         if (wl > seq_len) throw Error("reference would panic: slice index out of range");
                         if (out.streams & STREAM_FASTA) put_fasta(out.fasta, idstr, rseq, size_t(wl));
                     }
-                    put_normal_tsv_row(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, offset, frame, freq, nrows, rec->nvar, rec->nsom, n_sites,
-                                            n_som_sites, strand_s, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
-                                            germline_aa_change, std::string_view(reinterpret_cast<const char*>(rseq) + pep_lo, size_t(pep_hi - pep_lo)));
+                    if (out.streams & STREAM_TSV) {
+                        build_lists(variants, ncols, rec, prof_som, L);
+                        put_normal_tsv_row(out, idstr, transcript.id, gene.id, gene.name, gene.chrom, offset, frame, freq, nrows, rec->nvar, rec->nsom, L.n_sites,
+                                           L.n_som_sites, strand_s, L.variant_sites, L.somatic_positions, L.somatic_aa_change, L.germline_positions,
+                                           L.germline_aa_change, std::string_view(reinterpret_cast<const char*>(rseq) + pep_lo, size_t(pep_hi - pep_lo)));
+                    }
                 }
-                {   // the record is kept for every window of a regular exon: `normal` merges reach further back than the planner's marks
-                    hs.filled = true;
-                    NormalRecord& r = hs.nmake().nrecord;
-                    r.id = idstr;
-                    r.somatic_positions = somatic_positions; r.somatic_aa_change = somatic_aa_change;
-                    r.germline_positions = germline_positions; r.germline_aa_change = germline_aa_change;
-                    r.variant_sites = variant_sites;
-                    r.transcript = transcript.id; r.gene_id = gene.id; r.gene_name = gene.name; r.chrom = gene.chrom;
-                    r.offset = offset; r.frame = frame; r.freq = freq; r.depth = nrows;
-                    r.nvar = rec->nvar; r.nsomatic = rec->nsom; r.nvariant_sites = n_sites; r.nsomvariant_sites = n_som_sites;
-                    r.strand = strand_s;
-                    hs.nmake().sequence.assign(rseq, rseq + seq_len);
-                    r.peptide_sequence.assign(reinterpret_cast<const char*>(rseq), seq_len);  // carried record: unsliced (:618-625)
-                }
+                // the record is kept for every window of a regular exon: `normal` merges reach further back than the planner's marks
+                hs.filled = true;
+                hs.win = st.win;
+                hs.frame = frame;
+                hs.lazy_rec = gs.rec; hs.lazy_nrows = nrows; hs.lazy_freq = freq;
             }
             haplotypes_vec.push_back(std::move(hs));
         }
@@ -723,6 +766,8 @@ struct NormalConsumerHooks {
         for (const std::vector<HapSeq>* v : {&first_hap_vec, &sec_hap_vec})
             for (const HapSeq& h : *v)
                 if (!h.filled) throw Error("internal error: splice-side merge over a window whose records were not requested from the device");
+        for (HapSeq& h : hap_vec) materialize(h);        // the records of these two windows are needed now
+        for (HapSeq& h : prev_hap_vec) materialize(h);
         using Bytes = std::vector<uint8_t>;
         std::map<std::pair<uint64_t, Bytes>, NormalRecord> output_map;
         std::vector<HapSeq> new_hap_vec;

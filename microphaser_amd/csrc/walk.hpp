@@ -34,6 +34,10 @@ struct HapSeq {  // reference: HaplotypeSeq (microphasing.rs:141-145); record ca
     };
     std::unique_ptr<Payload> p;
     std::unique_ptr<NormalPayload> np;
+    // `normal` consumer: what it takes to build the NormalPayload when a splice-side merge asks for it (only the windows at exon ends
+    // are ever merged; every window of every exon has haplotypes): the device record and the three per-call values
+    uint32_t lazy_rec = 0xFFFFFFFFu, lazy_nrows = 0;
+    double lazy_freq = 0;
     bool filled = false;   // consumer: the record was built (the planner marked the window as carried or it is emitted)
     uint32_t win = 0xFFFFFFFFu;   // consumer: window the haplotype came from (diagnostics)
     uint64_t frame = 0;
