@@ -185,3 +185,12 @@ def test_peptides_union_in_key_slices_matches_numpy(built):
     bad[300000] = bad[299999]
     with pytest.raises(m.MicrophaserError, match="sorted and distinct"):
         ctx.peptides_union([bad, np.arange(0, 10 ** 6, 3, dtype=np.uint64)], 9)
+
+
+def test_header_compiles_as_plain_c():
+    """include/microphaser_hip.h is a C ABI: it must be valid C99 (what cgo / bindgen / ctypes-style binders read) and C++."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "microphaser_hip.h")
+    for cmd in (["gcc", "-std=c99", "-fsyntax-only", "-x", "c", hdr], ["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
