@@ -312,7 +312,7 @@ int mp_build_reference_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, u
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         std::unique_ptr<mp_peptides> p(new mp_peptides());
-        build_reference_device(dev.device(), std::string(fasta_text, len), peptide_len, p->res);
+        build_reference_device(dev.device(), std::string_view(fasta_text, len), peptide_len, p->res);
         p->bin = p->res.binary();
         *out = p.release();
     });
@@ -321,7 +321,7 @@ int mp_peptidome_from_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, ui
     return guarded(ctx, [&] {
         DeviceContext& dev = need_device(ctx);
         std::unique_ptr<mp_peptides> p(new mp_peptides());
-        build_reference_device(dev.device(), std::string(fasta_text, len), peptide_len, p->res, false);
+        build_reference_device(dev.device(), std::string_view(fasta_text, len), peptide_len, p->res, false);
         *out = p.release();   // (the bincode image is built on demand: mp_peptides_binary)
     });
 }

@@ -34,7 +34,7 @@ std::string PeptideResult::binary() const {
     return b;
 }
 
-void build_reference_device(int device, const std::string& fasta_text, uint32_t L, PeptideResult& out, bool want_fasta) {
+void build_reference_device(int device, std::string_view fasta_text, uint32_t L, PeptideResult& out, bool want_fasta) {
     if (L == 0 || L > 12) throw Error("peptide length must be 1..12 for the device peptidome (5-bit residue keys in a u64)");
     out = PeptideResult();
     out.peptide_len = L;

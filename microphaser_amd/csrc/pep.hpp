@@ -1,6 +1,7 @@
 // `microphaser build_reference` on the device (reference: src/peptides.rs:148-186, src/main.rs:146-169).
 #pragma once
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "model.hpp"
@@ -21,6 +22,6 @@ uint64_t peptide_to_key(const std::string& pep);
 
 // Translate every 3-nt-step window of every record of a nucleotide FASTA and de-duplicate, on HIP device `device`.
 // want_fasta = false: the peptidome (keys, binary) only - what a pipeline that feeds `filter` needs; the translated FASTA stays empty.
-void build_reference_device(int device, const std::string& fasta_text, uint32_t peptide_len, PeptideResult& out, bool want_fasta = true);
+void build_reference_device(int device, std::string_view fasta_text, uint32_t peptide_len, PeptideResult& out, bool want_fasta = true);   // (the text is read in place)
 
 }  // namespace mp
