@@ -68,12 +68,25 @@ def merge_by_gene(shards):
     for s in shards:
         if s["tsv"] and not header:
             header = s["tsv"][: s["off"][2][0]]
+    views = {id(s): {name: memoryview(s[name]) for name in out} for s in shards}   # slices without copies; b"".join copies once
+    run_s, run_k0, run_k1 = None, 0, 0     # a run of consecutive genes of one shard is one slice per stream
+
+    def flush():
+        if run_s is None:
+            return
+        for which, name in enumerate(("fasta", "normal_fasta", "tsv")):
+            off = run_s["off"][which]
+            if off:
+                out[name].append(views[id(run_s)][name][off[run_k0]: off[run_k1]])
+
     for g in sorted(owner):
         s, k = owner[g]
-        for which, name in enumerate(("fasta", "normal_fasta", "tsv")):
-            off = s["off"][which]
-            if off:
-                out[name].append(s[name][off[k]: off[k + 1]])
+        if s is run_s and k == run_k1:
+            run_k1 = k + 1
+        else:
+            flush()
+            run_s, run_k0, run_k1 = s, k, k + 1
+    flush()
     tsv_body = b"".join(out["tsv"])
     return dict(fasta=b"".join(out["fasta"]), normal_fasta=b"".join(out["normal_fasta"]), tsv=(header + tsv_body) if tsv_body else b"",
                 windows=sum(s.get("windows", 0) for s in shards))
