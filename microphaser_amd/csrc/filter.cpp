@@ -34,13 +34,30 @@ namespace {
 
 // One row of info.tsv (IDRecord, src/common.rs:350-373): text fields as views into the TSV buffer (or, for a quoted field, into the
 // arena that holds its unescaped form), numbers parsed.
-struct Row {
-    std::string_view id, transcript, gene_id, gene_name, chrom, strand, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
-        germline_aa_change, normal_sequence, mutant_sequence;
-    uint64_t offset = 0, frame = 0;
-    double freq = 0;
-    uint32_t depth = 0, nvar = 0, nsomatic = 0, nvariant_sites = 0, nsomvariant_sites = 0;
+// a string_view without a constructor, so that a Row can be created uninitialised (the parsing threads fill 8.8 M of them in place)
+struct SV {
+    const char* p;
+    size_t n;
+    SV& operator=(std::string_view v) { p = v.data(); n = v.size(); return *this; }
+    operator std::string_view() const { return std::string_view(p, n); }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    const char* data() const { return p; }
+    char back() const { return p[n - 1]; }
+    size_t find(char c) const { return std::string_view(p, n).find(c); }
 };
+inline bool operator==(const SV& a, const SV& b) { return std::string_view(a) == std::string_view(b); }
+inline bool operator!=(const SV& a, const SV& b) { return !(a == b); }
+inline bool operator==(const SV& a, const char* b) { return std::string_view(a) == std::string_view(b); }
+
+struct Row {
+    SV id, transcript, gene_id, gene_name, chrom, strand, variant_sites, somatic_positions, somatic_aa_change, germline_positions,
+        germline_aa_change, normal_sequence, mutant_sequence;
+    uint64_t offset, frame;
+    double freq;
+    uint32_t depth, nvar, nsomatic, nvariant_sites, nsomvariant_sites;
+};
+using RowVec = PodVec<Row>;   // rows are sized once and filled in place by the parsing threads (no zero fill: 250 bytes x 8.8 M rows)
 
 uint64_t field_u64(std::string_view s, const char* name) {
     uint64_t v = 0;
@@ -86,7 +103,7 @@ void row_from_fields(const std::string_view* f, size_t n, Row& r) {   // serde p
 // Unquoted fields (all of them in what `somatic` writes, unless a value holds a tab, a quote or a line break) are byte ranges of the
 // buffer; a field that starts with a quote is unescaped into `arena` ("" is a quote; the closing quote ends the quoting, further bytes
 // up to the delimiter are appended).
-void parse_rows(const char* p, const char* const end, size_t skip, std::vector<Row>& rows, std::deque<std::string>& arena) {
+void parse_rows(const char* p, const char* const end, size_t skip, RowVec& rows, std::deque<std::string>& arena) {
     std::vector<std::string_view> rec;
     rec.reserve(32);
     bool started = false;        // the current record holds at least one field or delimiter
@@ -132,6 +149,47 @@ void parse_rows(const char* p, const char* const end, size_t skip, std::vector<R
     end_record();
 }
 
+// The same for a text without a quote and without a carriage return (what `somatic` writes): lines end at '\n', fields at '\t' - both
+// found with memchr instead of a byte loop.
+// A record of such a text = a non-empty line; counted first so that every part's rows get their place in the one row array.
+size_t count_plain_records(const char* p, const char* const end) {
+    size_t n = 0;
+    while (p < end) {
+        const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
+        const char* const le = nl ? nl : end;
+        n += le > p;
+        p = nl ? nl + 1 : end;
+    }
+    return n;
+}
+void parse_rows_plain(const char* p, const char* const end, size_t skip, Row* out, size_t n_out) {
+    std::string_view rec[32];
+    size_t k = 0;
+    while (p < end) {
+        const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
+        const char* const le = nl ? nl : end;
+        if (le > p) {   // (an empty line is no record)
+            size_t nf = 0;
+            std::vector<std::string_view> many;   // a record with more fields than the fixed array holds (reported as malformed anyway)
+            for (const char* q = p;;) {
+                const char* tab = static_cast<const char*>(std::memchr(q, '\t', size_t(le - q)));
+                const std::string_view f(q, size_t((tab ? tab : le) - q));
+                if (nf < 32) rec[nf] = f; else { if (many.empty()) many.assign(rec, rec + 32); many.push_back(f); }
+                nf++;
+                if (!tab) break;
+                q = tab + 1;
+            }
+            if (skip) skip--;
+            else {
+                if (k >= n_out) throw Error("internal error: TSV record count changed between the two passes");
+                row_from_fields(many.empty() ? rec : many.data(), nf, out[k++]);
+            }
+        }
+        p = nl ? nl + 1 : end;
+    }
+    if (k != n_out) throw Error("internal error: TSV record count changed between the two passes");
+}
+
 // Threads of the host legs, in order: the error of the earliest part is the one reported (what a sequential pass would have hit first).
 template <class F> void run_parts(size_t n, F f) {
     std::vector<std::exception_ptr> errors(n);
@@ -145,12 +203,13 @@ template <class F> void run_parts(size_t n, F f) {
 
 // All rows of the TSV (first record = header). Without a quote anywhere in the text no field spans lines, so the text is cut at line
 // breaks and the parts are parsed by all host threads; rows stay in file order.
-void parse_tsv(std::string_view text, std::vector<Row>& rows, std::deque<std::string>& arena) {
+void parse_tsv(std::string_view text, RowVec& rows, std::deque<std::string>& arena) {
     const char* const b = text.data();
     const char* const e = b + text.size();
     size_t parts = std::min<size_t>(host_threads(), text.size() / (4u << 20) + 1);
-    // part 0 must hold the header (the first record that holds anything): a text that opens with a blank line is parsed in one piece
-    if (parts > 1 && (*b == '\n' || *b == '\r' || std::memchr(b, '"', text.size()) != nullptr)) parts = 1;
+    // the threaded form needs records that are lines: no quote (a quoted field may hold a line break), no carriage return; and part 0
+    // must hold the header (the first record that holds anything): a text that opens with a blank line is parsed in one piece
+    if (parts > 1 && (*b == '\n' || std::memchr(b, '"', text.size()) != nullptr || std::memchr(b, '\r', text.size()) != nullptr)) parts = 1;
     if (parts <= 1) {
         size_t nl = 0;
         for (const char* q = b; (q = static_cast<const char*>(std::memchr(q, '\n', size_t(e - q)))) != nullptr; q++) nl++;
@@ -166,21 +225,15 @@ void parse_tsv(std::string_view text, std::vector<Row>& rows, std::deque<std::st
         const char* nl = static_cast<const char*>(std::memchr(q, '\n', size_t(e - q)));
         cut[t] = nl ? nl + 1 : e;
     }
-    std::vector<std::vector<Row>> part_rows(parts);
-    std::vector<std::deque<std::string>> part_arena(parts);   // stays empty: no quotes
-    run_parts(parts, [&](size_t t) {
-        size_t nl = 0;
-        for (const char* q = cut[t]; (q = static_cast<const char*>(std::memchr(q, '\n', size_t(cut[t + 1] - q)))) != nullptr; q++) nl++;
-        part_rows[t].reserve(nl + 1);
-        parse_rows(cut[t], cut[t + 1], t == 0 ? 1 : 0, part_rows[t], part_arena[t]);
-    });
-    (void)arena;
-    size_t total = 0;
-    for (auto& v : part_rows) total += v.size();
-    rows.resize(total);
+    // pass 1: the parts' record counts -> every part's slice of the row array; pass 2: the rows, parsed in place
     std::vector<size_t> at(parts + 1, 0);
-    for (size_t t = 0; t < parts; t++) at[t + 1] = at[t] + part_rows[t].size();
-    run_parts(parts, [&](size_t t) { std::copy(part_rows[t].begin(), part_rows[t].end(), rows.begin() + ptrdiff_t(at[t])); });
+    run_parts(parts, [&](size_t t) { at[t + 1] = count_plain_records(cut[t], cut[t + 1]); });
+    if (at[1] == 0) throw Error("internal error: TSV header not in the first part");
+    at[1] -= 1;   // the header
+    for (size_t t = 0; t < parts; t++) at[t + 1] += at[t];
+    rows.resize(at[parts]);
+    advise_huge(rows.data(), rows.size() * sizeof(Row));
+    run_parts(parts, [&](size_t t) { parse_rows_plain(cut[t], cut[t + 1], t == 0 ? 1 : 0, rows.data() + at[t], at[t + 1] - at[t]); });
 }
 
 // FilteredRecord::FIELD_NAMES_AS_ARRAY (src/peptides.rs:21-47)
@@ -307,7 +360,7 @@ void filter_device(int device, std::string_view reference_binary, const std::vec
     lap("reference set decoded");
 
     // ---- rows and their two nucleotide windows
-    std::vector<Row> rows;
+    RowVec rows;
     std::deque<std::string> arena;
     parse_tsv(tsv_text, rows, arena);
     lap("tsv parsed");
