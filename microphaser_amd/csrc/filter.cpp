@@ -23,6 +23,7 @@
 #include "kernels_filter.hpp"
 #include "kernels_pep.hpp"
 #include "pep.hpp"
+#include "rowfmt.hpp"
 #include "util.hpp"
 
 namespace mp {
@@ -242,42 +243,26 @@ const char* const FILTERED_HEADER =
     "strand\tvariant_sites\tsomatic_positions\tsomatic_aa_change\tgermline_positions\tgermline_aa_change\tnormal_sequence\tmutant_sequence\t"
     "normal_peptide\ttumor_peptide\n";
 
-// csv crate, QuoteStyle::Necessary with delimiter '\t' (= tsv_field of util.hpp on a view)
-void put_field(std::string& out, std::string_view f) {
-    bool need = false;
-    for (char c : f)
-        if (c == '\t' || c == '"' || c == '\n' || c == '\r') { need = true; break; }
-    if (!need) { out.append(f.data(), f.size()); return; }
-    out.push_back('"');
-    for (char c : f) {
-        if (c == '"') out.push_back('"');
-        out.push_back(c);
-    }
-    out.push_back('"');
-}
-void put_u64(std::string& out, uint64_t v) {
-    char buf[24];
-    const auto r = std::to_chars(buf, buf + sizeof buf, v);
-    out.append(buf, size_t(r.ptr - buf));
-}
-void put_fasta(std::string& out, std::string_view id, const uint8_t* seq, size_t n) {   // bio::io::fasta::Writer::write(id, None, seq)
-    out.push_back('>');
-    out.append(id.data(), id.size());
-    out.push_back('\n');
-    out.append(reinterpret_cast<const char*>(seq), n);
-    out.push_back('\n');
-}
-void write_filtered_record(std::string& t, const Row& r, double freq, std::string_view id, const char* ci, std::string_view normal_pep,
+// One filtered row (FilteredRecord, src/peptides.rs:21-47), formatted in place at the end of its stream (rowfmt.hpp cursor writers)
+void write_filtered_record(TextBuf& t, const Row& r, double freq, std::string_view id, std::string_view ci, std::string_view normal_pep,
                            std::string_view tumor_pep) {
-    auto S = [&](std::string_view f) { put_field(t, f); t.push_back('\t'); };
-    auto U = [&](uint64_t v) { put_u64(t, v); t.push_back('\t'); };
+    const std::string_view text[] = {id, r.transcript, r.gene_id, r.gene_name, r.chrom, ci, r.strand, r.variant_sites, r.somatic_positions,
+                                     r.somatic_aa_change, r.germline_positions, r.germline_aa_change, r.normal_sequence, r.mutant_sequence,
+                                     normal_pep, tumor_pep};
+    size_t bound = 7 * 21 + 33 + 1;
+    for (std::string_view f : text) bound += field_bound(f);
+    char* const b = t.room(bound);
+    char* q = b;
+    auto S = [&](std::string_view f) { q = cur_field(q, f); *q++ = '\t'; };
+    auto U = [&](uint64_t v) { q = cur_u64(q, v); *q++ = '\t'; };
     S(id); S(r.transcript); S(r.gene_id); S(r.gene_name); S(r.chrom); U(r.offset); U(r.frame);
-    t += fmt_f64(freq); t.push_back('\t');
+    q = cur_f64(q, freq); *q++ = '\t';
     S(ci); U(r.depth); U(r.nvar); U(r.nsomatic); U(r.nvariant_sites); U(r.nsomvariant_sites);
     S(r.strand); S(r.variant_sites); S(r.somatic_positions); S(r.somatic_aa_change); S(r.germline_positions); S(r.germline_aa_change);
     S(r.normal_sequence); S(r.mutant_sequence); S(normal_pep);
-    put_field(t, tumor_pep);
-    t.push_back('\n');
+    q = cur_field(q, tumor_pep);
+    *q++ = '\n';
+    t.advance(size_t(q - b));
 }
 
 // The peptides already seen in the current (transcript, somatic_positions, germline_positions) run (seen_peptides, :262-400): a handful
@@ -628,7 +613,7 @@ void filter_device(int device, std::string_view reference_binary, const std::vec
         // ---- emission (:483-533, :662-706): the entries in order, written by all host threads (entry ranges) and joined
         for (const Entry& e : entries)
             if (ci[e.group].status) throw Error("reference would panic: called `Option::unwrap()` on a `None` value (partial_cmp of a NaN likelihood)");
-        struct Streams { std::string tsv, removed_tsv, fasta, normal_fasta, removed_fasta; uint64_t kept = 0, removed = 0; };
+        struct Streams { TextBuf tsv, removed_tsv, fasta, normal_fasta, removed_fasta; uint64_t kept = 0, removed = 0; };
         const size_t parts = std::max<size_t>(1, std::min<size_t>(threads, entries.size() / 2048 + 1));
         std::vector<Streams> part(parts);
         run_parts(parts, [&](size_t t) {
@@ -643,7 +628,7 @@ void filter_device(int device, std::string_view reference_binary, const std::vec
                 char buf[64];
                 std::snprintf(buf, sizeof buf, "%.2f-%.2f", c.a, c.b);
                 id.clear();
-                put_u64(id, e.i1);
+                append_u64(id, e.i1);
                 id.push_back('_');
                 id.append(row.id.data(), row.id.size());
                 const double freq = row.depth == 0 ? 0.0 : double(c.ml) * 0.01;
@@ -663,16 +648,16 @@ void filter_device(int device, std::string_view reference_binary, const std::vec
         });
         for (const Streams& o : part) { out.n_kept += o.kept; out.n_removed += o.removed; }
         const std::string_view header(FILTERED_HEADER);
-        auto join = [&](PodVec<char>& dst, std::string Streams::*m, bool with_header) {
+        auto join = [&](PodVec<char>& dst, TextBuf Streams::*m, bool with_header) {
             std::vector<size_t> at(parts + 1, with_header ? header.size() : 0);
             for (size_t t = 0; t < parts; t++) at[t + 1] = at[t] + (part[t].*m).size();
             dst.resize(at[parts]);
             advise_huge(dst.data(), dst.size());
             if (with_header) std::memcpy(dst.data(), header.data(), header.size());
             run_parts(parts, [&](size_t t) {
-                std::string& src = part[t].*m;
+                TextBuf& src = part[t].*m;
                 if (!src.empty()) std::memcpy(dst.data() + at[t], src.data(), src.size());
-                std::string().swap(src);
+                src = TextBuf();
             });
         };
         join(out.tsv, &Streams::tsv, true);
