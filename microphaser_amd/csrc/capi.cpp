@@ -328,7 +328,7 @@ int mp_peptidome_from_buffer(mp_ctx* ctx, const char* fasta_text, size_t len, ui
 const char* mp_peptides_fasta(const mp_peptides* p, size_t* len) { if (len) *len = p->res.fasta.size(); return p->res.fasta.data(); }
 const char* mp_peptides_binary(const mp_peptides* p, size_t* len) {
     mp_peptides* q = const_cast<mp_peptides*>(p);
-    if (q->bin.empty() && !q->res.keys.empty()) q->bin = q->res.binary();   // built on first use
+    std::call_once(q->bin_once, [q] { if (q->bin.empty()) q->bin = q->res.binary(); });   // (no peptides: u64 0, like serialize_into of an empty HashSet)
     if (len) *len = q->bin.size();
     return q->bin.data();
 }

@@ -1,6 +1,7 @@
 // C ABI, second part: the phase_gene-level boundary (decoded records in, include/microphaser_hip.h mp_gene_batch), gene lists,
 // per-gene stream offsets, translation and the peptidome union - what a host that keeps its own readers and its own multi-GPU
 // work queue binds (reference seam: src/microphasing.rs:882-893, :1963-1979; src/peptides.rs:128-186).
+#include <atomic>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -275,6 +276,23 @@ int mp_peptides_union(mp_ctx* ctx, const uint64_t* const* keys, const uint64_t* 
         for (uint32_t a = 0; a < n_arrays; a++) if (counts[a] > counts[longest]) longest = a;
         const uint64_t n_long = n_arrays ? counts[longest] : 0;
         const size_t parts = std::max<size_t>(1, std::min<size_t>(host_threads(), size_t(n_long / 65536 + 1)));
+        {   // every array is checked WHOLE before anything is derived from it (pivots from an unsorted array are not ascending, and a
+            // lower_bound pair on unsorted data can come out reversed): one linear pass, the arrays' chunks dealt to the host threads
+            std::atomic<bool> bad{false};
+            auto check = [&](size_t t) {
+                for (uint32_t a = 0; a < n_arrays; a++) {
+                    const uint64_t* k = keys[a];
+                    const uint64_t n = counts[a], lo = n * t / parts, hi = n * (t + 1) / parts;
+                    for (uint64_t i = std::max<uint64_t>(lo, 1); i < hi; i++)   // (incl. the pair that straddles the chunk's lower end)
+                        if (k[i] <= k[i - 1]) { bad = true; return; }
+                }
+            };
+            std::vector<std::thread> cth;
+            for (size_t t = 1; t < parts; t++) cth.emplace_back(check, t);
+            check(0);
+            for (auto& x : cth) x.join();
+            if (bad) throw Error("mp_peptides_union: key arrays must be sorted and distinct");
+        }
         std::vector<uint64_t> pivot(parts + 1, 0);           // slice t takes the keys in [pivot[t], pivot[t + 1]); the last one is open
         for (size_t t = 1; t < parts; t++) pivot[t] = keys[longest][n_long * t / parts];
         std::vector<std::vector<uint64_t>> slice(parts);
@@ -288,9 +306,7 @@ int mp_peptides_union(mp_ctx* ctx, const uint64_t* const* keys, const uint64_t* 
                     const uint64_t n = counts[a];
                     const uint64_t* lo = t == 0 ? k : std::lower_bound(k, k + n, pivot[t]);
                     const uint64_t* hi = t + 1 == parts ? k + n : std::lower_bound(k, k + n, pivot[t + 1]);
-                    for (const uint64_t* q = lo; q < hi; q++)   // (incl. the pair that straddles the slice's lower end)
-                        if (q > k && q[0] <= q[-1]) throw Error("mp_peptides_union: key arrays must be sorted and distinct");
-                    if (lo == hi) continue;
+                    if (lo >= hi) continue;
                     if (acc.empty()) { acc.assign(lo, hi); continue; }
                     tmp.resize(acc.size() + size_t(hi - lo));
                     tmp.resize(size_t(std::set_union(acc.begin(), acc.end(), lo, hi, tmp.begin()) - tmp.begin()));

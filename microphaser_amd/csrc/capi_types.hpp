@@ -1,5 +1,6 @@
 // Internal: the opaque C-ABI handle types (include/microphaser_hip.h) and the exception guard, shared by capi*.cpp.
 #pragma once
+#include <mutex>
 #include <memory>
 #include <string>
 
@@ -39,7 +40,8 @@ struct mp_filtered {
 };
 struct mp_peptides {
     PeptideResult res;
-    std::string bin;
+    std::string bin;            // bincode image of the set (src/peptides.rs:183); an EMPTY set still encodes as its 8-byte length
+    std::once_flag bin_once;    // built eagerly by mp_build_reference*, else on the first mp_peptides_binary (any thread)
 };
 
 namespace {

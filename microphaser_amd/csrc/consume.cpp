@@ -130,7 +130,7 @@ void record_add_freq(IDRecord& r, double freq) {
     r.freq = r.freq > 0.5 ? r.freq : r.freq + freq;
 }
 
-// MP_TRACE=<file>: one line per print_haplotypes call / merge (debugging aid, compared with the oracle's trace by tools/dbg_trace_case.py)
+// MP_TRACE=<file>: one line per print_haplotypes call / merge (debugging aid: the oracle writes the same trace)
 static const char* trace_path() { static const char* const p = std::getenv("MP_TRACE"); return p; }
 
 struct ConsumerHooks {

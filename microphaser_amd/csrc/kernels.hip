@@ -199,7 +199,18 @@ __device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, 
     const uint64_t b0 = (uint64_t(rdlane(uint32_t(base >> 32), leader)) << 32) | rdlane(uint32_t(base), leader);
     // one 16-byte item per listed group: its slot, its window and the record slot K2 reserved (0xFFFFFFFF = none) - K3 fetches the
     // window's static record straight from the item, without a hop through per-group arrays (a list is as long as its slots at most)
-    if (on) d.k3_items[(uint64_t(part) << d.group_part_log2) + b0 + lanes_below(m, lane)] = make_uint4(uint32_t(slot), win, rec, 0u);
+    // (a list cannot outgrow its sub-range while the groups fit theirs - one entry per group slot at most - but the cursor also counts
+    //  the entries of waves whose groups did NOT fit: never store past the sub-range, flag the pass instead; it is run again, larger)
+    if (on) {
+        const uint64_t at = b0 + lanes_below(m, lane);
+        if (at < (1ull << d.group_part_log2)) d.k3_items[(uint64_t(part) << d.group_part_log2) + at] = make_uint4(uint32_t(slot), win, rec, 0u);
+        else atomicOr(d.err, WD_GROUP_OVERFLOW);
+    }
+}
+// A pass whose group / record arenas overflowed is discarded and run again with larger ones (DeviceContext::run); its K3 lists then hold
+// entries that were reserved but never written. K3 / K3b leave at once in that case (the error word is complete: the K2 kernels have ended).
+__device__ __forceinline__ bool pass_overflowed(const DeviceBatch& d) {
+    return (__builtin_nontemporal_load(d.err) & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) != 0;
 }
 
 template <int RPL>
@@ -795,6 +806,7 @@ template <int HB, int STAGE_>   // STAGE_: RowRecs staged in LDS per pass (24 by
 __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t first, uint32_t count) {
     constexpr uint32_t NW = (1u << HB) / 4;   // table words per lane (four 8-bit counters each); NW <= 64
     constexpr uint32_t STAGE = STAGE_ ? STAGE_ : 1;
+    static_assert(STAGE_ == 0 || STAGE_ > int(K2L_MAX_ROWS), "a window's candidate reads must fit one stage pass, or the staging loop never ends");
     __shared__ uint32_t hist[NW * 64];
     __shared__ uint4 st_a[STAGE];
     __shared__ uint64_t st_s[STAGE];
@@ -945,8 +957,12 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         const uint64_t gbase = (uint64_t(rdlane(uint32_t(got >> 32), 0)) << 32) | rdlane(uint32_t(got), 0);
         const uint64_t rbase = (uint64_t(rdlane(uint32_t(got >> 32), 1)) << 32) | rdlane(uint32_t(got), 1);
-        uint64_t lslot = gpart_lo + ((uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2)) + (scan3 - n3);
-        const bool can_write = gbase + tot_g <= gpart_size;
+        const uint64_t lbase = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
+        uint64_t lslot = gpart_lo + lbase + (scan3 - n3);
+        // (the list cursor also counts the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
+        //  still find its list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
+        //  word makes it leave and the pass is run again with larger arenas)
+        const bool can_write = gbase + tot_g <= gpart_size && lbase + tot_3 <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
         if (!can_write) werr |= WD_GROUP_OVERFLOW;
@@ -2091,6 +2107,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     // blockIdx.y = the output allocator whose list this workgroup walks; the list's length is only known on the device - one scalar
     // load of its cursor (no prefix table, no search) - and the grid's x extent covers the host's upper bound of it
     const uint32_t lpart = blockIdx.y;
+    if (pass_overflowed(d)) return;
     const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + 8], 1ull << d.group_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
     const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue)
@@ -2466,6 +2483,7 @@ template <int SEQ_CAP>
 __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d) {
     __shared__ uint32_t lds_slots[K3_THREADS * K3Cfg<SEQ_CAP>::SLOT_DW];
     const uint32_t lpart = blockIdx.y;   // (as in k3_window_seq: one allocator's list per grid row)
+    if (pass_overflowed(d)) return;
     const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + 8], 1ull << d.group_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
         const uint64_t li = tile * K3_THREADS + threadIdx.x;
@@ -2496,6 +2514,7 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) 
     }
     __syncthreads();
     const uint32_t wp = blockIdx.y;      // the list of wanted records this workgroup walks; its length: one scalar load (known on the device only)
+    if (pass_overflowed(d)) return;
     const uint64_t n_recs = min((unsigned long long)d.cursors[wp * 32 + 24], 1ull << d.rec_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3B_THREADS < n_recs; tile += gridDim.x) {
     const uint64_t li = tile * K3B_THREADS + threadIdx.x;   // index into this list
@@ -2684,7 +2703,6 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipS
     static const int stage = [] { const char* e = std::getenv("MP_K2L_STAGE"); return e ? std::atoi(e) : 256; }();   // experiments
     switch (stage) {
         case 0: launch_k2l<0>(d, stream_small, stream_wide); break;
-        case 128: launch_k2l<128>(d, stream_small, stream_wide); break;
         case 384: launch_k2l<384>(d, stream_small, stream_wide); break;
         default: launch_k2l<256>(d, stream_small, stream_wide); break;
     }

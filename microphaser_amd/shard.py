@@ -98,45 +98,57 @@ def _bytes_tensor(torch, data, device):
 
 
 def gather_shards(local, dist=None, dst=0, device="cpu"):
-    """Gather every rank's shard_of() dict on `dst` (list in rank order): the byte streams and offset tables travel as uint8 /
-    int64 tensors (sizes first, then one padded all_gather per field), not as pickled Python objects."""
+    """Gather every rank's shard_of() dict on `dst` (list in rank order; None elsewhere): the byte streams and offset tables travel as
+    uint8 / int64 tensors, not as pickled Python objects. Only `dst` merges, so only `dst` receives: the field sizes are all-gathered
+    (a few integers per rank), then every other rank SENDS its fields to `dst` point to point at their exact sizes - no padding, and no
+    rank holds world x max-size bytes of FASTA / TSV it will never read (an all_gather of config E's streams is gigabytes per rank)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [local]
     import torch
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     fields = [("fasta", "u8"), ("normal_fasta", "u8"), ("tsv", "u8"), ("genes", "i64"), ("off0", "i64"), ("off1", "i64"), ("off2", "i64")]
     loc = {"fasta": local["fasta"], "normal_fasta": local["normal_fasta"], "tsv": local["tsv"], "genes": local["genes"],
            "off0": local["off"][0], "off1": local["off"][1], "off2": local["off"][2]}
-    tens = {}
-    for name, kind in fields:
-        tens[name] = _bytes_tensor(torch, loc[name], device) if kind == "u8" else torch.tensor(loc[name], dtype=torch.int64, device=device)
-    sizes = torch.tensor([tens[n].numel() for n, _ in fields] + [int(local.get("windows", 0))], dtype=torch.int64, device=device)
+    sizes = torch.tensor([len(loc[n]) for n, _ in fields] + [int(local.get("windows", 0))], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    gathered = {}
-    for i, (name, kind) in enumerate(fields):
-        m = max(1, max(int(s[i].item()) for s in all_sizes))
-        pad = torch.zeros(m, dtype=tens[name].dtype, device=device)
-        pad[: tens[name].numel()] = tens[name]
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
-        gathered[name] = [b[: int(s[i].item())].cpu() for b, s in zip(bufs, all_sizes)]
-    if dist.get_rank() != dst:
+    all_sizes = [s.cpu().tolist() for s in all_sizes]
+    if rank != dst:
+        for name, kind in fields:
+            if len(loc[name]) == 0:
+                continue   # (nothing to send: dst knows the size)
+            t = _bytes_tensor(torch, loc[name], device) if kind == "u8" else torch.tensor(loc[name], dtype=torch.int64, device=device)
+            dist.send(t, dst=dst)
+            del t
         return None
     out = []
     for r in range(world):
-        g = {n: gathered[n][r] for n, _ in fields}
+        if r == dst:
+            out.append(dict(genes=list(local["genes"]), fasta=local["fasta"], normal_fasta=local["normal_fasta"], tsv=local["tsv"],
+                            off=[list(o) for o in local["off"]], windows=int(local.get("windows", 0))))
+            continue
+        g = {}
+        for i, (name, kind) in enumerate(fields):
+            n = int(all_sizes[r][i])
+            buf = torch.empty(n, dtype=torch.uint8 if kind == "u8" else torch.int64, device=device)
+            if n:
+                dist.recv(buf, src=r)
+            g[name] = buf.cpu()
+            del buf
         out.append(dict(genes=g["genes"].tolist(), fasta=bytes(g["fasta"].numpy()), normal_fasta=bytes(g["normal_fasta"].numpy()),
                         tsv=bytes(g["tsv"].numpy()), off=[g["off0"].tolist(), g["off1"].tolist(), g["off2"].tolist()],
-                        windows=int(all_sizes[r][len(fields)].item())))
+                        windows=int(all_sizes[r][len(fields)])))
     return out
 
 
 def allgather_keys(local_keys, dist=None, device="cpu"):
     """The exchange step of the multi-GPU build_reference: every rank contributes its sorted distinct u64 peptide keys (a numpy
     uint64 array or a torch int64 tensor - keys are < 2^60), every rank gets the list of all ranks' arrays (numpy uint64).
-    Variable-length all-gather = exchange the counts, pad to the maximum, one all_gather (~10 MB per rank at config E: a single
-    direct all-gather over xGMI, no ring needed)."""
+    Variable-length all-gather = exchange the counts, pad to the maximum, one all_gather. Size at config E: the 20000-transcript
+    exome's peptidome is 70 M distinct 9-mers = 560 MB of keys (measured, profiles/r04o_config_e_20k_one_gpu.json); every distinct key
+    is on at least one rank, so the ranks' arrays sum to >= 560 MB - >= 70 MB per rank at N = 8 - and every rank receives that sum.
+    xGMI is point to point (7 links x ~153 GB/s per GPU): ~0.6 GB per rank is a few milliseconds for RCCL's all-gather, small
+    beside the sort / unique that produced the keys. (Unmeasured on a multi-GPU node.)"""
     import numpy as np
     import torch
     if isinstance(local_keys, torch.Tensor):
