@@ -12,7 +12,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "_lib")
+# MP_LIB_DIR: another build of the same library (csrc/Makefile SAN=...: the sanitizer builds of the host side, CPU suite only)
+LIB_DIR = os.environ.get("MP_LIB_DIR") or os.path.join(_HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmicrophaser_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "microphaser")
 
@@ -24,6 +25,8 @@ STREAM_FASTA, STREAM_NORMAL_FASTA, STREAM_TSV, STREAM_ALL = 1, 2, 4, 7   # mp_ba
 def build(verbose=False):
     """Compile the HIP library + CLI for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if os.environ.get("MP_LIB_DIR"):
+        return   # a sanitizer build is made by its own make invocation (tools/run_sanitized.sh), never implicitly
     r = subprocess.run(cmd, capture_output=not verbose, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libmicrophaser_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))

@@ -43,6 +43,7 @@ int mp_create(int device, mp_ctx** out) {
     if (!out) return 1;
     *out = nullptr;
     std::unique_ptr<mp_ctx> c(new mp_ctx());
+    reaper_retain();   // (released by mp_destroy: the last context to go joins the library's worker thread)
     int rc = guarded(c.get(), [&] {
         if (device >= 0) c->dev.reset(new DeviceContext(device));
     });
@@ -51,7 +52,11 @@ int mp_create(int device, mp_ctx** out) {
     return rc;
 }
 
-void mp_destroy(mp_ctx* ctx) { delete ctx; }
+void mp_destroy(mp_ctx* ctx) {
+    if (!ctx) return;
+    delete ctx;
+    reaper_release();   // scratch handed to release_later is gone, and no thread of the library is left, once the last context is
+}
 
 const char* mp_last_error(const mp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

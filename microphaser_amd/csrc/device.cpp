@@ -22,6 +22,8 @@ DeviceContext::DeviceContext(int device) : device_(device) {
     for (auto& st : side_) HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto& ev : fork_) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&cleared_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&k3_fork_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&k3_join_, hipEventDisableTiming));
     for (auto& ev : join_) HIP_OK(hipEventCreate(&ev));
 }
 
@@ -31,6 +33,8 @@ DeviceContext::~DeviceContext() {
     for (auto& ev : ev_) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : fork_) if (ev) (void)hipEventDestroy(ev);
     if (cleared_) (void)hipEventDestroy(cleared_);
+    if (k3_fork_) (void)hipEventDestroy(k3_fork_);
+    if (k3_join_) (void)hipEventDestroy(k3_join_);
     for (auto& ev : join_) if (ev) (void)hipEventDestroy(ev);
     for (auto& st : side_) if (st) (void)hipStreamDestroy(st);
     if (stream_) hipStreamDestroy(stream_);
@@ -161,7 +165,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.err = reinterpret_cast<uint32_t*>(d_.cursors + NPART * 32);   // the error word sits behind the cursors: one memset, one copy back per pass
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
-    last_slots_ = last_recs_ = last_want_ = last_k3_ = 0;
+    last_slots_ = last_recs_ = last_want_ = last_k3a_ = last_k3b_ = 0;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
@@ -233,13 +237,23 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(join_[1], side_[1]));
         for (auto& ev : join_) HIP_OK(hipStreamWaitEvent(stream_, ev, 0));
         HIP_OK(hipEventRecord(ev_[2], stream_));
-        // K3 walks the used slots of all allocators and lists the records that need an id; K3b walks those lists
-        // (their grids cover an upper bound of the counts: the previous pass's counts of this batch plus a margin, else an estimate)
-        const uint64_t slot_bound = last_slots_ ? last_k3_ + last_k3_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 8 + 65536);
+        // K3 walks the lists the K2 kernels made: list A (sequences, records and - somatic - their ids in one kernel) and, beside it on a
+        // side stream, list B (flags only). `normal`: K3n over list A, then K3b over the records K3n wants ids for.
+        // (the grids cover an upper bound of the list lengths: the previous pass's counts of this batch plus a margin, else an estimate)
+        const uint64_t a_bound = last_slots_ ? last_k3a_ + last_k3a_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * (d_.normal ? 8 : 2) + 65536);
+        const uint64_t b_bound = last_slots_ ? last_k3b_ + last_k3b_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 2 + 65536);
         const uint64_t want_bound = last_slots_ ? last_want_ + last_want_ / 16 + 4096 : std::min<uint64_t>(rec_cap_, uint64_t(d_.n_wins) * 2 + 65536);
-        launch_k3_window_seq(d_, slot_bound, stream_);
+        if (!d_.normal) {
+            HIP_OK(hipEventRecord(k3_fork_, stream_));
+            HIP_OK(hipStreamWaitEvent(side_[0], k3_fork_, 0));
+        }
+        launch_k3_window_seq(d_, a_bound, b_bound, stream_, side_[0]);
+        if (!d_.normal) {
+            HIP_OK(hipEventRecord(k3_join_, side_[0]));
+            HIP_OK(hipStreamWaitEvent(stream_, k3_join_, 0));
+        }
         HIP_OK(hipEventRecord(ev_[3], stream_));
-        launch_k3b_haplotype_ids(d_, want_bound, stream_);
+        if (d_.normal) launch_k3b_haplotype_ids(d_, want_bound, stream_);
         HIP_OK(hipEventRecord(ev_[4], stream_));
         std::vector<unsigned long long> cur(NPART * 32 + 1);
         HIP_OK(hipMemcpyAsync(cur.data(), d_.cursors, cur.size() * 8, hipMemcpyDeviceToHost, stream_));
@@ -268,14 +282,15 @@ void DeviceContext::run(RunTiming& t) {
             continue;
         }
         if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
-        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3 = 0;
+        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3a = 0, n_k3b = 0;
         for (uint32_t p = 0; p < NPART; p++) {
             used_g_[p] = cur[p * 32];
             used_r_[p] = cur[p * 32 + 16];
             slots += used_g_[p];
             rec_slots += used_r_[p];
             n_want += cur[p * 32 + 24];
-            n_k3 += cur[p * 32 + 8];
+            n_k3a += cur[p * 32 + 8];
+            n_k3b += cur[p * 32 + 12];
         }
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
@@ -294,11 +309,13 @@ void DeviceContext::run(RunTiming& t) {
         last_slots_ = slots;
         last_recs_ = rec_slots;
         last_want_ = n_want;
-        last_k3_ = n_k3;
+        last_k3a_ = n_k3a;
+        last_k3b_ = n_k3b;
         t.n_group_slots = slots;    // group slots K3 walked (incl. the unused tail of each wave's last chunk) / records K3b hashed
         t.n_recs = n_want;
         t.n_groups = slots;
-        t.n_k3 = n_k3;
+        t.n_k3 = n_k3a + n_k3b;
+        t.n_k3a = n_k3a;
         return;
     }
     throw Error("device result buffers kept overflowing");

@@ -1,4 +1,7 @@
 #include "io.hpp"
+#include <functional>
+#include <deque>
+#include <condition_variable>
 #include <cerrno>
 #include <unistd.h>
 #include <sys/stat.h>
@@ -31,6 +34,69 @@ void advise_huge(const void* p, size_t bytes) {
     (void)p; (void)bytes;
 #endif
 }
+
+// The reaper (model.hpp release_later): one owned worker thread, started by the first job, joined when the last context dies or the
+// library is torn down.
+namespace {
+struct Reaper {
+    std::mutex m;
+    std::condition_variable work_cv, idle_cv;
+    std::deque<std::function<void()>> q;
+    std::thread th;
+    bool running = false, stop = false, busy = false;
+    int users = 0;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            work_cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;   // (stop is only honoured once the queue is empty)
+            std::function<void()> job = std::move(q.front());
+            q.pop_front();
+            busy = true;
+            lk.unlock();
+            job();
+            job = nullptr;           // the held object dies here, outside the lock
+            lk.lock();
+            busy = false;
+            if (q.empty()) idle_cv.notify_all();
+        }
+    }
+    void post(std::function<void()> job) {
+        std::lock_guard<std::mutex> lk(m);
+        q.push_back(std::move(job));
+        if (!running) { stop = false; th = std::thread([this] { loop(); }); running = true; }
+        work_cv.notify_one();
+    }
+    void drain() {
+        std::unique_lock<std::mutex> lk(m);
+        idle_cv.wait(lk, [&] { return q.empty() && !busy; });
+    }
+    void shutdown() {
+        std::thread t;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!running) return;
+            stop = true;
+            running = false;
+            t = std::move(th);
+            work_cv.notify_all();
+        }
+        t.join();   // the loop leaves only with an empty queue
+    }
+    ~Reaper() { shutdown(); }
+};
+Reaper& reaper() { static Reaper r; return r; }
+}  // namespace
+void reaper_post(std::function<void()> job) { reaper().post(std::move(job)); }
+void reaper_retain() { Reaper& r = reaper(); std::lock_guard<std::mutex> lk(r.m); r.users++; }
+void reaper_release() {
+    Reaper& r = reaper();
+    bool last;
+    { std::lock_guard<std::mutex> lk(r.m); last = --r.users <= 0; if (last) r.users = 0; }
+    if (last) r.shutdown();
+}
+void reaper_drain() { reaper().drain(); }
+bool reaper_running() { Reaper& r = reaper(); std::lock_guard<std::mutex> lk(r.m); return r.running; }
 
 
 // =================================================================== BGZF / BAM

@@ -185,25 +185,34 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t lane) { 
 
 constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: one emit call)
 
-// K2 -> K3: the group slots K3 has to look at are appended to a dense list per output allocator (list p lives at
-// k3_items[p << group_part_log2 ...], its length in cursors[p * 32 + 8]); one wave-aggregated atomic per call. The lane-per-window
-// kernel settles most groups itself (no somatic column set, simple window without a possible stop: GroupSum = {GS_VALID}) and lists
-// only the rest, so K3 runs over ~1/5 of the groups instead of all of them and no longer scans (or needs cleared) unused slots.
+// K2 -> K3: the group slots K3 has to look at are appended to two dense lists per output allocator, both inside the allocator's
+// sub-range of k3_items (one 16-byte item {group slot, window, record slot, 0} per listed group):
+//   list A - groups K2 reserved a record slot for (a somatic column is set, or the planner wants every haplotype of the window): K3
+//            builds their sequences, hashes their ids and writes their records; grows upwards from the sub-range's first entry,
+//            length in cursors[p * 32 + 8]
+//   list B - the other listed groups (K3 only decides stop / differs / indel flags for them): grows downwards from the sub-range's
+//            last entry, length in cursors[p * 32 + 12]
+// so the lanes of a K3 wave all do the same kind of work (the SHA-1 of the ids is two thirds of K3's instructions; in one mixed list
+// 40 % of its lanes would idle through it). The lists cannot meet while the groups fit their sub-range (one entry per group slot at
+// most); one atomic instruction per call (two lanes, one per list). The lane-per-window kernel settles most groups itself (no somatic
+// column set, simple window without a possible stop: GroupSum = {GS_VALID}) and lists only the rest.
 __device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, bool on, uint64_t slot, uint32_t win, uint32_t rec) {
-    const uint64_t m = __ballot(on);
-    if (!m) return;
+    const bool to_a = on && rec != 0xFFFFFFFFu;
+    const uint64_t ma = __ballot(to_a), mb = __ballot(on && !to_a);
+    if (!(ma | mb)) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t leader = uint32_t(__builtin_ctzll(m));
+    const uint32_t la = ma ? uint32_t(__builtin_ctzll(ma)) : 64u, lb = mb ? uint32_t(__builtin_ctzll(mb)) : 64u;
     unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(d.cursors + part * 32 + 8, (unsigned long long)__popcll(m));
-    const uint64_t b0 = (uint64_t(rdlane(uint32_t(base >> 32), leader)) << 32) | rdlane(uint32_t(base), leader);
-    // one 16-byte item per listed group: its slot, its window and the record slot K2 reserved (0xFFFFFFFF = none) - K3 fetches the
-    // window's static record straight from the item, without a hop through per-group arrays (a list is as long as its slots at most)
-    // (a list cannot outgrow its sub-range while the groups fit theirs - one entry per group slot at most - but the cursor also counts
-    //  the entries of waves whose groups did NOT fit: never store past the sub-range, flag the pass instead; it is run again, larger)
+    if (lane == la || lane == lb)
+        base = atomicAdd(d.cursors + part * 32 + (lane == la ? 8 : 12), (unsigned long long)__popcll(lane == la ? ma : mb));
+    const uint32_t src = to_a ? (la & 63u) : (lb & 63u);
+    const uint64_t b0 = (uint64_t(uint32_t(__shfl(int(uint32_t(base >> 32)), int(src)))) << 32) | uint32_t(__shfl(int(uint32_t(base)), int(src)));
+    // (the cursors also count the entries of waves whose groups did NOT fit their sub-range: never store outside the sub-range, flag
+    //  the pass instead; it is run again with larger arenas and K3 never walks the lists of a flagged pass)
     if (on) {
-        const uint64_t at = b0 + lanes_below(m, lane);
-        if (at < (1ull << d.group_part_log2)) d.k3_items[(uint64_t(part) << d.group_part_log2) + at] = make_uint4(uint32_t(slot), win, rec, 0u);
+        const uint64_t size = 1ull << d.group_part_log2;
+        const uint64_t at = b0 + lanes_below(to_a ? ma : mb, lane);
+        if (at < size) d.k3_items[(uint64_t(part) << d.group_part_log2) + (to_a ? at : size - 1 - at)] = make_uint4(uint32_t(slot), win, rec, 0u);
         else atomicOr(d.err, WD_GROUP_OVERFLOW);
     }
 }
@@ -940,29 +949,33 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         const uint32_t total = rdlane(scan, 63);
         const uint32_t tot_g = total & 0xFFFF, tot_r = total >> 16;
-        const uint32_t n3 = trivial ? nneed : ng;        // groups of this window that K3 has to look at
-        uint32_t scan3 = n3;
+        // K3's two lists (k3_enqueue): A = the groups with a record slot (exactly the nneed ones: list A and the record slots advance in
+        // step, so their prefix is the one already at hand), B = the other groups of a window that is not trivial
+        const uint32_t nb = trivial ? 0u : ng - nneed;
+        uint32_t scanb = nb;
 #pragma unroll
         for (uint32_t off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(scan3, off);
-            if (lane >= off) scan3 += up;
+            const uint32_t up = __shfl_up(scanb, off);
+            if (lane >= off) scanb += up;
         }
-        const uint32_t tot_3 = rdlane(scan3, 63);
-        // the tile's three allocations - group slots, record slots, K3 list entries - in ONE atomic instruction: lanes 0, 1, 2 each add
-        // to their own cursor (three in a row, each under its own condition, were three dependent round trips to L2)
+        const uint32_t tot_b = rdlane(scanb, 63);
+        // the tile's four allocations - group slots, record slots, entries of K3's two lists - in ONE atomic instruction: lanes 0..3 each
+        // add to their own cursor (one after the other, each under its own condition, they were dependent round trips to L2)
         unsigned long long got = 0;
-        if (lane < 3) {
-            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : gcur + 8;
-            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : tot_3));
+        if (lane < 4) {
+            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : lane == 2 ? gcur + 8 : gcur + 12;
+            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 3 ? tot_b : tot_r));
         }
         const uint64_t gbase = (uint64_t(rdlane(uint32_t(got >> 32), 0)) << 32) | rdlane(uint32_t(got), 0);
         const uint64_t rbase = (uint64_t(rdlane(uint32_t(got >> 32), 1)) << 32) | rdlane(uint32_t(got), 1);
-        const uint64_t lbase = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
-        uint64_t lslot = gpart_lo + lbase + (scan3 - n3);
-        // (the list cursor also counts the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
-        //  still find its list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
-        //  word makes it leave and the pass is run again with larger arenas)
-        const bool can_write = gbase + tot_g <= gpart_size && lbase + tot_3 <= gpart_size;
+        const uint64_t la_base = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
+        const uint64_t lb_base = (uint64_t(rdlane(uint32_t(got >> 32), 3)) << 32) | rdlane(uint32_t(got), 3);
+        uint64_t la_slot = gpart_lo + la_base + ((scan >> 16) - nneed);                       // list A: upwards from the sub-range's first entry
+        uint64_t lb_slot = gpart_lo + gpart_size - 1 - (lb_base + (scanb - nb));              // list B: downwards from its last
+        // (the list cursors also count the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
+        //  still find a list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
+        //  word makes it leave and the pass is run again with larger arenas. The two lists cannot meet unless the groups overflow.)
+        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_r <= gpart_size && lb_base + tot_b <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
         if (!can_write) werr |= WD_GROUP_OVERFLOW;
@@ -987,8 +1000,9 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                             const bool settled = trivial && !need;   // what K3 would find: valid, no stop, mutant == germline, no record
                             Group G; G.hap = key; G.count = cnt; G.aux = settled ? GROUP_SETTLED : 0u;
                             d.groups[gslot] = G;
-                            if (!settled)   // the rest is for K3 only: one item (k3_enqueue's layout)
-                                d.k3_items[lslot++] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                            // the rest is for K3 only: one item (k3_enqueue's layout) in list A or B
+                            if (need) d.k3_items[la_slot++] = make_uint4(uint32_t(gslot), win, rec_ok ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                            else if (!settled) d.k3_items[lb_slot--] = make_uint4(uint32_t(gslot), win, 0xFFFFFFFFu, 0u);
                         }
                         gslot++;
                         rslot += need ? 1u : 0u;
@@ -2099,21 +2113,115 @@ __device__ __forceinline__ bool stop_codon_at(const uint8_t* s, uint32_t c, bool
     return (a == 'T' && b == 'C' && e == 'A') || (a == 'C' && b == 'T' && e == 'A') || (a == 'T' && b == 'T' && e == 'A');
 }
 
+// ---- haplotype ids: id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
+constexpr uint32_t K3B_BUF_WORDS = 48;   // three SHA-1 blocks per thread (a 27..31-nt window + an id of <= 17 characters always fits)
+// decimal text of a byte value followed by ", ", packed big-endian: text << 8 | length (256 entries, filled by the workgroup)
+__device__ __forceinline__ void fill_byte_text(uint64_t* byte_text, uint32_t n_threads) {
+    for (uint32_t v = threadIdx.x; v < 256; v += n_threads) {
+        uint64_t txt;
+        uint32_t n;
+        if (v >= 100) { txt = (uint64_t('0' + v / 100) << 16) | (uint64_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10); n = 3; }
+        else if (v >= 10) { txt = (uint64_t('0' + v / 10) << 8) | ('0' + v % 10); n = 2; }
+        else { txt = '0' + v; n = 1; }
+        txt = (txt << 16) | (uint64_t(',') << 8) | ' ';
+        byte_text[v] = (txt << 8) | (n + 2);
+    }
+}
+// The first 60 bits of the id of one haplotype per lane (wave-level: every lane of the wave calls it, `active` lanes get an id). The
+// sequence comes in registers (sq: SEQ_CAP / 4 dwords), the transcript id as its first 20+ characters in six aligned dwords (idw; longer
+// ids: the rest byte by byte from the pool). The padded message (<= 3 blocks for every 27..31-nt window) is first laid out in the lane's LDS buffer
+// `blk` (K3B_BUF_WORDS + 1 dwords) - decimal text from the 256-entry table, id and offset fed four / five characters at a time - and then
+// compressed in a wave-uniform loop with a fully unrolled, register-resident schedule. Streaming the compression executes the
+// ~800-instruction round function once per distinct block boundary in the wave, because lanes with different numbers of three-digit
+// bytes reach their boundaries at different feeds (kept for messages that do not fit the buffer).
 template <int SEQ_CAP>
+__device__ __forceinline__ uint64_t haplotype_id60(const DeviceBatch& d, bool active, const uint32_t* sq, uint32_t seq_len, uint32_t id_off, uint32_t id_len,
+                                                   const uint32_t* idw, uint32_t id_mis, uint32_t win_sso, uint32_t* blk, const uint64_t* byte_text) {
+    auto feed_message = [&](auto& sh) {
+        sh.feed('[', 1);
+#pragma unroll
+        for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP); k0 += 4) {
+            if (k0 >= seq_len) break;
+            const uint32_t dw = sq[k0 >> 2];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t k = k0 + b;
+                if (k < seq_len) {
+                    // "{:?}" of a Vec<u8>: decimal value, then ", " unless it is the last element - one feed of <= 5 bytes
+                    const uint64_t e = byte_text[(dw >> (8 * b)) & 0xFF];   // text << 8 | length, incl. the separator
+                    uint64_t txt = e >> 8;
+                    uint32_t n = uint32_t(e & 0xFF);
+                    if (k + 1 >= seq_len) { txt >>= 16; n -= 2; }
+                    sh.feed(txt, n);
+                }
+            }
+        }
+        sh.feed(']', 1);
+#pragma unroll
+        for (uint32_t k = 0; k < 20; k += 4) {   // transcript id, four characters per feed: from the prefetched dwords
+            if (k < id_len) {
+                const uint32_t n = min(4u, id_len - k);
+                const uint32_t le = __builtin_amdgcn_alignbyte(idw[k / 4 + 1], idw[k / 4], id_mis);   // characters k .. k + 3, first one in the low byte
+                const uint32_t be = __builtin_bswap32(le) >> (8 * (4 - n));                           // big-endian, the first n of them
+                sh.feed(be, n);
+            }
+        }
+        for (uint32_t k = 20; k < id_len; k += 4) {
+            uint64_t txt = 0;
+            const uint32_t n = min(4u, id_len - k);
+            for (uint32_t c = 0; c < n; c++) txt = (txt << 8) | d.str_pool[id_off + k + c];
+            sh.feed(txt, n);
+        }
+        sh.feed_dec(win_sso);
+        sh.finish();
+    };
+    uint32_t o0 = 0, o1 = 0;
+    // <= 192 bytes incl. padding (every 27..31-nt window with a transcript id of up to ~30 characters): buffered form
+    const bool fits = 5 * seq_len + id_len + 20 <= K3B_BUF_WORDS * 4;
+    if (__ballot(active && !fits) == 0) {
+        ShaStreamT<true> sh;
+        sh.init(blk);
+        if (active) feed_message(sh);
+        const uint32_t nblk = active ? sh.widx >> 4 : 0u;
+        // wave-uniform trip count from ballots (nblk <= K3B_BUF_WORDS / 16 = 3)
+        const uint32_t maxblk = __ballot(nblk >= 3) ? 3u : __ballot(nblk >= 2) ? 2u : __ballot(nblk >= 1) ? 1u : 0u;
+        for (uint32_t bk = 0; bk < maxblk; bk++)
+            if (bk < nblk) sh.compress(bk * 16);
+        o0 = sh.h0; o1 = sh.h1;
+    } else if (active) {
+        ShaStreamT<false> sh;
+        sh.init(blk);
+        feed_message(sh);
+        o0 = sh.h0; o1 = sh.h1;
+    }
+    return (uint64_t(o0) << 28) | (uint64_t(o1) >> 4);
+}
+
+// LIST_A: the groups of list A (k3_enqueue) - sequences, flags, the record AND its id in one go: the sequence is still in the lane's LDS
+// slot when the id is hashed, so the record is written once, complete, and never read again on the device (a separate id kernel re-read
+// 0.5 GB of records per config C pass and ran at 9 % of the HBM roofline; here its ALU work overlaps the other waves' gathers).
+// !LIST_A: list B - flags only, no record, no id.
+template <int SEQ_CAP, bool LIST_A>
 __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
-    constexpr int K3_SLOT_DW = K3Cfg<SEQ_CAP>::SLOT_DW;
+    // the lane's LDS slot: ref | seq | germ while the sequences are built; list A re-uses it as the SHA-1 message buffer afterwards (the
+    // sequences are in registers by then), so it is at least K3B_BUF_WORDS + 1 dwords there (odd stride: bank-conflict free)
+    constexpr int K3_SLOT_DW = LIST_A ? ((K3Cfg<SEQ_CAP>::SLOT_DW > int(K3B_BUF_WORDS + 1) ? K3Cfg<SEQ_CAP>::SLOT_DW : int(K3B_BUF_WORDS + 1)) | 1) : K3Cfg<SEQ_CAP>::SLOT_DW;
     __shared__ uint32_t lds_slots[K3_THREADS * K3_SLOT_DW];
+    __shared__ uint64_t byte_text[LIST_A ? 256 : 1];
+    if constexpr (LIST_A) { fill_byte_text(byte_text, K3_THREADS); __syncthreads(); }
     const uint32_t tid = threadIdx.x;
     // blockIdx.y = the output allocator whose list this workgroup walks; the list's length is only known on the device - one scalar
     // load of its cursor (no prefix table, no search) - and the grid's x extent covers the host's upper bound of it
     const uint32_t lpart = blockIdx.y;
     if (pass_overflowed(d)) return;
-    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + 8], 1ull << d.group_part_log2);
+    const uint64_t part_size = 1ull << d.group_part_log2;
+    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST_A ? 8 : 12)], (unsigned long long)part_size);
     for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
-    const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue)
-    const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + li;
-    // the item K2 listed: group slot, window, reserved record slot (one 16-byte load, at a clamped index for the lanes past the end)
-    const uint4 item = d.k3_items[li < n_slots ? lpos : (uint64_t(lpart) << d.group_part_log2)];
+    const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue: A upwards, B downwards)
+    const uint64_t lidx = li < n_slots ? li : 0;   // (a clamped index for the lanes past the end)
+    const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST_A ? lidx : part_size - 1 - lidx);
+    // the item K2 listed: group slot, window, reserved record slot (one 16-byte load)
+    const uint4 item = d.k3_items[lpos];
     const uint64_t g = li < n_slots ? item.x : 0;
     uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
     uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
@@ -2129,10 +2237,16 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     uint64_t prof_set = 0;
     bool want_id = false;
     uint32_t seq_len = 0, germ_len = 0, prof_len = 0, nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
-    uint32_t rec_sso = 0, rec_tx = 0;
+    uint32_t rec_sso = 0;
+    uint32_t id_off = 0, id_len = 0, id_mis = 0;
+    uint32_t idw[6] = {0, 0, 0, 0, 0, 0};
     if (live) {
         const WinStatic ws = d.wins[w];
-        rec_sso = ws.sso; rec_tx = ws.tx;
+        rec_sso = ws.sso;
+        if constexpr (LIST_A) {   // the transcript's id: issued first (loads complete in order), its characters are fetched below, beside the sequence work
+            const TxDev* T = d.tx + ws.tx;
+            id_off = T->id_off; id_len = T->id_len;
+        }
         const uint32_t vbase = ws.vbase;
         const uint64_t hap = hap_pre;
         const bool is_rev = (ws.flags & WSF_REVERSE) != 0;
@@ -2154,6 +2268,12 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
             for (int k = 0; k < 8; k++) { const WinCol* wc = d.win_cols + ws.col_off + min(uint32_t(k), last_c); cp[k] = wc->pos; ci[k] = wc->info; }
 #pragma unroll
             for (int k = 0; k < K3_REFCAP / 4; k++) slot[k] = refw[k];
+        }
+        if constexpr (LIST_A) {   // the id's first 20+ characters as six aligned dwords, fetched together (the pool is padded); used after the walk
+            const uint8_t* idp = d.str_pool + id_off;
+            id_mis = uint32_t(reinterpret_cast<uintptr_t>(idp) & 3u);
+#pragma unroll
+            for (int k = 0; k < 6; k++) idw[k] = reinterpret_cast<const uint32_t*>(idp - id_mis)[k];
         }
         const uint32_t staged = min(uint32_t(ws.wlen), uint32_t(K3_REFCAP) - mis);
         auto ref_at = [&](uint32_t pos) -> uint8_t {  // reference base at absolute position pos (>= sso)
@@ -2321,29 +2441,37 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
     }
     // the record slot (if any) was assigned by K2; a slot K3 turns out not to need is marked "no id"
     uint32_t recidx = 0;
-    if (live) {
-        const uint32_t slot_idx = rec_pre;
-        if (slot_idx != 0xFFFFFFFFu) {
-            uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(slot_idx) * d.rec_stride);
-            if (need_rec) {
-                // 16-byte stores (records are 16-byte aligned: rec_stride and the header are multiples of 16): a quarter of the store instructions
-                uint4* const out4 = reinterpret_cast<uint4*>(out);
-                out4[0] = make_uint4(uint32_t(prof_set), uint32_t(prof_set >> 32), rec_sso, rec_tx);   // [2], [3]: what K3b hashes besides the sequence
-                                                                                                      // (it overwrites them with the id)
-                out4[1] = make_uint4(seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24), nsom | (first_fs << 8) | (first_fs_j << 16), w, want_id ? 1u : 0u);
-                const uint32_t* sq = slot + K3_REFCAP / 4;
+    if constexpr (LIST_A) {
+        // sequences -> registers (the slot becomes the message buffer), id, then the whole record in one run of 16-byte stores
+        // (records are 16-byte aligned: rec_stride and the header are multiples of 16)
+        uint32_t sqr[2 * SEQ_CAP / 4];
 #pragma unroll
-                for (int k = 0; k < 2 * SEQ_CAP / 16; k++) out4[2 + k] = make_uint4(sq[4 * k], sq[4 * k + 1], sq[4 * k + 2], sq[4 * k + 3]);
+        for (int k = 0; k < 2 * SEQ_CAP / 4; k++) sqr[k] = slot[K3_REFCAP / 4 + k];
+        const bool has_slot = live && rec_pre != 0xFFFFFFFFu;
+        const bool hash = has_slot && need_rec && want_id;
+        const uint64_t id60 = haplotype_id60<SEQ_CAP>(d, hash, sqr, seq_len, id_off, id_len, idw, id_mis, rec_sso, slot, byte_text);
+        if (has_slot) {
+            uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(rec_pre) * d.rec_stride);
+            if (need_rec) {
+                uint4* const out4 = reinterpret_cast<uint4*>(out);
+                out4[0] = make_uint4(uint32_t(prof_set), uint32_t(prof_set >> 32), uint32_t(id60), uint32_t(id60 >> 32));
+                out4[1] = make_uint4(seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24), nsom | (first_fs << 8) | (first_fs_j << 16), w, want_id ? 1u : 0u);
+#pragma unroll
+                for (int k = 0; k < 2 * SEQ_CAP / 16; k++) out4[2 + k] = make_uint4(sqr[4 * k], sqr[4 * k + 1], sqr[4 * k + 2], sqr[4 * k + 3]);
                 sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
-                recidx = slot_idx;
+                recidx = rec_pre;
             } else {
                 out[7] = 0;
             }
-        } else if (need_rec) {
-            atomicOr(d.err, WD_REC_OVERFLOW);  // K2's superset rule missed a haplotype (must not happen) or the record buffer is full
+        } else if (live && need_rec) {
+            atomicOr(d.err, WD_REC_OVERFLOW);  // the record buffer is full (K2 flagged it too)
         }
+        // the number of ids of the pass (statistics only: one wave-aggregated add without a return value)
+        const uint64_t hm = __ballot(hash);
+        if (hm && (tid & 63u) == uint32_t(__builtin_ctzll(hm))) atomicAdd(d.cursors + ((blockIdx.x + blockIdx.y) & (NPART - 1)) * 32 + 24, (unsigned long long)__popcll(hm));
+    } else {
+        if (live && need_rec) atomicOr(d.err, WD_REC_OVERFLOW);  // K2's superset rule missed a haplotype (must not happen)
     }
-    append_wanted(d, live && (sumflags & GS_ID_VALID), recidx);
     if (live) {
         GroupSum gs;
         gs.flags = sumflags;
@@ -2495,33 +2623,24 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq_normal(DeviceBatch d
     }
 }
 
-// K3b: SHA-1 ids of the haplotype records (dense: one thread per record, so only lanes that need an id exist).
-// id = sha1(format!("{:?}{}{}", seq, transcript.id, offset))[..15]   (reference: src/microphasing.rs:667-675)
-constexpr uint32_t K3B_BUF_WORDS = 48;   // three SHA-1 blocks per thread (a 27..31-nt window + an id of <= 17 characters always fits)
+// K3b: SHA-1 ids of the haplotype records of `microphaser normal` (dense: one thread per record of K3n's wanted lists; the somatic path
+// hashes its ids inside k3_window_seq<CAP, true>).
 constexpr uint32_t K3B_THREADS = 192;    // three waves share the byte_text table: 39.7 KB of LDS per workgroup -> 4 workgroups = 12 waves per CU
 template <int SEQ_CAP>
 __global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) {
     __shared__ uint32_t lds_blk[K3B_THREADS * (K3B_BUF_WORDS + 1)];   // odd stride: bank-conflict free
-    __shared__ uint64_t byte_text[256];   // decimal text of a byte value followed by ", ", packed big-endian: text << 8 | length
-    for (uint32_t v = threadIdx.x; v < 256; v += K3B_THREADS) {
-        uint64_t txt;
-        uint32_t n;
-        if (v >= 100) { txt = (uint64_t('0' + v / 100) << 16) | (uint64_t('0' + (v / 10) % 10) << 8) | ('0' + v % 10); n = 3; }
-        else if (v >= 10) { txt = (uint64_t('0' + v / 10) << 8) | ('0' + v % 10); n = 2; }
-        else { txt = '0' + v; n = 1; }
-        txt = (txt << 16) | (uint64_t(',') << 8) | ' ';
-        byte_text[v] = (txt << 8) | (n + 2);
-    }
+    __shared__ uint64_t byte_text[256];
+    fill_byte_text(byte_text, K3B_THREADS);
     __syncthreads();
     const uint32_t wp = blockIdx.y;      // the list of wanted records this workgroup walks; its length: one scalar load (known on the device only)
     if (pass_overflowed(d)) return;
     const uint64_t n_recs = min((unsigned long long)d.cursors[wp * 32 + 24], 1ull << d.rec_part_log2);
     for (uint64_t tile = blockIdx.x; tile * K3B_THREADS < n_recs; tile += gridDim.x) {
     const uint64_t li = tile * K3B_THREADS + threadIdx.x;   // index into this list
-    if (li >= n_recs) continue;
-    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + li];
+    const bool active = li < n_recs;
+    const uint64_t r = d.want_recs[(uint64_t(wp) << d.rec_part_log2) + (active ? li : 0)];
     uint32_t* rec = reinterpret_cast<uint32_t*>(d.recs + r * d.rec_stride);
-    // everything the id needs sits in the record K3 wrote (header: sequence length, window offset, transcript; then the sequence):
+    // everything the id needs sits in the record K3n wrote (header: sequence length, window offset, transcript; then the sequence):
     // one contiguous read instead of record -> window -> transcript hops, issued at once
     const uint4* rec4 = reinterpret_cast<const uint4*>(rec);
     const uint4 h0 = rec4[0], h1 = rec4[1];
@@ -2529,73 +2648,19 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) 
 #pragma unroll
     for (int k = 0; k < SEQ_CAP / 16; k++) { const uint4 v = rec4[2 + k]; sq[4 * k] = v.x; sq[4 * k + 1] = v.y; sq[4 * k + 2] = v.z; sq[4 * k + 3] = v.w; }
     const uint32_t seq_len = h1.x & 0xFF, win_sso = h0.z;
-    const TxDev T = d.tx[h0.w];
+    const TxDev T = d.tx[active ? h0.w : 0];
     // the transcript id: its first 20+ characters as six aligned dwords, fetched together (longer ids: the rest byte by byte)
     const uint8_t* idp = d.str_pool + T.id_off;
     const uint32_t id_mis = uint32_t(reinterpret_cast<uintptr_t>(idp) & 3u);
     uint32_t idw[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) idw[k] = reinterpret_cast<const uint32_t*>(idp - id_mis)[k];   // (the pool is padded)
-    auto feed_message = [&](auto& sh) {
-        sh.feed('[', 1);
-#pragma unroll
-        for (uint32_t k0 = 0; k0 < uint32_t(SEQ_CAP); k0 += 4) {
-            if (k0 >= seq_len) break;
-            const uint32_t dw = sq[k0 >> 2];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const uint32_t k = k0 + b;
-                if (k < seq_len) {
-                    // "{:?}" of a Vec<u8>: decimal value, then ", " unless it is the last element - one feed of <= 5 bytes
-                    const uint64_t e = byte_text[(dw >> (8 * b)) & 0xFF];   // text << 8 | length, incl. the separator
-                    uint64_t txt = e >> 8;
-                    uint32_t n = uint32_t(e & 0xFF);
-                    if (k + 1 >= seq_len) { txt >>= 16; n -= 2; }
-                    sh.feed(txt, n);
-                }
-            }
-        }
-        sh.feed(']', 1);
-#pragma unroll
-        for (uint32_t k = 0; k < 20; k += 4) {   // transcript id, four characters per feed: from the prefetched dwords
-            if (k < T.id_len) {
-                const uint32_t n = min(4u, T.id_len - k);
-                const uint32_t le = __builtin_amdgcn_alignbyte(idw[k / 4 + 1], idw[k / 4], id_mis);   // characters k .. k + 3, first one in the low byte
-                const uint32_t be = __builtin_bswap32(le) >> (8 * (4 - n));                           // big-endian, the first n of them
-                sh.feed(be, n);
-            }
-        }
-        for (uint32_t k = 20; k < T.id_len; k += 4) {
-            uint64_t txt = 0;
-            const uint32_t n = min(4u, T.id_len - k);
-            for (uint32_t c = 0; c < n; c++) txt = (txt << 8) | d.str_pool[T.id_off + k + c];
-            sh.feed(txt, n);
-        }
-        sh.feed_dec(win_sso);
-        sh.finish();
-    };
-    uint32_t o0, o1;
-    // <= 256 bytes incl. padding (every 27..31-nt window with a transcript id of up to ~80 characters): buffered form
-    const bool fits = 5 * seq_len + T.id_len + 20 <= K3B_BUF_WORDS * 4;
-    if (__ballot(!fits) == 0) {
-        ShaStreamT<true> sh;
-        sh.init(lds_blk + threadIdx.x * (K3B_BUF_WORDS + 1));
-        feed_message(sh);
-        const uint32_t nblk = sh.widx >> 4;
-        // wave-uniform trip count from ballots (only the active lanes vote; nblk <= K3B_BUF_WORDS / 16 = 3)
-        const uint32_t maxblk = __ballot(nblk >= 3) ? 3u : __ballot(nblk >= 2) ? 2u : 1u;
-        for (uint32_t bk = 0; bk < maxblk; bk++)
-            if (bk < nblk) sh.compress(bk * 16);
-        o0 = sh.h0; o1 = sh.h1;
-    } else {
-        ShaStreamT<false> sh;
-        sh.init(lds_blk + threadIdx.x * (K3B_BUF_WORDS + 1));
-        feed_message(sh);
-        o0 = sh.h0; o1 = sh.h1;
+    const uint64_t id60 = haplotype_id60<SEQ_CAP>(d, active, sq, seq_len, T.id_off, T.id_len, idw, id_mis, win_sso,
+                                                  lds_blk + threadIdx.x * (K3B_BUF_WORDS + 1), byte_text);
+    if (active) {
+        rec[2] = uint32_t(id60);
+        rec[3] = uint32_t(id60 >> 32);
     }
-    uint64_t id60 = (uint64_t(o0) << 28) | (uint64_t(o1) >> 4);
-    rec[2] = uint32_t(id60);
-    rec[3] = uint32_t(id60 >> 32);
     }   // tiles of this wave
 }
 
@@ -2708,32 +2773,40 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipS
     }
 }
 
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_group_slots, hipStream_t stream) {
-    if (max_group_slots == 0) return;
-    // the grid covers the host's upper bound of the used slots (surplus waves find nothing and leave; were the bound too low, the
+template <bool LIST_A>
+static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t stream) {
+    if (max_items == 0) return;
+    // the grid covers the host's upper bound of the list lengths (surplus waves find nothing and leave; were the bound too low, the
     // waves walk the rest in turn - slower, still complete)
     // one grid row per allocator list; the lists fill evenly (allocator = workgroup index & 63 in the K2 kernels), a quarter more for the spread
-    const uint64_t per_list = max_group_slots / NPART + max_group_slots / (4 * NPART) + K3_THREADS;
+    const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + K3_THREADS;
     dim3 grid(uint32_t(std::min<uint64_t>((per_list + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull)), NPART), block(K3_THREADS);
-    if (d.normal) {
+    switch (d.seq_cap) {
+        case 32: hipLaunchKernelGGL((k3_window_seq<32, LIST_A>), grid, block, 0, stream, d); break;
+        case 48: hipLaunchKernelGGL((k3_window_seq<48, LIST_A>), grid, block, 0, stream, d); break;
+        case 112: hipLaunchKernelGGL((k3_window_seq<112, LIST_A>), grid, block, 0, stream, d); break;
+        case 240: hipLaunchKernelGGL((k3_window_seq<240, LIST_A>), grid, block, 0, stream, d); break;
+        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+    HIP_CHECK_LAUNCH();
+}
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, hipStream_t stream_a, hipStream_t stream_b) {
+    if (d.normal) {   // `microphaser normal`: every group has a record (all of them are in list A); ids by k3b_haplotype_ids afterwards
+        if (max_list_a == 0) return;
+        const uint64_t per_list = max_list_a / NPART + max_list_a / (4 * NPART) + K3_THREADS;
+        dim3 grid(uint32_t(std::min<uint64_t>((per_list + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull)), NPART), block(K3_THREADS);
         switch (d.seq_cap) {
-            case 32: hipLaunchKernelGGL(k3_window_seq_normal<32>, grid, block, 0, stream, d); break;
-        case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream, d); break;
-            case 112: hipLaunchKernelGGL(k3_window_seq_normal<112>, grid, block, 0, stream, d); break;
-            case 240: hipLaunchKernelGGL(k3_window_seq_normal<240>, grid, block, 0, stream, d); break;
+            case 32: hipLaunchKernelGGL(k3_window_seq_normal<32>, grid, block, 0, stream_a, d); break;
+            case 48: hipLaunchKernelGGL(k3_window_seq_normal<48>, grid, block, 0, stream_a, d); break;
+            case 112: hipLaunchKernelGGL(k3_window_seq_normal<112>, grid, block, 0, stream_a, d); break;
+            case 240: hipLaunchKernelGGL(k3_window_seq_normal<240>, grid, block, 0, stream_a, d); break;
             default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
         }
         HIP_CHECK_LAUNCH();
         return;
     }
-    switch (d.seq_cap) {
-        case 32: hipLaunchKernelGGL(k3_window_seq<32>, grid, block, 0, stream, d); break;
-        case 48: hipLaunchKernelGGL(k3_window_seq<48>, grid, block, 0, stream, d); break;
-        case 112: hipLaunchKernelGGL(k3_window_seq<112>, grid, block, 0, stream, d); break;
-        case 240: hipLaunchKernelGGL(k3_window_seq<240>, grid, block, 0, stream, d); break;
-        default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
-    }
-    HIP_CHECK_LAUNCH();
+    launch_k3_list<true>(d, max_list_a, stream_a);    // sequences + records + ids
+    launch_k3_list<false>(d, max_list_b, stream_b);   // flags only; independent of list A's groups, may run beside it
 }
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {

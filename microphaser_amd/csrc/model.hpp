@@ -6,6 +6,8 @@
 // and rust-bio. Reads are kept in pooled struct-of-arrays form (ReadStore) so the
 // very same pools can be uploaded to HBM unchanged.
 #pragma once
+#include <functional>
+#include <memory>
 #include <memory>
 #include <cstdint>
 #include <cstring>
@@ -97,10 +99,17 @@ template <class T> using PodVec = std::vector<T, DefaultInitAlloc<T>>;
 void advise_huge(const void* p, size_t bytes);
 
 // Giving gigabytes of scratch back to the OS (the planner's sub-batches, the consumer's pieces, the downloaded results) is page-table
-// work under the process-wide mm lock: it is taken off the caller's path - the object is moved to a thread that destroys it.
+// work under the process-wide mm lock: it is taken off the caller's path - the object is moved to the library's reaper thread, which
+// destroys it. The reaper is OWNED: it starts with the first job, mp_destroy of the last live context waits for the queue to drain and
+// joins it (reaper_release), and so does the library's static teardown - no detached thread outlives the library or races an unload.
+void reaper_post(std::function<void()> job);
+void reaper_retain();    // a context came to life
+void reaper_release();   // a context died; the last one drains the queue and joins the thread
+void reaper_drain();     // blocks until every posted job has run (tests, orderly teardown)
+bool reaper_running();   // a reaper thread exists (tests)
 template <class T> void release_later(T&& obj) {
-    auto* held = new std::decay_t<T>(std::move(obj));
-    std::thread([held] { delete held; }).detach();
+    auto held = std::make_shared<std::decay_t<T>>(std::move(obj));   // (std::function needs a copyable callable)
+    reaper_post([held]() mutable { held.reset(); });
 }
 
 struct ReadStore {

@@ -7,7 +7,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+ORACLE_CLI = os.environ.get("MP_ORACLE_CLI") or os.path.join(ROOT, "oracle", "_build", "oracle_cli")   # (tools/run_sanitized.sh: the sanitizer build)
 
 # (test dir, bam, vcf, gtf, mini fasta, expected stem) - the reference's live somatic tests (tests/lib.rs:211-342)
 SOMATIC_FIXTURES = {
