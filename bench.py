@@ -6,7 +6,7 @@
 
 Metric (BASELINE.json): peptide-windows/s, `somatic`, 9-mer (27 nt), on the synthetic 20k-transcript
 whole exome (30x, ~5 variant sites per window). A "step" is one pass of the
-hot path (K1 pileup bits -> K2 window replay -> K3 window sequences -> K3b ids) over the batch, with
+hot path (K1 pileup bits -> K2 window replay -> K3 window sequences + ids) over the batch, with
 the packed inputs already resident in HBM and the results left in HBM.
 
 Multi-GPU (BASELINE.json configs[2]: ONE 20k-transcript exome sharded across the GPUs): genes are
@@ -174,9 +174,11 @@ def main():
     # the unit count: main-ORF print_haplotypes calls the reference makes = what the consumer actually walks
     t0 = time.perf_counter()
     windows = None
+    emitted = None
     if not args.no_consume:
         res = batch.results()
         windows = res.windows
+        emitted = max(0, res.tsv.count(b"\n") - 1)   # TSV rows = emitted haplotypes
     t_consume = time.perf_counter() - t0
     if windows is None:
         windows = st.n_windows_planned
@@ -203,12 +205,17 @@ def main():
         # Roofline units: kernels that run one after the other on the launch stream, except the window phase - k2l (two launches) and k2w are
         # launched side by side on separate streams, so their HIP-event intervals overlap (each spans most of the phase); the phase is
         # priced as ONE unit: the three launches' bytes over the phase's wall time (first start to last end, HIP events)
+        k3_name = "k3_window_seq (sequences + records + SHA-1 ids: list A | flags: list B, concurrent)"
+        kern[k3_name] = kern.pop("k3_window_seq")
         units = {"k1_pileup_bits": kern["k1_pileup_bits"] + (["k1_pileup_bits"],),
                  "k2a_admission": kern["k2a_admission"] + (["k2a_admission"],),
                  "k2_window_phase (k2l_window_lanes<6> | k2l_window_lanes<8> | k2w_window_rows, concurrent)":
                      (k2win / steps, st.bytes_k2l + st.bytes_k2w, ["k2l_window_lanes", "k2w_window_rows"]),
-                 "k3_window_seq": kern["k3_window_seq"] + (["k3_window_seq"],),
-                 "k3b_haplotype_ids": kern["k3b_haplotype_ids"] + (["k3b_haplotype_ids"],)}
+                 k3_name: kern[k3_name] + (["k3_window_seq"],)}
+        if kern["k3b_haplotype_ids"][0] > 0:   # (`normal` mode only: somatic ids are hashed inside K3)
+            units["k3b_haplotype_ids"] = kern["k3b_haplotype_ids"] + (["k3b_haplotype_ids"],)
+        else:
+            del kern["k3b_haplotype_ids"]
         if k2win <= 0:   # no window-parallel work in this batch: the sequential replay is the K2 unit
             del units["k2_window_phase (k2l_window_lanes<6> | k2l_window_lanes<8> | k2w_window_rows, concurrent)"]
             units["k2_window_replay"] = kern["k2_window_replay"] + (["k2_window_replay"],)
@@ -219,6 +226,7 @@ def main():
         # command, so they come from the committed summary of those passes (tools/pmc_summary.py), only when it is for this workload
         traffic, traffic_src, traffic_note = None, None, None
         valu = {}
+        pass_pmc = None
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_config%s.json" % args.config)), reverse=True):
             try:
@@ -227,25 +235,34 @@ def main():
                 continue
             if args.transcripts or world != 1:
                 break
+            traffic_src = os.path.relpath(path, ROOT)
+            pass_pmc = {"fetch_raw": sum(e.get("fetch_bytes_raw", 0.0) for e in pt.values()), "write": sum(e.get("write_bytes", 0.0) for e in pt.values())}
             hit = [k for k in pt if any(k.split("<")[0].startswith(x) for x in dom_kernels) and "fetch_bytes_raw" in pt[k]]   # (k2w_window_rows[_multi|_deep])
             if hit:
                 traffic = sum(pt[k]["fetch_bytes_raw"] + pt[k].get("write_bytes", 0.0) for k in hit)
-                traffic_src = os.path.relpath(path, ROOT)
                 traffic_note = ("FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per launch, summed over %s; with the gfx950 correction for wide streaming reads "
                                 "(FETCH_SIZE counts them at half, MI355X_MICROARCH.md HBM section) the read side is at most %.3g bytes"
                                 % (", ".join(hit), sum(pt[k].get("fetch_bytes_x2", 0.0) for k in hit)))
-                for k, e in pt.items():
-                    if "SQ_INSTS_VALU" in e:
-                        valu[k.split("<")[0]] = valu.get(k.split("<")[0], 0.0) + e["SQ_INSTS_VALU"]
-                break
+            for k, e in pt.items():
+                if "SQ_INSTS_VALU" in e:
+                    valu[k.split("<")[0]] = valu.get(k.split("<")[0], 0.0) + e["SQ_INSTS_VALU"]
+            break
         t_pass = elapsed_max / steps
+        # Second byte accounting: SURVEY.md 8(d)'s COMPULSORY traffic of the whole pass, every byte counted once, with this run's counts -
+        # per read 172 B in (16 B core + 51 B packed bases + 101 B qualities + 4 B cigar) and 2 x 32 B K1 -> K2 hand-over (+ 16 B per extra
+        # mask word), 16 B per variant, 1 B per CDS nt (= nt-offset steps), 16 B per window, 16 B per distinct haplotype, 54 B per emitted
+        # haplotype. The per-kernel figures above count each kernel's own inputs + outputs (planner-made structures and inter-kernel
+        # hand-overs included, hand-overs twice); this one prices only what the problem itself has to move.
+        n_emit = emitted if emitted is not None else int(st.n_ids)
+        compulsory = (172 * st.n_reads + (64 + 32 * (st.mask_words - 1)) * st.n_reads + 16 * st.n_variants + st.n_steps
+                      + 16 * st.n_windows_device + 16 * st.n_groups + 54 * n_emit)
         out = {
             "metric": "peptide-windows/s (somatic, 9-mer)", "value": value, "unit": "peptide-windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "ONE synthetic %d-transcript exome, %gx, SNV every %g nt, 101-nt reads (SURVEY 8d config %s, seed %d, per-gene random streams)%s; "
                                    "step = K1 + K2 (k2a admission, k2l one lane per window, k2w one wave per window for the wide ones; sequential k2 replay for the "
-                                   "segments that need it) + K3 + K3b over the HBM-resident batch"
+                                   "segments that need it) + K3 (window sequences, records and their SHA-1 ids) over the HBM-resident batch"
                                    % (n_tx, depth, spacing, args.config, seed,
                                       "" if world == 1 else ", its genes dealt to the %d GPUs by estimated cost (LPT on CDS nt x depth)" % world),
                        "windows_total": int(total_windows), "windows_rank0": int(windows), "reads_rank0": int(st.n_reads), "variants_rank0": int(st.n_variants),
@@ -253,6 +270,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms, "rocprof_kernels": dom_kernels,
+                         "compulsory_bytes": int(compulsory), "compulsory_frac": compulsory / t_pass / 1e9 / HBM_PEAK_GBS,
+                         "compulsory_note": "whole pass, SURVEY 8(d) formula with this run's counts (%d reads, %d variants, %d steps, %d windows, %d haplotype groups, "
+                                            "%d emitted) over ms_per_step, against the 8 TB/s peak" % (st.n_reads, st.n_variants, st.n_steps, st.n_windows_device, st.n_groups, n_emit),
+                         "pmc_over_compulsory": None if not pass_pmc else {
+                             "raw": (pass_pmc["fetch_raw"] + pass_pmc["write"]) / compulsory, "with_fetch_x2": (2 * pass_pmc["fetch_raw"] + pass_pmc["write"]) / compulsory,
+                             "write_bytes_per_pass": pass_pmc["write"], "fetch_bytes_raw_per_pass": pass_pmc["fetch_raw"], "source": traffic_src,
+                             "note": "FETCH_SIZE + WRITE_SIZE of every kernel of one pass (committed PMC summary) over the compulsory bytes; FETCH_SIZE raw and "
+                                     "with the gfx950 x2 correction for wide streaming reads (MI355X_MICROARCH.md, HBM)"},
                          "limiter": "instruction issue / latency, not HBM (integer and bitset work: see DESIGN.md section 4 and profiles/)"},
             "roofline_units": {k: {"ms": v[0], "algorithmic_bytes": int(v[1]), "hbm_frac": (v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else 0.0)}
                                for k, v in units.items()},
@@ -271,7 +296,8 @@ def main():
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),
             "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm),
                        "windows_lane_kernel": int(st.n_windows_lane), "windows_wave_kernel": int(st.n_windows_wave),
-                       "groups": int(st.n_groups), "groups_k3": int(st.n_groups_k3)},
+                       "groups": int(st.n_groups), "groups_k3": int(st.n_groups_k3), "groups_k3_list_a": int(st.n_groups_k3a), "ids_hashed": int(st.n_ids),
+                       "emitted_haplotypes": emitted},
             "hbm_resident_bytes": int(st.hbm_bytes),
             "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "pass_s": t_pass, "d2h_consume_s": None if args.no_consume else t_consume,
                            "windows_per_s": None if args.no_consume else windows / (t_plan + t_pass + t_consume),

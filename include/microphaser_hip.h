@@ -128,7 +128,7 @@ void mp_dataset_free(mp_dataset* ds);
 
 /* Statistics of one pass of the hot path (filled by mp_batch_run). */
 typedef struct mp_run_stats {
-    double k1_ms, k2_ms, k3_ms, k3b_ms, total_ms;  /* HIP-event times on the launch stream */
+    double k1_ms, k2_ms, k3_ms, k3b_ms, total_ms;  /* HIP-event times on the launch stream (k3b_ms: `normal` mode only - somatic ids are hashed inside K3) */
     uint64_t n_windows_planned;            /* main-ORF windows in the speculative schedule */
     uint64_t n_steps, n_transcripts, n_reads, n_variants;
     uint64_t n_groups, n_records;
@@ -150,6 +150,9 @@ typedef struct mp_run_stats {
      * columns and the wave-per-window kernels together): k2seq_ms, k2l_ms and k2w_ms are overlapping intervals; k2win_ms is the wall
      * time from the end of k2a until all of them have finished. */
     double k2win_ms;
+    uint64_t n_windows_device;             /* printing windows the device computed (main ORF and shifted frames, speculative past a stop) */
+    uint64_t n_groups_k3a;                 /* of n_groups_k3: groups with a record slot (k3_window_seq list A: sequences, records, ids) */
+    uint64_t n_ids;                        /* haplotype ids hashed (somatic: inside k3_window_seq; normal: k3b_haplotype_ids) */
 } mp_run_stats;
 
 /* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM

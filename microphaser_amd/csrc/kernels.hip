@@ -2456,8 +2456,16 @@ __global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
                 uint4* const out4 = reinterpret_cast<uint4*>(out);
                 out4[0] = make_uint4(uint32_t(prof_set), uint32_t(prof_set >> 32), uint32_t(id60), uint32_t(id60 >> 32));
                 out4[1] = make_uint4(seq_len | (germ_len << 8) | (prof_len << 16) | (nvar << 24), nsom | (first_fs << 8) | (first_fs_j << 16), w, want_id ? 1u : 0u);
+                // only the 16-byte pieces that hold sequence bytes are stored (the host reads seq_len / germ_len bytes): a 27..32-nt window
+                // in a batch whose capacity is 48 writes 96 of its record's 128 bytes
 #pragma unroll
-                for (int k = 0; k < 2 * SEQ_CAP / 16; k++) out4[2 + k] = make_uint4(sqr[4 * k], sqr[4 * k + 1], sqr[4 * k + 2], sqr[4 * k + 3]);
+                for (int k = 0; k < SEQ_CAP / 16; k++) {
+                    if (uint32_t(16 * k) < seq_len) out4[2 + k] = make_uint4(sqr[4 * k], sqr[4 * k + 1], sqr[4 * k + 2], sqr[4 * k + 3]);
+                    if (uint32_t(16 * k) < germ_len) {
+                        constexpr int G = SEQ_CAP / 16;
+                        out4[2 + G + k] = make_uint4(sqr[4 * (G + k)], sqr[4 * (G + k) + 1], sqr[4 * (G + k) + 2], sqr[4 * (G + k) + 3]);
+                    }
+                }
                 sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
                 recidx = rec_pre;
             } else {
