@@ -22,7 +22,6 @@
 
 #include "hostsha.hpp"
 #include "rowfmt.hpp"
-#include "util.hpp"
 
 namespace mp {
 

@@ -24,7 +24,6 @@
 #include "kernels_pep.hpp"
 #include "pep.hpp"
 #include "rowfmt.hpp"
-#include "util.hpp"
 
 namespace mp {
 

@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../microphaser_amd/csrc/model.hpp"
-#include "../microphaser_amd/csrc/util.hpp"
+#include "oracle_util.hpp"
 #include "peptides_oracle.hpp"
 
 namespace mp_oracle {

@@ -14,7 +14,7 @@
 #include <limits>
 #include <map>
 
-#include "../microphaser_amd/csrc/util.hpp"
+#include "oracle_util.hpp"
 
 using namespace mp;
 
@@ -40,7 +40,7 @@ inline void switch_ascii_case_vec(const std::string& v, uint8_t r, Bytes& out) {
 bool supports_variant(const ReadStore& rs, size_t read, const Variant& v) {  // :43-78 (no quality gate)
     switch (v.kind) {
         case VK_SNV: {
-            int64_t p = cigar_read_pos(rs.cigar(read), rs.n_cigar[read], rs.pos[read], int64_t(uint32_t(v.pos)));
+            int64_t p = oracle_read_pos(rs.cigar(read), rs.n_cigar[read], rs.pos[read], int64_t(uint32_t(v.pos)));
             if (p < 0) return false;
             if (uint64_t(p) >= rs.l_seq[read]) ref_panic("seq index out of range");
             return rs.base(read, uint32_t(p)) == v.alt;

@@ -1,6 +1,8 @@
-// Small host utilities whose exact output format is part of the parity contract:
-// SHA-1 ids, shortest-round-trip f64 printing (Rust `ryu` pretty format, used by the
-// `csv` crate's serde serializer), FASTA and TSV record writers.
+// TEST INFRASTRUCTURE - the CPU oracle's OWN primitives (the product does not include this file: its host legs use rowfmt.hpp /
+// hostsha.hpp, its kernels their own device code; tests/test_host_formatting.py and tests/test_shared_primitives.py compare the two).
+// Small host utilities whose exact output format is part of the parity contract: SHA-1 ids, shortest-round-trip f64 printing (Rust
+// `ryu` pretty format, used by the `csv` crate's serde serializer), FASTA and TSV record writers, and the oracle's own restatement of
+// rust-htslib's CigarStringView::read_pos.
 #pragma once
 #include <charconv>
 #include <cmath>
@@ -9,9 +11,49 @@
 #include <cstring>
 #include <string>
 
-#include "model.hpp"
+#include "../microphaser_amd/csrc/model.hpp"
 
 namespace mp {
+
+// ------------------------------------------------------------------ CIGAR
+// rust-htslib 0.36 `CigarStringView::read_pos(ref_pos, include_softclips = false, include_dels = false)` (the crate is not vendored in the
+// reference; call sites src/microphasing.rs:106, src/normal_microphasing.rs:48; semantics pinned by the fixtures' depth / freq columns,
+// SURVEY 3.5.3 and Appendix B). The oracle's own statement of it, written as the walk over (op, length) pairs the crate does - kept apart
+// from the product's cigar_read_pos (model.hpp) and its device twin so that a mistake in one does not hide in the other
+// (tests/test_shared_primitives.py runs both over every read of the fixture BAMs). Returns -1 for `None`.
+inline int64_t oracle_read_pos(const uint32_t* cigar, uint32_t n_ops, int64_t read_start, int64_t ref_pos) {
+    enum { M = 0, I = 1, D = 2, N = 3, S = 4, H = 5, P = 6, EQ = 7, X = 8 };
+    // the crate first looks for the first operation that consumes read bases; leading hard clips / pads are stepped over, a leading
+    // deletion / skip is an error (the callers treat an error like None), a hard clip that is neither first nor last as well
+    uint32_t first = n_ops;
+    for (uint32_t k = 0; k < n_ops; k++) {
+        const uint32_t op = cigar[k] & 15u;
+        if (op == M || op == EQ || op == X || op == I || op == S) { first = k; break; }
+        if (op == D || op == N) return -1;
+        if (op == H && k != 0 && k + 1 != n_ops) return -1;
+    }
+    if (first == n_ops) return -1;
+    int64_t ref_cursor = read_start, read_cursor = 0;
+    for (uint32_t k = first; k < n_ops; k++) {
+        if (ref_cursor > ref_pos) return -1;           // walked past the position without an aligned base on it
+        const uint32_t op = cigar[k] & 15u;
+        const int64_t len = int64_t(cigar[k] >> 4);
+        if (op == M || op == EQ || op == X) {
+            if (ref_pos < ref_cursor + len) return read_cursor + (ref_pos - ref_cursor);
+            ref_cursor += len;
+            read_cursor += len;
+        } else if (op == I || op == S) {
+            read_cursor += len;                       // soft clips count as read bases but (include_softclips = false) never match a position
+        } else if (op == D || op == N) {
+            ref_cursor += len;                        // a position inside a deletion has no read base (include_dels = false): the next loop turn returns None
+        } else if (op == H) {
+            return -1;                                // the trailing hard clip: nothing behind it
+        } else if (op != P) {
+            return -1;
+        }
+    }
+    return -1;
+}
 
 // ------------------------------------------------------------------ SHA-1
 // (reference: `sha1 = "0.6"` crate, call sites src/microphasing.rs:667-675, src/common.rs:387-395)

@@ -14,7 +14,7 @@
 #include <map>
 #include <tuple>
 
-#include "../microphaser_amd/csrc/util.hpp"
+#include "oracle_util.hpp"
 
 using namespace mp;
 
@@ -78,7 +78,7 @@ bool supports_variant(const Ctx& cx, size_t read, const Variant& v) {  // :95-13
             if (relative_pos < rs.l_seq[read]) {
                 if (rs.qual(read)[relative_pos] < 10) return false;
             }
-            int64_t p = cigar_read_pos(rs.cigar(read), rs.n_cigar[read], rs.pos[read], int64_t(uint32_t(v.pos)));
+            int64_t p = oracle_read_pos(rs.cigar(read), rs.n_cigar[read], rs.pos[read], int64_t(uint32_t(v.pos)));
             if (p < 0) return false;
             if (uint64_t(p) >= rs.l_seq[read]) ref_panic("seq index out of range");
             return rs.base(read, uint32_t(p)) == v.alt;

@@ -1,12 +1,12 @@
 // Test infrastructure (built and run by tests/test_host_formatting.py): the product's in-place row writers (rowfmt.hpp) and host SHA-1 ids
-// (hostsha.hpp) against the plain versions of util.hpp that the CPU oracle uses.
+// (hostsha.hpp) against the oracle's own plain versions (oracle/oracle_util.hpp).
 #include <chrono>
 #include <cstdio>
 #include <random>
 
 #include "hostsha.hpp"
 #include "rowfmt.hpp"
-#include "util.hpp"
+#include "oracle_util.hpp"
 
 int main() {
     std::mt19937_64 rng(7);
@@ -55,7 +55,7 @@ int main() {
         if (no.tsv != std::string(nt.tsv.data(), nt.tsv.size())) { std::printf("normal rows DIFFERENT\n"); bad++; }
     }
 
-    // ids: SHA extensions (where the CPU has them) and the portable block function against util.hpp
+    // ids: SHA extensions (where the CPU has them) and the portable block function against oracle_util.hpp
     std::printf("cpu has sha: %d\n", int(mp::hostsha::cpu_has_sha()));
     size_t ids = 0;
     for (int it = 0; it < 60000; it++) {
