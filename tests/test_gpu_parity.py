@@ -391,26 +391,66 @@ def test_gpu_config_e_pipeline_matches_oracle(ctx, tmp_path):
     assert (f2.fasta, f2.tsv, f2.removed_tsv) == (f.fasta, f.tsv, f.removed_tsv)
 
 
-def test_gpu_full_size_config_c_matches_the_oracle_verified_checksums(ctx):
-    """BASELINE config C at FULL size (20000 transcripts, 7.8 M windows, 8.8 M TSV rows, 3.5 GB of text): the oracle needs 80 s for it, so
-    the suite compares checksums - the md5 of the three streams recorded in the run in which `oracle_cli somatic` on the same exome
-    produced identical streams (tests/golden/config_c/checksums.json, tools/e2e_cli.py C --md5) - and two size-independent
-    property: a second pass over the resident batch gives the same bytes and window count."""
+@pytest.mark.parametrize("gold_file", ["checksums_gene_streams.json", "checksums.json"])
+def test_gpu_full_size_config_c_matches_the_oracle_verified_checksums(ctx, gold_file):
+    """BASELINE config C at FULL size (20000 transcripts, 7.8 M windows, 8.8 M TSV rows, 3.5 GB of text): the oracle needs minutes for it
+    on one thread, so the suite compares checksums - the md5 of the three streams recorded in a run in which the CPU oracle produced
+    identical streams on the same exome - and two size-independent properties: a second pass over the resident batch gives the same
+    bytes and window count. checksums_gene_streams.json is THE EXOME bench.py TIMES (per-gene random streams; recorded by
+    tools/record_golden.py C, oracle on the host threads of the GPU box, window count 7755097 as in the bench line); checksums.json is
+    the single-stream variant of the generator (tools/e2e_cli.py C --md5: product CLI and oracle_cli somatic on the same files)."""
     import hashlib
-    gold = json.load(open(os.path.join(GOLDEN, "config_c", "checksums.json")))
-    ds = ctx.synth(gold["seed"], gold["transcripts"], gold["depth"], gold["spacing"])
+    gold = json.load(open(os.path.join(GOLDEN, "config_c", gold_file)))
+    ds = ctx.synth(gold["seed"], gold["transcripts"], gold["depth"], gold["spacing"], gene_streams=bool(gold.get("gene_streams")))
     b = ds.batch()
     b.run()
     r = b.results()
     md5 = {k: hashlib.md5(getattr(r, k)).hexdigest() for k in ("fasta", "normal_fasta", "tsv")}
     assert md5 == gold["md5"]
     assert r.tsv.count(b"\n") - 1 == gold["tsv_rows"]
+    if "windows" in gold:
+        assert r.windows == gold["windows"]
     n_windows = r.windows
     r.close()
     b.run()                       # idempotence: the pass again over the same resident inputs
     r2 = b.results(m_stream_tsv())
     assert hashlib.md5(r2.tsv).hexdigest() == gold["md5"]["tsv"] and r2.windows == n_windows and r2.fasta == b""
     r2.close(); b.close()
+
+
+def test_gpu_config_e_at_4000_transcripts_matches_the_oracle_verified_checksums(ctx, tmp_path):
+    """Config E (normal -> build_reference -l 9 -> somatic -> filter) on a 4000-transcript exome of BASELINE's shape (seed 2020, 30x, SNV
+    every 5.4 nt, per-gene random streams): 1.56 M `normal` windows, a 14 M-peptide normal peptidome, 1.76 M somatic TSV rows. The CPU
+    oracle needs 71 s for its four stages on 32 threads, so the suite compares the md5 of EVERY stream with the values recorded in the
+    run of tools/record_golden.py E 4000 in which the oracle's stages produced the same bytes (tests/golden/config_e/checksums_4000.json;
+    the peptidome as the md5 of its sorted peptide list - HashSet order is arbitrary)."""
+    import hashlib
+    import numpy as np
+    import microphaser_amd as m
+    gold = json.load(open(os.path.join(GOLDEN, "config_e", "checksums_4000.json")))
+    L = gold["peptide_len"]
+    md5 = lambda b: hashlib.md5(b).hexdigest()
+    ds = ctx.synth(gold["seed"], gold["transcripts"], gold["depth"], gold["spacing"], gene_streams=True)
+    b = ds.batch(window_len=3 * L, mode=m.MODE_NORMAL)
+    b.run()
+    nres = b.results(m.STREAM_FASTA)
+    normal_fa, normal_windows = nres.fasta, nres.windows
+    nres.close(); b.close()
+    got = {"normal_fasta_of_normal_mode": md5(normal_fa)}
+    pep = ctx.peptidome(normal_fa, L, lazy=False)
+    body = np.frombuffer(pep.binary, dtype=np.uint8)
+    n_pep = int(body[:8].view("<u8")[0])
+    peps = np.sort(np.ascontiguousarray(body[8:].reshape(n_pep, 8 + L)[:, 8:]).view("S%d" % L)[:, 0])
+    got["peptidome_sorted"] = md5(peps.tobytes())
+    sres = ds.phase()
+    got.update({"somatic_fasta": md5(sres.fasta), "somatic_normal_fasta": md5(sres.normal_fasta), "somatic_tsv": md5(sres.tsv)})
+    f = ctx.filter(sres.tsv, pep)    # the peptidome by handle (sorted keys straight to the GPU) ...
+    got.update({"filter_fasta": md5(f.fasta), "filter_normal_fasta": md5(f.normal_fasta), "filter_tsv": md5(f.tsv),
+                "filter_removed_tsv": md5(f.removed_tsv), "filter_removed_fasta": md5(f.removed_fasta)})
+    assert got == gold["md5"]
+    c = gold["counts"]
+    assert (normal_windows, n_pep, sres.windows, f.kept, f.removed, f.groups) == (c["normal_windows"], c["peptidome"], c["somatic_windows"],
+                                                                                  c["filter_kept"], c["filter_removed"], c["filter_groups"])
 
 
 @pytest.mark.parametrize("name,seed,n,depth,spacing,windows", [("B", 1001, 1000, 30.0, 5.4, 388716), ("D", 5005, 500, 500.0, 1.35, 184824)])
