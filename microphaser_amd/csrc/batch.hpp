@@ -1,6 +1,7 @@
 // Host-side packed batch: what mp_phase_genes uploads to HBM. Built by the planner (plan.cpp)
 // from the per-gene inputs phase_gene would load (reference: src/microphasing.rs:895-942).
 #pragma once
+#include <deque>
 #include <string>
 #include <utility>
 #include <vector>
@@ -28,6 +29,11 @@ struct GeneHost {           // host-only per-gene bookkeeping
     uint64_t ref_off = 0;
     uint32_t tx_off = 0, n_tx = 0;        // coding transcripts only
     std::vector<uint32_t> tx_src;         // index into gene.transcripts for each planned transcript
+    // Deep genes (plan.cpp split_deep_genes): the planned genes [this, this + n_extra] are copies of ONE gene that hold disjoint subsets
+    // of its reads and walk the same schedule; rows are independent of each other (src/microphasing.rs:297-343: push_read looks at the
+    // read and the columns only), so the windows' haplotype counts and depths are the sums over the copies - the consumer adds them up.
+    uint32_t n_extra = 0;                 // copies that follow this gene in Batch::genes
+    bool is_extra = false;                // this entry is such a copy: no output of its own
 };
 
 struct Batch {
@@ -81,6 +87,8 @@ struct Batch {
     // transcripts whose speculative schedule ran into a failure: (index into tx, message); the plan stops before that step and the
     // consumer raises the message only if the real walk reaches it
     std::vector<std::pair<uint32_t, std::string>> tx_errors;
+    PodVec<uint32_t> tx_max_live;         // host-only, per transcript: upper bound on its simultaneously live rows (+ pending candidates)
+    std::deque<GeneInput> split_inputs;   // the read-subset copies of deep genes (owned here: GeneHost::input points into it)
     // ---- sizing
     uint32_t seq_cap = SEQ_CAPS[0];       // HapRec sequence capacity of this batch (SEQ_CAPS)
     uint32_t mask_words = 1;              // W: u64 words of the per-read support / low-qual masks

@@ -144,6 +144,9 @@ struct ConsumerHooks {
     uint64_t window_len;
     size_t next_step = 0, cur_step = 0;
     bool is_fwd;
+    // a deep gene is planned as 1 + n_extra copies with disjoint read subsets (batch.hpp GeneHost::n_extra): the same transcript of
+    // copy k is T + tx_stride * k, its steps and windows mirror T's one to one
+    uint32_t n_extra = 0, tx_stride = 0;
 
     void on_exon(const ExonGeom&) {}
     void begin_step() {}
@@ -168,8 +171,41 @@ struct ConsumerHooks {
         const Step& st = b.steps[cur_step];
         if (!(st.flags & SF_PRINT)) throw Error("internal error: print_haplotypes at a step the planner did not schedule");
         const WinStatic& ws = b.wins[st.win];
-        const WinDyn& wd = res.win_dyn[st.win];
+        WinDyn wd = res.win_dyn[st.win];
         if (!(wd.flags & WD_DONE)) throw Error("internal error: window was not computed on the device");
+        // Deep gene: the groups of the window = the union of its copies' groups, counts and depth added up (rows are independent of each
+        // other; every copy's list is ascending in (haplotype, frame), so is the merge). A merged entry keeps the slot of the first copy
+        // that has the group: sequence, flags and record of a (window, haplotype) do not depend on the reads.
+        struct MGroup { uint64_t hap; uint32_t aux, count; uint64_t slot; };
+        static thread_local std::vector<MGroup> merged;
+        if (n_extra) {
+            merged.clear();
+            for (uint32_t k = 0; k < wd.ngroups; k++) {
+                const Group& G = res.grp(uint64_t(wd.group_off) + k);
+                merged.push_back({G.hap, G.aux & ~GROUP_SETTLED, G.count, uint64_t(wd.group_off) + k});
+            }
+            for (uint32_t c = 1; c <= n_extra; c++) {
+                const TxDev& Tc = (&T)[size_t(tx_stride) * c];
+                const Step& sc = b.steps[Tc.step_off + (cur_step - T.step_off)];
+                if (sc.win == 0xFFFFFFFFu) throw Error("internal error: a deep gene's copies diverged");
+                const WinDyn& wc = res.win_dyn[sc.win];
+                if (!(wc.flags & WD_DONE)) throw Error("internal error: window was not computed on the device");
+                wd.nrows += wc.nrows;
+                static thread_local std::vector<MGroup> next;
+                next.clear();
+                size_t i = 0;
+                for (uint32_t k = 0; k < wc.ngroups; k++) {
+                    const uint64_t slot = uint64_t(wc.group_off) + k;
+                    const Group& G = res.grp(slot);
+                    const uint32_t aux = G.aux & ~GROUP_SETTLED;
+                    while (i < merged.size() && (merged[i].hap < G.hap || (merged[i].hap == G.hap && merged[i].aux < aux))) next.push_back(merged[i++]);
+                    if (i < merged.size() && merged[i].hap == G.hap && merged[i].aux == aux) { MGroup m = merged[i++]; m.count += G.count; next.push_back(m); }
+                    else next.push_back({G.hap, aux, G.count, slot});
+                }
+                while (i < merged.size()) next.push_back(merged[i++]);
+                merged.swap(next);
+            }
+        }
         if (frame_in == 0) out.n_windows++;
         const std::vector<Variant>& gvars = gh.input->variants;
         const uint32_t ncols = ws.ncols;
@@ -186,18 +222,21 @@ struct ConsumerHooks {
         size_t frame_depth = 0;
         uint64_t frame = frame_in;
         uint64_t zero_slot = ~0ull;
-        for (uint32_t k = 0; k < wd.ngroups; k++) {
-            uint64_t slot = uint64_t(wd.group_off) + k;
-            const Group& G = res.grp(slot);
-            if (G.hap == 0 && zero_slot == ~0ull) zero_slot = slot;
-            if (G.count == 0) continue;
-            uint64_t f0 = (G.aux & ~GROUP_SETTLED) >> 1;
-            bool f1nz = G.aux & 1;
+        const uint32_t n_listed = n_extra ? uint32_t(merged.size()) : wd.ngroups;
+        for (uint32_t k = 0; k < n_listed; k++) {
+            uint64_t slot = n_extra ? merged[k].slot : uint64_t(wd.group_off) + k;
+            const Group& G0 = res.grp(slot);
+            const uint64_t g_hap = n_extra ? merged[k].hap : G0.hap;
+            const uint32_t g_count = n_extra ? merged[k].count : G0.count, g_aux = n_extra ? merged[k].aux : (G0.aux & ~GROUP_SETTLED);
+            if (g_hap == 0 && zero_slot == ~0ull) zero_slot = slot;
+            if (g_count == 0) continue;
+            uint64_t f0 = g_aux >> 1;
+            bool f1nz = g_aux & 1;
             if (frame > 0 && f0 != frame && f1nz) continue;
-            frame_depth += G.count;
+            frame_depth += g_count;
             uint64_t kf = frame > 0 ? frame : f0;
-            if (!keys.empty() && keys.back().hap == G.hap && keys.back().hframe == kf) keys.back().count += G.count;
-            else keys.push_back({G.hap, kf, G.count, slot});
+            if (!keys.empty() && keys.back().hap == g_hap && keys.back().hframe == kf) keys.back().count += g_count;
+            else keys.push_back({g_hap, kf, g_count, slot});
         }
         if (keys.empty()) {  // :429-431
             if (zero_slot == ~0ull) throw Error("internal error: reference haplotype missing from device results");
@@ -835,10 +874,14 @@ void reserve_streams(NormalText& p, size_t recs) {
 const TextBuf* normal_stream(const SomaticText& p) { return &p.normal_fasta; }
 const TextBuf* normal_stream(const NormalText&) { return nullptr; }
 
+inline void set_copies(ConsumerHooks& h, const GeneHost& gh) { h.n_extra = gh.n_extra; h.tx_stride = gh.n_tx; }   // (copies are planned back to back)
+inline void set_copies(NormalConsumerHooks&, const GeneHost&) {}                                                   // (`normal` genes are never split)
+
 template <class Hooks, class Out>
 void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1, Out& out) {
     for (size_t g = g0; g < g1; g++) {
         const GeneHost& gh = b.genes[g];
+        if (gh.is_extra) continue;   // a read-subset copy of the deep gene before it: consumed with that one
         const GeneInput& gi = *gh.input;
         VarIndex vi{&gi.variants};
         for (uint32_t k = 0; k < gh.n_tx; k++) {
@@ -846,6 +889,7 @@ void consume_range(const Batch& b, const HostResults& res, size_t g0, size_t g1,
             const Transcript& t = gi.gene.transcripts[gh.tx_src[k]];
             PROF(0);
             Hooks hooks{b, res, gh, gi.gene, t, T, out, b.window_len, 0, 0, t.strand == FORWARD};
+            set_copies(hooks, gh);
             walk_transcript(gi.gene, t, vi, gh.max_read_len, b.window_len, hooks);
         }
         const TextBuf* nf = normal_stream(out);

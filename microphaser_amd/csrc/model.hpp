@@ -212,6 +212,10 @@ struct GeneInput {
     std::vector<uint8_t> refseq;      // [gene.start, gene.end+100), case preserved
     std::vector<size_t> reads;        // indices into the ReadStore, BAM file order (mapq NOT yet filtered)
     std::vector<Variant> variants;    // variant_tree flattened: ascending pos, ALT order within pos
+    // A gene too deep for the row slots of the sequential replay is planned as several copies that each hold a SUBSET of its reads
+    // (plan.cpp split_deep_genes); the copies must walk the schedule of the whole gene, which depends on the reads only through
+    // max_read_len (candidate key range, src/microphasing.rs:913-915, :1198-1248): the whole gene's value, 0 = derive from the reads
+    uint64_t max_read_len_override = 0;
 };
 
 // One output record (reference: src/common.rs:350-373, field order = TSV column order).

@@ -727,10 +727,11 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
         std::vector<size_t> kept;
         for (size_t r : gi.reads) {
             if (rs.mapq[r] < mapq_min) continue;
-            gh.max_read_len = std::max<uint64_t>(gh.max_read_len, rs.l_seq[r]);
+            gh.max_read_len = std::max<uint64_t>(gh.max_read_len, rs.l_seq[r]);   // (a read-subset copy of a deep gene: overridden below)
             gh.max_ref_span = std::max<uint64_t>(gh.max_ref_span, uint64_t(rs.end_pos[r] - rs.pos[r]));
             kept.push_back(r);
         }
+        if (gi.max_read_len_override) gh.max_read_len = gi.max_read_len_override;
         std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t c) { return rs.pos[a] < rs.pos[c]; });
         gh.read_off = uint32_t(b.r_pos.size());
         gh.n_reads = uint32_t(kept.size());
@@ -841,6 +842,7 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
                 else { td.sl_lo = uint32_t(ex.end >= 3 ? ex.end - 3 : 0); td.sl_hi = uint32_t(ex.end); }
                 break;
             }
+            uint64_t tx_live = 0;
             auto run = [&](auto& hooks) {
                 hooks.pmax_end = &pmax_end;
                 hooks.take_mark();
@@ -852,6 +854,7 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
                 hooks.finish();
                 td.n_steps = uint32_t(b.steps.size()) - td.step_off;
                 b.max_rows_bound = std::max<uint32_t>(b.max_rows_bound, uint32_t(hooks.max_live));
+                tx_live = hooks.max_live;
                 b.seq_cap = std::max(b.seq_cap, seq_cap_for(hooks.max_seq_len));
             };
             if (normal) {
@@ -862,6 +865,7 @@ static void build_batch_range(const GeneInput* const* genes, size_t n_genes, con
                 run(hooks);
             }
             b.tx.push_back(td);
+            b.tx_max_live.push_back(uint32_t(std::min<uint64_t>(tx_live, 0xFFFFFFFFull)));
             gh.tx_src.push_back(uint32_t(ti));
         }
         gh.n_tx = uint32_t(b.tx.size()) - gh.tx_off;
@@ -974,6 +978,7 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
     mt.add(b.seg_info, parts, &B::seg_info, [](Batch::SegInfo&, size_t) {});
     mt.add(b.exons, parts, &B::exons, [&o](ExonPlan& e, size_t t) { e.tx += uint32_t(o[t].t); });
     mt.add(b.str_pool, parts, &B::str_pool);
+    mt.add(b.tx_max_live, parts, &B::tx_max_live);
     mt.add(b.tx_errors, parts, &B::tx_errors, [&o](std::pair<uint32_t, std::string>& x, size_t t) { x.first += uint32_t(o[t].t); });
     std::vector<std::function<void()>>& tasks = mt.run;
     std::atomic<size_t> next{0};
@@ -999,7 +1004,7 @@ void merge_parts(Batch& b, std::vector<Batch>& parts, size_t nthreads) {
 }  // namespace
 
 // Genes are independent: plan gene ranges on worker threads, then concatenate the sub-batches in gene order.
-void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
+static void build_batch_plain(const GeneInput* const* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
     size_t nthreads = std::min(host_threads(), std::max<size_t>(1, n_genes / 8));
     if (nthreads <= 1) { build_batch_range(genes, n_genes, rs, window_len, normal, b, true); return; }
     std::vector<uint64_t> cost(n_genes + 1, 0);
@@ -1037,6 +1042,92 @@ void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore&
     finalize_segments(b);
     release_later(std::move(parts));   // after the routing pass: unmapping 5 GB of sub-batches holds the mm lock its page faults wait on
     if (dbg) std::fprintf(stderr, "[mp]   plan on %zu threads %.1f ms, merge %.1f ms, finalize %.1f ms\n", nthreads, ms(t0, t1), ms(t1, t2), ms(t2, now()));
+}
+
+// Deep genes. The sequential replay (k2_window_replay: indel / multi-allelic columns, exon chains linked by spanning reads) keeps its
+// rows in the lanes of ONE wave - at most 64 x 16 = 1024 simultaneously live reads; the closed-form kernels stream rows and have no
+// such limit. A gene that needs the sequential replay somewhere AND can exceed the slots there is planned as K copies, each with
+// every K-th read (reads that share (start, name) stay together: `contains`, :281-294, compares exactly those): push_read,
+// extend_right, shrink_left and cleanup_reads act on each row by itself (:220-343), so every copy's matrix is the sub-matrix of
+// its reads, and a window's haplotype counts, frame depths and nrows are the sums over the copies - formed by the consumer
+// (consume.cpp). One amplicon-deep exon with an indel costs its own gene K passes' worth of rows and nothing else. The copies walk
+// the whole gene's schedule (max_read_len_override) - checked step by step below.
+static constexpr uint32_t K2_ROW_SLOTS = 1024;   // kernels.hip: 64 lanes x RPL <= 16
+static uint32_t deep_split_factor(const Batch& b, size_t g) {
+    const GeneHost& gh = b.genes[g];
+    uint32_t live = 0;
+    for (const SegDev& sg : b.segs)   // (segments left to the sequential replay after routing; none in an SNV-only exome)
+        if (sg.tx >= gh.tx_off && sg.tx < gh.tx_off + gh.n_tx) live = std::max(live, b.tx_max_live[sg.tx]);
+    const char* const e = std::getenv("MP_TEST_ROW_SLOTS");   // tests: split shallow genes
+    const uint32_t slots = e && std::atoi(e) >= 8 ? uint32_t(std::atoi(e)) : K2_ROW_SLOTS;
+    if (live <= slots) return 1;
+    return (live + slots - slots / 8 - 1) / (slots - slots / 8);   // copies of at most 7/8 of the slots each (the bound is per transcript, not per window)
+}
+
+void build_batch(const GeneInput* const* genes, size_t n_genes, const ReadStore& rs, uint64_t window_len, bool normal, Batch& b) {
+    build_batch_plain(genes, n_genes, rs, window_len, normal, b);
+    if (normal || b.segs.empty()) return;   // (`normal` keeps one slot per read and transcript: its own, loud limits)
+    std::vector<uint32_t> k_of(n_genes, 1);
+    bool any = false;
+    for (size_t g = 0; g < n_genes; g++) { k_of[g] = deep_split_factor(b, g); any = any || k_of[g] > 1; }
+    if (!any) return;
+    std::deque<GeneInput> copies;
+    std::vector<const GeneInput*> list;
+    std::vector<uint32_t> extra_of;   // per planned gene: copies that follow it (first copy), or 0xFFFFFFFF (a following copy)
+    for (size_t g = 0; g < n_genes; g++) {
+        const GeneInput& gi = *genes[g];
+        if (k_of[g] == 1) { list.push_back(&gi); extra_of.push_back(0); continue; }
+        const uint32_t K = k_of[g];
+        // the whole gene's max_read_len over the reads the matrix would keep (mapq filter of :910), and the subsets: reads in start order,
+        // every first occurrence of a (start, name) pair dealt round robin, later occurrences to the subset of the first
+        uint64_t mrl = 0;
+        std::vector<size_t> kept;
+        for (size_t r : gi.reads) if (rs.mapq[r] >= 5) { mrl = std::max<uint64_t>(mrl, rs.l_seq[r]); kept.push_back(r); }
+        std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t c) { return rs.pos[a] < rs.pos[c]; });
+        std::map<std::pair<int64_t, std::string>, uint32_t> subset_of;
+        std::vector<std::vector<size_t>> sub(K);
+        uint32_t next = 0;
+        for (size_t r : kept) {
+            auto ins = subset_of.emplace(std::make_pair(rs.pos[r], std::string(rs.qname(r))), next);
+            if (ins.second) next = (next + 1) % K;
+            sub[ins.first->second].push_back(r);
+        }
+        for (uint32_t k = 0; k < K; k++) {
+            copies.emplace_back();
+            GeneInput& c = copies.back();
+            c.gene = gi.gene; c.refseq = gi.refseq; c.variants = gi.variants;
+            c.reads = std::move(sub[k]);
+            std::sort(c.reads.begin(), c.reads.end());   // BAM file order, as phase_gene lists them
+            c.max_read_len_override = mrl ? mrl : 1;
+            list.push_back(&c);
+            extra_of.push_back(k == 0 ? K - 1 : 0xFFFFFFFFu);
+        }
+    }
+    build_batch_plain(list.data(), list.size(), rs, window_len, normal, b);
+    b.split_inputs = std::move(copies);   // (a deque: the addresses the GeneHosts hold stay valid)
+    for (size_t p = 0; p < list.size(); p++) {
+        if (extra_of[p] == 0xFFFFFFFFu) { b.genes[p].is_extra = true; continue; }
+        b.genes[p].n_extra = extra_of[p];
+        // every copy walks the first one's schedule: same transcripts, same steps, same printing windows
+        for (uint32_t k = 1; k <= extra_of[p]; k++) {
+            const GeneHost &a = b.genes[p], &c = b.genes[p + k];
+            bool same = a.n_tx == c.n_tx;
+            for (uint32_t t = 0; same && t < a.n_tx; t++) {
+                const TxDev &ta = b.tx[a.tx_off + t], &tc = b.tx[c.tx_off + t];
+                same = ta.n_steps == tc.n_steps;
+                for (uint32_t i = 0; same && i < ta.n_steps; i++) {
+                    const Step &x = b.steps[ta.step_off + i], &y = b.steps[tc.step_off + i];
+                    same = x.sso == y.sso && x.wlen == y.wlen && x.col_hi == y.col_hi && (x.win == 0xFFFFFFFFu) == (y.win == 0xFFFFFFFFu);
+                }
+            }
+            if (!same) throw Error("internal error: the read-subset copies of a deep gene do not share one schedule");
+        }
+    }
+    if (std::getenv("MP_DEBUG")) {
+        size_t n = 0, k = 0;
+        for (size_t g = 0; g < n_genes; g++) if (k_of[g] > 1) { n++; k += k_of[g]; }
+        std::fprintf(stderr, "[mp]   %zu deep gene(s) planned as %zu read-subset copies (sequential replay: %u row slots per wave)\n", n, k, K2_ROW_SLOTS);
+    }
 }
 
 uint64_t Batch::bytes_k1_in() const {
