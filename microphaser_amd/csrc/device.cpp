@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace mp {
 
@@ -30,6 +31,9 @@ DeviceContext::DeviceContext(int device) : device_(device) {
 DeviceContext::~DeviceContext() {
     hipSetDevice(device_);
     free_batch();
+    for (auto& p : pin_) if (p) (void)hipHostFree(p);
+    for (auto& ev : pin_ev_) if (ev) (void)hipEventDestroy(ev);
+    if (xfer_stream_) (void)hipStreamDestroy(xfer_stream_);
     for (auto& ev : ev_) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : fork_) if (ev) (void)hipEventDestroy(ev);
     if (cleared_) (void)hipEventDestroy(cleared_);
@@ -54,8 +58,79 @@ typename V::value_type* DeviceContext::up(const V& v) {
     using T = typename V::value_type;
     T* p = static_cast<T*>(dalloc(v.size() * sizeof(T) + 64));  // +64: kernels stage pools with 16-byte loads
     allocs_.push_back(p);
-    if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
+    // (copied by upload_impl once every array has its device memory: one pipelined run through the pinned ring)
+    if (!v.empty()) pending_up_.push_back(XferSeg{const_cast<char*>(reinterpret_cast<const char*>(v.data())), reinterpret_cast<char*>(p), v.size() * sizeof(T)});
     return p;
+}
+
+// Parallel memcpy of one staging slot's worth of bytes (the destination's pages may be touched here for the first time).
+static void copy_parallel(char* dst, const char* src, size_t n, size_t nthreads) {
+    const size_t piece = size_t(4) << 20;
+    const size_t parts = std::min<size_t>(nthreads, (n + piece - 1) / piece);
+    if (parts <= 1) { std::memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < parts; t++) {
+        const size_t lo = n * t / parts, hi = n * (t + 1) / parts;
+        th.emplace_back([=] { std::memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, n / parts);
+    for (auto& x : th) x.join();
+}
+
+void DeviceContext::xfer(const std::vector<XferSeg>& segs, bool to_device) {
+    size_t total = 0;
+    for (const XferSeg& s : segs) total += s.bytes;
+    if (!total) return;
+    if (std::getenv("MP_NO_PINNED") || total < (size_t(1) << 20)) {   // small transfers (and the A/B switch of the measurements): plain copies
+        for (const XferSeg& s : segs)
+            if (s.bytes) HIP_OK(hipMemcpyAsync(to_device ? (void*)s.dev : (void*)s.host, to_device ? (const void*)s.host : (const void*)s.dev, s.bytes,
+                                               to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        return;
+    }
+    if (!xfer_stream_) HIP_OK(hipStreamCreateWithFlags(&xfer_stream_, hipStreamNonBlocking));
+    for (size_t k = 0; k < XFER_SLOTS; k++) {
+        if (!pin_[k]) HIP_OK(hipHostMalloc(&pin_[k], XFER_SLOT_BYTES, hipHostMallocDefault));
+        if (!pin_ev_[k]) HIP_OK(hipEventCreateWithFlags(&pin_ev_[k], hipEventDisableTiming));
+    }
+    HIP_OK(hipStreamSynchronize(stream_));   // the kernels that produced / will read these buffers run on stream_
+    // chunks: every segment cut into slot-sized pieces (a piece never spans two segments: both sides stay contiguous)
+    struct Chunk { size_t seg, off, len; };
+    std::vector<Chunk> chunks;
+    for (size_t i = 0; i < segs.size(); i++)
+        for (size_t off = 0; off < segs[i].bytes; off += XFER_SLOT_BYTES) chunks.push_back(Chunk{i, off, std::min(XFER_SLOT_BYTES, segs[i].bytes - off)});
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>(8, host_threads()));
+    const size_t n = chunks.size();
+    if (to_device) {
+        // fill slot (host threads) -> DMA; a slot is refilled only after its previous DMA has completed
+        for (size_t i = 0; i < n; i++) {
+            const size_t k = i % XFER_SLOTS;
+            if (i >= XFER_SLOTS) HIP_OK(hipEventSynchronize(pin_ev_[k]));
+            const Chunk& c = chunks[i];
+            copy_parallel(static_cast<char*>(pin_[k]), segs[c.seg].host + c.off, c.len, nthreads);
+            HIP_OK(hipMemcpyAsync(segs[c.seg].dev + c.off, pin_[k], c.len, hipMemcpyHostToDevice, xfer_stream_));
+            HIP_OK(hipEventRecord(pin_ev_[k], xfer_stream_));
+        }
+        HIP_OK(hipStreamSynchronize(xfer_stream_));
+    } else {
+        // DMA into slots up to XFER_SLOTS ahead; drain a slot (host threads) as soon as its DMA has completed
+        size_t issued = 0;
+        auto issue = [&] {
+            const Chunk& c = chunks[issued];
+            const size_t k = issued % XFER_SLOTS;
+            HIP_OK(hipMemcpyAsync(pin_[k], segs[c.seg].dev + c.off, c.len, hipMemcpyDeviceToHost, xfer_stream_));
+            HIP_OK(hipEventRecord(pin_ev_[k], xfer_stream_));
+            issued++;
+        };
+        while (issued < n && issued < XFER_SLOTS) issue();
+        for (size_t i = 0; i < n; i++) {
+            const size_t k = i % XFER_SLOTS;
+            HIP_OK(hipEventSynchronize(pin_ev_[k]));
+            const Chunk& c = chunks[i];
+            copy_parallel(segs[c.seg].host + c.off, static_cast<const char*>(pin_[k]), c.len, nthreads);
+            if (issued < n) issue();   // (slot k is free again: chunk i + XFER_SLOTS goes there)
+        }
+    }
 }
 
 void DeviceContext::free_outputs() {
@@ -67,6 +142,7 @@ void DeviceContext::free_outputs() {
 }
 
 void DeviceContext::free_batch() {
+    pending_up_.clear();
     free_outputs();
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
@@ -178,6 +254,8 @@ void DeviceContext::upload_impl(const Batch& b) {
     while ((uint64_t(NPART) << rlog_) < r_need + r_need / 4) rlog_++;
     if (std::getenv("MP_TEST_SMALL_CAPS")) glog_ = rlog_ = 8;   // tests: start far too small, so that run() has to grow the buffers
     alloc_outputs();
+    xfer(pending_up_, true);
+    pending_up_.clear();
     HIP_OK(hipStreamSynchronize(stream_));
 }
 
@@ -337,24 +415,22 @@ void DeviceContext::download(HostResults& r) {
     advise_huge(r.win_dyn.data(), r.win_dyn.size() * sizeof(WinDyn));
     r.group_part_log2 = glog_;
     r.rec_part_log2 = rlog_;
-    if (d_.n_wins) HIP_OK(hipMemcpyAsync(r.win_dyn.data(), d_.win_dyn, size_t(d_.n_wins) * sizeof(WinDyn), hipMemcpyDeviceToHost, stream_));
+    std::vector<XferSeg> segs;
+    auto seg = [&](void* host, const void* dev, size_t bytes) { if (bytes) segs.push_back(XferSeg{static_cast<char*>(host), const_cast<char*>(static_cast<const char*>(dev)), bytes}); };
+    seg(r.win_dyn.data(), d_.win_dyn, size_t(d_.n_wins) * sizeof(WinDyn));
     uint64_t go = 0, ro = 0;
     for (uint32_t p = 0; p < NPART; p++) {   // the used prefix of every allocator's sub-range, back to back
         r.group_prefix[p] = go;
         r.rec_prefix[p] = ro;
-        if (used_g_[p]) {
-            HIP_OK(hipMemcpyAsync(r.groups.data() + go, d_.groups + (uint64_t(p) << glog_), used_g_[p] * sizeof(Group), hipMemcpyDeviceToHost, stream_));
-            HIP_OK(hipMemcpyAsync(r.gsum.data() + go, d_.gsum + (uint64_t(p) << glog_), used_g_[p] * sizeof(GroupSum), hipMemcpyDeviceToHost, stream_));
-        }
-        if (used_r_[p])
-            HIP_OK(hipMemcpyAsync(r.recs.data() + ro * d_.rec_stride, d_.recs + (uint64_t(p) << rlog_) * d_.rec_stride, used_r_[p] * d_.rec_stride,
-                                  hipMemcpyDeviceToHost, stream_));
+        seg(r.groups.data() + go, d_.groups + (uint64_t(p) << glog_), used_g_[p] * sizeof(Group));
+        seg(r.gsum.data() + go, d_.gsum + (uint64_t(p) << glog_), used_g_[p] * sizeof(GroupSum));
+        seg(r.recs.data() + ro * d_.rec_stride, d_.recs + (uint64_t(p) << rlog_) * d_.rec_stride, used_r_[p] * d_.rec_stride);
         go += used_g_[p];
         ro += used_r_[p];
     }
     r.group_prefix[NPART] = go;
     r.rec_prefix[NPART] = ro;
-    HIP_OK(hipStreamSynchronize(stream_));
+    xfer(segs, false);   // pipelined through the pinned ring: DMA of one slot beside the host threads draining the others
 }
 
 }  // namespace mp

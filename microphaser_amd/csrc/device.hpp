@@ -55,6 +55,18 @@ class DeviceContext {
     uint64_t hbm_bytes() const { return hbm_bytes_; }
 
   private:
+    // Host <-> device transfers go through a small ring of PINNED staging buffers (f1; the reference side is the per-gene
+    // fetch of src/microphasing.rs:905-942): the DMA engine moves one slot while the host threads fill (H2D) or drain (D2H) the
+    // others, so the PCIe link runs at its pinned rate and the page faults of freshly allocated host arrays are taken by several
+    // threads beside it - a pageable hipMemcpy stages through the runtime's own buffer on ONE thread. The big host arrays themselves
+    // stay pageable: pinning gigabytes costs more than one pass through them.
+    struct XferSeg { char* host; char* dev; size_t bytes; };
+    static constexpr size_t XFER_SLOTS = 4, XFER_SLOT_BYTES = size_t(32) << 20;
+    void* pin_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pin_ev_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t xfer_stream_ = nullptr;
+    std::vector<XferSeg> pending_up_;     // upload(): the arrays to copy once everything is allocated
+    void xfer(const std::vector<XferSeg>& segs, bool to_device);
     void* dalloc(size_t bytes);
     template <class V> typename V::value_type* up(const V& v);
     void upload_impl(const Batch& b);
