@@ -77,7 +77,8 @@ struct Batch {
     PodVec<WChunk> wchunks, wchunks_m, wchunks_d;   // single-block / multi-block / streamed (any depth) window-parallel work items (kernels.hpp)
     uint32_t rows_per_lane_w = 1;
     PodVec<WinW> winw;                   // lane-per-window replay (plan.hpp WinW): one per entry of lane_small / lane_wide
-    uint32_t n_lane_small = 0;           // winw[0 .. n_lane_small): windows with <= K2L_SMALL_COLS columns, the rest: up to K2L_MAX_COLS
+    uint32_t n_lane_small = 0;           // winw[0 .. n_lane_small): windows with <= K2L_SMALL_COLS columns, [n_lane_small, n_lane_mid): up to K2L_MAX_COLS,
+    uint32_t n_lane_mid = 0;             // the rest: 9..K2L_HASH_COLS columns (the lane kernel's hash-table form)
     PodVec<uint32_t> lane_win;           // window index of each winw entry
     PodVec<uint32_t> win_trivial;        // bit per window, see kernels.hpp
     bool lane_on = false;                // K2a writes RowRecs and the lane kernel takes the eligible windows

@@ -81,7 +81,12 @@ void DeviceContext::xfer(const std::vector<XferSeg>& segs, bool to_device) {
     size_t total = 0;
     for (const XferSeg& s : segs) total += s.bytes;
     if (!total) return;
-    if (std::getenv("MP_NO_PINNED") || total < (size_t(1) << 20)) {   // small transfers (and the A/B switch of the measurements): plain copies
+    // Uploads go straight from the pageable arrays unless MP_PINNED_H2D is set: measured at config C (8.1 GB up, 32 host threads), the
+    // runtime's own pageable path already moves 32 GB/s and filling the ring from the same pageable pages with 8 threads is no faster
+    // (284 vs 250 ms); downloads through the ring take 90 instead of 174 ms (2.3 GB; profiles/r05g_e2e_pinned_vs_pageable.log) - their
+    // destination pages are fresh and are then first touched by eight threads instead of the runtime's one.
+    const bool plain = std::getenv("MP_NO_PINNED") || total < (size_t(1) << 20) || (to_device && !std::getenv("MP_PINNED_H2D"));
+    if (plain) {   // small transfers, uploads, and the A/B switch of the measurements: plain copies
         for (const XferSeg& s : segs)
             if (s.bytes) HIP_OK(hipMemcpyAsync(to_device ? (void*)s.dev : (void*)s.host, to_device ? (const void*)s.host : (const void*)s.dev, s.bytes,
                                                to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream_));
@@ -216,6 +221,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.lane_win = up(b.lane_win);
     d_.win_trivial = up(b.win_trivial);
     d_.n_lane_small = b.n_lane_small;
+    d_.n_lane_mid = b.n_lane_mid;
     d_.n_lane_all = uint32_t(b.winw.size());
     if (b.lane_on) {
         d_.rr_a = static_cast<RowRecA*>(dalloc(size_t(b.n_adm + 1) * sizeof(RowRecA))); allocs_.push_back(d_.rr_a);
@@ -308,9 +314,11 @@ void DeviceContext::run(RunTiming& t) {
         HIP_OK(hipEventRecord(fork_[1], stream_));
         HIP_OK(hipStreamWaitEvent(side_[0], fork_[1], 0));
         HIP_OK(hipStreamWaitEvent(side_[1], fork_[1], 0));
-        launch_k2_window_lanes(d_, stream_, side_[0]);   // lane per window: <= 6 columns here, 7-8 columns beside it
+        HIP_OK(hipStreamWaitEvent(side_[3], fork_[1], 0));
+        launch_k2_window_lanes(d_, stream_, side_[0], side_[3]);   // lane per window: <= 6 columns here, 7-8 and 9-16 columns beside it
         HIP_OK(hipEventRecord(ev_[7], stream_));
         HIP_OK(hipEventRecord(join_[0], side_[0]));
+        HIP_OK(hipEventRecord(join_[3], side_[3]));
         launch_k2_window_rows(d_, side_[1]);             // wave per window: the rest, beside them
         HIP_OK(hipEventRecord(join_[1], side_[1]));
         for (auto& ev : join_) HIP_OK(hipStreamWaitEvent(stream_, ev, 0));
@@ -376,10 +384,11 @@ void DeviceContext::run(RunTiming& t) {
         // (overlapping intervals: k2seq beside k2a; k2l = the longer of its two launches, k2w beside them, both from the end of K2a)
         HIP_OK(hipEventElapsedTime(&t.k2seq_ms, ev_[1], join_[2]));
         HIP_OK(hipEventElapsedTime(&t.k2a_ms, ev_[1], ev_[6]));
-        float l6 = 0, l8 = 0;
+        float l6 = 0, l8 = 0, l16 = 0;
         HIP_OK(hipEventElapsedTime(&l6, ev_[6], ev_[7]));
         HIP_OK(hipEventElapsedTime(&l8, ev_[6], join_[0]));
-        t.k2l_ms = std::max(l6, l8);
+        HIP_OK(hipEventElapsedTime(&l16, ev_[6], join_[3]));
+        t.k2l_ms = std::max(std::max(l6, l8), l16);
         HIP_OK(hipEventElapsedTime(&t.k2w_ms, ev_[6], join_[1]));
         HIP_OK(hipEventElapsedTime(&t.k2win_ms, ev_[6], ev_[2]));
         HIP_OK(hipEventElapsedTime(&t.k3_ms, ev_[2], ev_[3]));

@@ -74,8 +74,8 @@ class DeviceContext {
     void free_outputs();
     int device_ = 0;
     hipStream_t stream_ = nullptr;
-    hipStream_t side_[3] = {nullptr, nullptr, nullptr};   // the independent launches of the window phase run side by side (run())
-    hipEvent_t fork_[2] = {nullptr, nullptr}, join_[3] = {nullptr, nullptr, nullptr}, cleared_ = nullptr;
+    hipStream_t side_[4] = {nullptr, nullptr, nullptr, nullptr};   // the independent launches of the window phase run side by side (run())
+    hipEvent_t fork_[2] = {nullptr, nullptr}, join_[4] = {nullptr, nullptr, nullptr, nullptr}, cleared_ = nullptr;
     hipEvent_t k3_fork_ = nullptr, k3_join_ = nullptr;    // K3's list B runs beside list A on side_[0]
     hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs_, out_allocs_;

@@ -811,9 +811,16 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
 // the wave then takes one run of group slots / record slots for all its windows (prefix sums, two atomics per 64 windows),
 // so consecutive windows' groups are consecutive in memory and no slot is left unused.
 //   reference: ObservationMatrix rows and the count phase of print_haplotypes, src/microphasing.rs:220-343, :383-411
+// HB = 6 / 8: windows of <= 6 / 8 columns, a direct table of 2^HB byte counters per lane. HB = 16 (K2L_HASH_COLS): windows of 9..16 columns
+// with at most K2L_HASH_ROWS candidate reads - the direct table would need 64 K counters, so the lane keeps a 64-slot open-addressing
+// table in its LDS column instead (entry = haplotype word << 8 | count; linear probing; at most 63 distinct words, so a probe always ends
+// at a free slot): one dependent LDS round trip per row instead of the wave-per-window kernel's ballots and readlanes (470 wave
+// instructions per WINDOW there, ~40 here); the keys come out ascending by repeated minimum over the lane's occupied slots.
 template <int HB, int STAGE_>   // STAGE_: RowRecs staged in LDS per pass (24 bytes each); 0 = gather from memory (experiments)
 __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t first, uint32_t count) {
-    constexpr uint32_t NW = (1u << HB) / 4;   // table words per lane (four 8-bit counters each); NW <= 64
+    constexpr bool HASH = HB > 8;
+    constexpr uint32_t NW = HASH ? 64u : (1u << HB) / 4;   // table words per lane (direct: four 8-bit counters each; hash: one entry each); NW <= 64
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     constexpr uint32_t STAGE = STAGE_ ? STAGE_ : 1;
     static_assert(STAGE_ == 0 || STAGE_ > int(K2L_MAX_ROWS), "a window's candidate reads must fit one stage pass, or the staging loop never ends");
     __shared__ uint32_t hist[NW * 64];
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
     __shared__ uint64_t st_s[STAGE];
     const uint32_t lane = threadIdx.x;
 #pragma unroll 4
-    for (uint32_t t = 0; t < NW; t++) hist[t * 64 + lane] = 0;
+    for (uint32_t t = 0; t < NW; t++) hist[t * 64 + lane] = HASH ? EMPTY : 0u;
     const uint32_t part = blockIdx.x & (NPART - 1);
     unsigned long long* const gcur = d.cursors + part * 32;
     unsigned long long* const rcur = gcur + 16;
@@ -861,8 +868,24 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
             const uint32_t bits = dsh >= 0 ? (dsh < 64 ? right : 0u) : (dsh > -32 ? left : 0u);
             const uint32_t h = (fwd ? (__brev(bits) >> rev_sh) : bits) & cmask32;
             nrows += row ? 1u : 0u;
-            atomicAdd(&hist[(h >> 2) * 64 + lane], act ? (1u << (8 * (h & 3))) : 0u);   // the lane's own counter: a plain ds_add
-            touched |= act ? (1ull << (h >> 2)) : 0ull;
+            if constexpr (!HASH) {
+                atomicAdd(&hist[(h >> 2) * 64 + lane], act ? (1u << (8 * (h & 3))) : 0u);   // the lane's own counter: a plain ds_add
+                touched |= act ? (1ull << (h >> 2)) : 0ull;
+            } else {
+                // insert / count in the lane's own table column (every lane probes in step; `touched` = the occupied slots)
+                uint32_t slot = (h * 0x9E3779B1u) >> 26;
+                bool todo = act;
+                while (__ballot(todo)) {
+                    const uint32_t e = hist[slot * 64 + lane];
+                    const bool fresh = e == EMPTY, hit = (e >> 8) == h;
+                    if (todo && (fresh || hit)) {
+                        hist[slot * 64 + lane] = fresh ? ((h << 8) | 1u) : e + 1u;
+                        touched |= fresh ? (1ull << slot) : 0ull;
+                        todo = false;
+                    }
+                    slot = (slot + 1) & 63u;
+                }
+            }
         };
         // The candidate ranges of a tile's windows overlap almost completely (consecutive windows of one exon): the wave stages
         // their union in LDS, STAGE records at a time starting at the lowest range not done yet - one pass for most tiles, two
@@ -925,20 +948,28 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         }
         // ---- groups in ascending key order: key 0 (the reference haplotype) is always listed (:429-431)
-        touched |= 1ull;
+        if constexpr (!HASH) touched |= 1ull;
         uint32_t ng = 0, nneed = 0;
+        bool has_zero = false;   // (hash form) the reference haplotype has an entry of its own
         if (valid) {
             uint64_t tm = touched;
             while (tm) {
                 const uint32_t t = uint32_t(__builtin_ctzll(tm));
                 tm &= tm - 1;
                 const uint32_t x = hist[t * 64 + lane];
+                if constexpr (HASH) {
+                    const uint32_t key = x >> 8;
+                    ng++; nneed += (need_all || (uint64_t(key) & som_mask)) ? 1u : 0u;
+                    has_zero = has_zero || key == 0;
+                } else {
 #pragma unroll
-                for (uint32_t b = 0; b < 4; b++) {
-                    const uint32_t key = 4 * t + b;
-                    if (((x >> (8 * b)) & 0xFF) || key == 0) { ng++; nneed += (need_all || (uint64_t(key) & som_mask)) ? 1u : 0u; }
+                    for (uint32_t b = 0; b < 4; b++) {
+                        const uint32_t key = 4 * t + b;
+                        if (((x >> (8 * b)) & 0xFF) || key == 0) { ng++; nneed += (need_all || (uint64_t(key) & som_mask)) ? 1u : 0u; }
+                    }
                 }
             }
+            if (HASH && !has_zero) { ng++; nneed += need_all ? 1u : 0u; }   // key 0 is listed with count 0 (:429-431)
         }
         // wave-inclusive prefix sums of (ng, nneed), packed: ng <= 256 per lane -> sum <= 16384; nneed likewise
         uint32_t scan = ng | (nneed << 16);
@@ -985,6 +1016,38 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         uint64_t rslot = rpart_lo + rbase + ((scan >> 16) - nneed);
         if (valid) {
             const uint32_t goff = uint32_t(gslot);
+            auto emit = [&](const uint32_t key, const uint32_t cnt) {
+                const bool need = need_all || (uint64_t(key) & som_mask) != 0;
+                if (can_write) {
+                    const bool settled = trivial && !need;   // what K3 would find: valid, no stop, mutant == germline, no record
+                    Group G; G.hap = key; G.count = cnt; G.aux = settled ? GROUP_SETTLED : 0u;
+                    d.groups[gslot] = G;
+                    // the rest is for K3 only: one item (k3_enqueue's layout) in list A or B
+                    if (need) d.k3_items[la_slot++] = make_uint4(uint32_t(gslot), win, rec_ok ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                    else if (!settled) d.k3_items[lb_slot--] = make_uint4(uint32_t(gslot), win, 0xFFFFFFFFu, 0u);
+                }
+                gslot++;
+                rslot += need ? 1u : 0u;
+            };
+            if constexpr (HASH) {
+                // ascending keys (the reference's BTreeMap order, :383): the smallest remaining entry of the lane's occupied slots, again
+                // and again (entries are key << 8 | count with distinct keys: comparing entries compares keys)
+                if (!has_zero) emit(0u, 0u);
+                uint64_t left = touched;
+                while (left) {
+                    uint32_t best = EMPTY, bs = 0;
+                    uint64_t tm = left;
+                    while (tm) {
+                        const uint32_t t = uint32_t(__builtin_ctzll(tm));
+                        tm &= tm - 1;
+                        const uint32_t e = hist[t * 64 + lane];
+                        if (e < best) { best = e; bs = t; }
+                    }
+                    left &= ~(1ull << bs);
+                    hist[bs * 64 + lane] = EMPTY;   // ready for the next tile
+                    emit(best >> 8, best & 0xFFu);
+                }
+            } else {
             uint64_t tm = touched;
             while (tm) {
                 const uint32_t t = uint32_t(__builtin_ctzll(tm));
@@ -994,20 +1057,9 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
 #pragma unroll
                 for (uint32_t b = 0; b < 4; b++) {
                     const uint32_t key = 4 * t + b, cnt = (x >> (8 * b)) & 0xFF;
-                    if (cnt || key == 0) {
-                        const bool need = need_all || (uint64_t(key) & som_mask) != 0;
-                        if (can_write) {
-                            const bool settled = trivial && !need;   // what K3 would find: valid, no stop, mutant == germline, no record
-                            Group G; G.hap = key; G.count = cnt; G.aux = settled ? GROUP_SETTLED : 0u;
-                            d.groups[gslot] = G;
-                            // the rest is for K3 only: one item (k3_enqueue's layout) in list A or B
-                            if (need) d.k3_items[la_slot++] = make_uint4(uint32_t(gslot), win, rec_ok ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
-                            else if (!settled) d.k3_items[lb_slot--] = make_uint4(uint32_t(gslot), win, 0xFFFFFFFFu, 0u);
-                        }
-                        gslot++;
-                        rslot += need ? 1u : 0u;
-                    }
+                    if (cnt || key == 0) emit(key, cnt);
                 }
+            }
             }
             WinDyn wd;
             wd.group_off = goff;
@@ -1074,7 +1126,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
         }
         // (the windows the lane-per-window kernel takes are not this kernel's: plan.cpp lane_window)
         uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT) &&
-                                     !(d.lane_on && (w7 >> 16) <= K2L_MAX_COLS && (w7 & 0xFFFF) <= K2L_MAX_ROWS));
+                                     !(d.lane_on && k2l_takes(w7 >> 16, w7 & 0xFFFF)));
         while (printing) {
             const uint32_t i = uint32_t(__builtin_ctzll(printing));
             printing &= printing - 1;
@@ -1320,7 +1372,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
         }
         // (the windows the lane-per-window kernel takes are not this kernel's: plan.cpp lane_window)
         uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT) &&
-                                     !(d.lane_on && (w7 >> 16) <= K2L_MAX_COLS && (w7 & 0xFFFF) <= K2L_MAX_ROWS));
+                                     !(d.lane_on && k2l_takes(w7 >> 16, w7 & 0xFFFF)));
         while (printing) {
             const uint32_t i = uint32_t(__builtin_ctzll(printing));
             printing &= printing - 1;
@@ -2754,10 +2806,10 @@ void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
 }
 
 template <int STAGE>
-static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide) {
+static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide, hipStream_t stream_hash) {
     // one wave per tile of 64 windows: a wave that walked several tiles would wait for its own result stores to drain before the
     // next tile's loads return (loads and stores share the in-order vmcnt counter)
-    const uint32_t n_small = d.n_lane_small, n_wide = d.n_lane_all - d.n_lane_small;
+    const uint32_t n_small = d.n_lane_small, n_wide = d.n_lane_mid - d.n_lane_small, n_hash = d.n_lane_all - d.n_lane_mid;
     const uint32_t lds_small = 4096 + 24 * STAGE, lds_wide = 16384 + 24 * STAGE;
     static const bool persistent = std::getenv("MP_K2L_PERSISTENT") != nullptr;   // experiments: a fixed grid that walks the tiles
     if (n_small) {
@@ -2770,14 +2822,19 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream
         hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
         HIP_CHECK_LAUNCH();
     }
+    if (n_hash) {   // 9..16 columns: the per-lane hash table (same LDS footprint as the 7-8 column form)
+        const uint32_t tiles = (n_hash + 63) / 64, waves = min(32u, 163840u / lds_wide);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_HASH_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_hash, d, d.n_lane_mid, n_hash);
+        HIP_CHECK_LAUNCH();
+    }
 }
-void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide) {
+void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide, hipStream_t stream_hash) {
     if (!d.lane_on) return;
     static const int stage = [] { const char* e = std::getenv("MP_K2L_STAGE"); return e ? std::atoi(e) : 256; }();   // experiments
     switch (stage) {
-        case 0: launch_k2l<0>(d, stream_small, stream_wide); break;
-        case 384: launch_k2l<384>(d, stream_small, stream_wide); break;
-        default: launch_k2l<256>(d, stream_small, stream_wide); break;
+        case 0: launch_k2l<0>(d, stream_small, stream_wide, stream_hash); break;
+        case 384: launch_k2l<384>(d, stream_small, stream_wide, stream_hash); break;
+        default: launch_k2l<256>(d, stream_small, stream_wide, stream_hash); break;
     }
 }
 

@@ -49,7 +49,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const WinW* winw;
     const uint32_t* lane_win;
     const uint32_t* win_trivial;    // bit per window: WSF_SIMPLE && WSF_NOSTOP and no record demand of its own (plan.hpp WW_TRIVIAL)
-    uint32_t n_lane_small, n_lane_all, lane_on, lane_pad_;
+    uint32_t n_lane_small, n_lane_all, lane_on, n_lane_mid;   // winw[0, small): <= 6 columns, [small, mid): 7-8, [mid, all): 9-16 (hash form)
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
     uint32_t n_exons_w, n_wchunks, n_wchunks_m, n_achunks;
     uint32_t rows_per_lane_w;       // RPL of k2w_window_rows_multi: 64 * RPL >= candidate reads of any of its windows
@@ -88,8 +88,8 @@ void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
 void launch_k2_admission(const DeviceBatch& d, hipStream_t stream);     // K2a over the ExonW part of the plan
 void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream);   // K2w, after K2a
-// K2l, after K2a: the windows of winw; the <= 6-column and the 7-8-column launch are independent and may go to different streams
-void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide);
+// K2l, after K2a: the windows of winw; the <= 6-column, the 7-8-column and the 9-16-column (hash table) launch are independent and may go to different streams
+void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide, hipStream_t stream_hash);
 // K3 / K3b: one grid row per output allocator; a row reads its list's length from the allocator's cursor on the device, the host only
 // passes an upper bound of the total that sizes the rows.
 // somatic: two launches - list A (sequences, records AND their SHA-1 ids) and list B (flags only) - independent, may go to two streams;

@@ -464,12 +464,15 @@ static void validate_segments(const Batch& b) {
 // Lane-per-window replay (plan.hpp WinW): flatten every eligible printing window of the window-parallel exons, small windows
 // (<= K2L_SMALL_COLS columns) first; the wave-per-window kernels keep only the work items that still hold one of their windows.
 static bool lane_window(const Batch& b, uint32_t si) {
-    return b.lane_on && (b.steps[si].flags & SF_PRINT) && b.step_ncols[si] <= K2L_MAX_COLS && b.step_rn[si] <= K2L_MAX_ROWS;
+    static const bool no_hash = std::getenv("MP_NO_LANE_HASH") != nullptr;   // (measurements: the 9..16-column windows back to the wave kernels)
+    if (no_hash && b.step_ncols[si] > K2L_MAX_COLS) return false;
+    return b.lane_on && (b.steps[si].flags & SF_PRINT) && k2l_takes(b.step_ncols[si], b.step_rn[si]);
 }
 static void route_lane_windows(Batch& b) {
     b.winw.clear();
     b.lane_win.clear();
     b.n_lane_small = 0;
+    b.n_lane_mid = 0;
     b.win_trivial.assign(b.wins.size() / 32 + 2, 0u);
     for (size_t w = 0; w < b.wins.size(); w++) {
         const WinStatic& ws = b.wins[w];
@@ -478,7 +481,7 @@ static void route_lane_windows(Batch& b) {
     }
     if (!b.lane_on) return;
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>(host_threads(), b.exons_w.size() / 64 + 1));
-    struct Part { PodVec<WinW> w[2]; PodVec<uint32_t> id[2]; };
+    struct Part { PodVec<WinW> w[3]; PodVec<uint32_t> id[3]; };
     std::vector<Part> parts(nthreads);
     auto work = [&](size_t t) {
         Part& P = parts[t];
@@ -512,7 +515,7 @@ static void route_lane_windows(Batch& b) {
                     }
                 }
                 w.som_lo = uint32_t(som); w.som_hi = uint32_t(som >> 32);
-                const int cls = nc <= K2L_SMALL_COLS ? 0 : 1;
+                const int cls = nc <= K2L_SMALL_COLS ? 0 : nc <= K2L_MAX_COLS ? 1 : 2;
                 P.w[cls].push_back(w);
                 P.id[cls].push_back(st.win);
             }
@@ -524,14 +527,15 @@ static void route_lane_windows(Batch& b) {
         for (size_t t = 0; t < nthreads; t++) th.emplace_back(work, t);
         for (auto& x : th) x.join();
     }
-    size_t n[2] = {0, 0};
-    for (const Part& P : parts) { n[0] += P.w[0].size(); n[1] += P.w[1].size(); }
-    b.winw.resize(n[0] + n[1]);
-    b.lane_win.resize(n[0] + n[1]);
+    size_t n[3] = {0, 0, 0};
+    for (const Part& P : parts) { n[0] += P.w[0].size(); n[1] += P.w[1].size(); n[2] += P.w[2].size(); }
+    b.winw.resize(n[0] + n[1] + n[2]);
+    b.lane_win.resize(n[0] + n[1] + n[2]);
     b.n_lane_small = uint32_t(n[0]);
-    size_t at[2] = {0, n[0]};
+    b.n_lane_mid = uint32_t(n[0] + n[1]);
+    size_t at[3] = {0, n[0], n[0] + n[1]};
     for (const Part& P : parts)
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < 3; c++) {
             if (!P.w[c].empty()) {
                 std::memcpy(static_cast<void*>(b.winw.data() + at[c]), P.w[c].data(), P.w[c].size() * sizeof(WinW));
                 std::memcpy(b.lane_win.data() + at[c], P.id[c].data(), P.id[c].size() * 4);

@@ -83,6 +83,15 @@ struct AdmEntry {                   // K2a output per (ExonW, read)
 constexpr uint32_t K2L_MAX_COLS = 8;
 constexpr uint32_t K2L_SMALL_COLS = 6;    // windows with <= 6 columns: 64 counters per lane (4 KB of LDS per wave); 7-8: 256 (16 KB)
 constexpr uint32_t K2L_MAX_ROWS = 255;    // 8-bit counters
+constexpr uint32_t K2L_HASH_COLS = 16;    // windows with 9..16 columns: a 64-slot hash table per lane (entry = 16-bit haplotype word << 8 | count) ...
+constexpr uint32_t K2L_HASH_ROWS = 63;    // ... which must keep a free slot: at most 63 candidate reads (so at most 63 distinct words)
+// does the lane-per-window kernel take a printing window with this many columns / candidate reads? (planner and wave kernels agree on it)
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline bool k2l_takes(uint32_t ncols, uint32_t rn) {
+    return (ncols <= K2L_MAX_COLS && rn <= K2L_MAX_ROWS) || (ncols <= K2L_HASH_COLS && rn <= K2L_HASH_ROWS);
+}
 struct WinW {
     uint32_t rr_lo;      // RowRec index of the window's first candidate read
     uint32_t pack;       // r_n (bits 0-9) | ncols (10-15) | WW_FWD | WW_NEED_ALL
