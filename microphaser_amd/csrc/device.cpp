@@ -217,6 +217,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.n_adm = b.n_adm;
     d_.adm = static_cast<AdmEntry*>(dalloc(size_t(b.n_adm + 1) * sizeof(AdmEntry))); allocs_.push_back(d_.adm);
     d_.lane_on = b.lane_on ? 1u : 0u;
+    d_.lane_hash = b.lane_hash ? 1u : 0u;
     d_.winw = up(b.winw);
     d_.lane_win = up(b.lane_win);
     d_.win_trivial = up(b.win_trivial);

@@ -64,12 +64,11 @@ __device__ __forceinline__ uint8_t decode_base4(uint32_t code) {  // BAM 4-bit c
 
 constexpr uint32_t K1_LANES = 4;    // lanes per read (measured at config C: 1 lane 1.40 ms, 2: 1.07, 4: 1.10, 8: 1.31, 16: 1.71; with the
                                     // batched rounds below - lanes x rounds = 2 x 12: 1.00 ms, 4 x 6: 0.75, 8 x 3: 0.88)
-constexpr uint32_t K1_SLICE = (1u << K1_LANES) - 1u;
+static_assert(K1_LANES == 4, "the group's lanes combine their bits with quad permutes");
 template <int W>
 __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
     const uint32_t sub = threadIdx.x & (K1_LANES - 1);             // lane within the read's group
-    const uint32_t gshift = (threadIdx.x & 63u) & ~(K1_LANES - 1); // bit position of the group's slice in a wave ballot
     const uint64_t i_raw = t / K1_LANES;
     const bool valid = i_raw < d.n_reads;
     const uint32_t i = valid ? uint32_t(i_raw) : d.n_reads - 1;              // surplus groups shadow the last read (no stores)
@@ -89,12 +88,19 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
 #pragma unroll
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
     uint32_t ncov = 0;
-    bool more = true;   // the group's run may continue (every variant of the previous round was covered)
-    // The kernel is bound by dependent loads, not by bytes: (variant position -> base, quality) is a two-level chain per variant. K1_ROUNDS
-    // rounds of K1_LANES variants are therefore taken together - all their positions are loaded first, then all their bases and
-    // qualities, then everything is evaluated - so a typical read (about 20 variants in its span) pays the chain once, not five times.
+    bool more = true;   // the group's run may continue (every variant of the previous batch was covered)
+    // The kernel is bound by dependent loads and by instruction issue, not by bytes: (variant position -> base, quality) is a two-level
+    // chain per variant. K1_ROUNDS rounds of K1_LANES variants are therefore taken together - all their positions are loaded first, then all
+    // their bases and qualities, then everything is evaluated - so a typical read (about 20 variants in its span) pays the chain once, not
+    // five times. The evaluation of a batch is branch-free for the common case (SNV under a single-M CIGAR): every lane collects its
+    // coverage / support / low-quality bits of the batch in three 24-bit words (bit 4 r + lane-in-group), the rare other cases (indels,
+    // SNVs under a CIGAR with clips / indels) are marked and settled in a loop of their own, and the group's four lanes OR their words
+    // together with two DPP moves each - no ballots, no 64-bit shifts per round (27 -> ~20 vector instructions per read and round).
     constexpr uint32_t K1_ROUNDS = 6;
-    for (uint32_t b0 = 0; b0 < 64u * W; b0 += K1_LANES * K1_ROUNDS) {
+    constexpr uint32_t K1_BATCH = K1_LANES * K1_ROUNDS;
+    const uint32_t one_sub = 1u << sub;
+    const uint32_t len0 = c0 >> 4;
+    for (uint32_t b0 = 0; b0 < 64u * W; b0 += K1_BATCH) {
         if (__ballot(more) == 0) break;   // wave-uniform
         uint32_t vpos[K1_ROUNDS], info[K1_ROUNDS];
         bool in[K1_ROUNDS];
@@ -109,10 +115,6 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             vpos[r] = d.v_pos[at];
             info[r] = d.v_info[at];
         }
-        bool cov[K1_ROUNDS], snv[K1_ROUNDS];
-        bool qb[K1_ROUNDS];
-        uint8_t b4[K1_ROUNDS];
-        int rp[K1_ROUNDS];
         const uint32_t last_q = lseq ? lseq - 1 : 0;
         uint32_t ql[K1_ROUNDS];
         uint8_t sl[K1_ROUNDS];
@@ -123,49 +125,61 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
             ql[r] = lowq[relc >> 5];
             sl[r] = seq4[relc >> 1];
         }
+        uint32_t acc_c = 0, acc_s = 0, acc_q = 0, slow = 0;
 #pragma unroll
         for (uint32_t r = 0; r < K1_ROUNDS; r++) {
-            cov[r] = in[r] && vpos[r] < cover_end;
-            snv[r] = cov[r] && (info[r] & VI_KIND_MASK) == 0;
+            const bool cov = in[r] && vpos[r] < cover_end;
+            const bool snv = cov && (info[r] & VI_KIND_MASK) == 0;
             const uint32_t rel = vpos[r] - rpos;
-            qb[r] = snv[r] && rel < lseq && ((ql[r] >> (rel & 31u)) & 1u);   // the reference indexes the qualities by reference offset (:82-88)
-            rp[r] = (snv[r] && simple && rel < (c0 >> 4)) ? int(rel) : -1;
-            b4[r] = (rp[r] >= 0 && rel < lseq) ? sl[r] : uint8_t(0);
+            // the reference indexes the qualities by reference offset (:82-88); `normal` has no quality gate (src/normal_microphasing.rs:43-52)
+            const bool q = snv && !d.normal && rel < lseq && ((ql[r] >> (rel & 31u)) & 1u);
+            const bool fast = snv && simple && rel < len0 && rel < lseq;   // a single M op: read_pos(p) = p - start
+            const uint32_t code = (rel & 1) ? (sl[r] & 0xFu) : (uint32_t(sl[r]) >> 4);
+            const bool s = fast && !q && decode_base4(code) == uint8_t(info[r] >> VI_ALT_SHIFT);   // SNV (:97-112, :80-92)
+            const uint32_t bit = one_sub << (K1_LANES * r);
+            acc_c |= cov ? bit : 0u;
+            acc_s |= s ? bit : 0u;
+            acc_q |= q ? bit : 0u;
+            slow |= (cov && ((snv && !simple && !q) || !snv)) ? (1u << r) : 0u;
         }
+        if (__ballot(slow != 0)) {   // insertions / deletions, SNVs under a CIGAR with more than one M: rare, settled apart
 #pragma unroll
-        for (uint32_t r = 0; r < K1_ROUNDS; r++) {
-            bool s = false, q = false;
-            if (snv[r]) {  // SNV (:97-112, :80-92)
-                q = !d.normal && qb[r];  // `normal` has no quality gate (src/normal_microphasing.rs:43-52)
-                if (!q) {
-                    int p = rp[r];
-                    uint8_t byte = b4[r];
-                    if (!simple) {
-                        p = cigar_read_pos_dev(cig, ncig, rpos, vpos[r]);
-                        if (p >= 0 && uint32_t(p) < lseq) byte = seq4[p >> 1];
-                    }
+            for (uint32_t r = 0; r < K1_ROUNDS; r++) {
+                if (!((slow >> r) & 1u)) continue;
+                bool s = false;
+                if ((info[r] & VI_KIND_MASK) == 0) {
+                    const int p = cigar_read_pos_dev(cig, ncig, rpos, vpos[r]);
                     if (p >= 0 && uint32_t(p) < lseq) {
-                        const uint32_t code = (p & 1) ? (byte & 0xF) : (byte >> 4);
+                        const uint8_t byte = seq4[p >> 1];
+                        const uint32_t code = (p & 1) ? (byte & 0xFu) : (uint32_t(byte) >> 4);
                         s = decode_base4(code) == uint8_t(info[r] >> VI_ALT_SHIFT);
                     }
+                } else {  // insertion / deletion: any I / D op of exactly that length (:113-137)
+                    const uint32_t want = (info[r] & VI_KIND_MASK) == 1 ? 1u : 2u;
+                    const uint32_t vlen = d.v_len[vfirst + b0 + r * K1_LANES + sub];
+                    for (uint32_t c = 0; c < ncig; c++)
+                        if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
                 }
-            } else if (cov[r]) {  // insertion / deletion: any I / D op of exactly that length (:113-137)
-                const uint32_t b = b0 + r * K1_LANES + sub;
-                const uint32_t want = (info[r] & VI_KIND_MASK) == 1 ? 1u : 2u;
-                const uint32_t vlen = d.v_len[vfirst + b];
-                for (uint32_t c = 0; c < ncig; c++)
-                    if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
+                acc_s |= s ? (one_sub << (K1_LANES * r)) : 0u;
             }
-            // the group's slices of the three wave ballots: coverage (a prefix of the lanes), support, low quality
-            const uint32_t bb = b0 + r * K1_LANES;
-            const uint32_t covm = uint32_t(__ballot(cov[r]) >> gshift) & K1_SLICE;
-            const uint64_t supm = (__ballot(s) >> gshift) & uint64_t(K1_SLICE), lqm = (__ballot(q) >> gshift) & uint64_t(K1_SLICE);
-            ncov += __popc(covm);
-#pragma unroll
-            for (int w = 0; w < W; w++)
-                if ((bb >> 6) == uint32_t(w)) { sup[w] |= supm << (bb & 63); lq[w] |= lqm << (bb & 63); }
-            more = more && covm == K1_SLICE;
         }
+        // the four lanes of the group OR their words (quad permutes: lane ^ 1, then lane ^ 2)
+        auto quad_or = [](uint32_t v) {
+            v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+            v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2, 3, 0, 1]
+            return v;
+        };
+        acc_c = quad_or(acc_c); acc_s = quad_or(acc_s); acc_q = quad_or(acc_q);
+        ncov += __popc(acc_c);
+#pragma unroll
+        for (int w = 0; w < W; w++) {   // the batch's 24 bits start at bit b0 of the mask: one or two of its words
+            const uint32_t lo_bit = 64u * uint32_t(w), hi_bit = lo_bit + 64u;
+            if (b0 + K1_BATCH > lo_bit && b0 < hi_bit) {
+                if (b0 >= lo_bit) { sup[w] |= uint64_t(acc_s) << (b0 - lo_bit); lq[w] |= uint64_t(acc_q) << (b0 - lo_bit); }
+                else { sup[w] |= uint64_t(acc_s) >> (lo_bit - b0); lq[w] |= uint64_t(acc_q) >> (lo_bit - b0); }
+            }
+        }
+        more = more && acc_c == (1u << K1_BATCH) - 1u;
     }
     if (valid && sub == 0) {
         d.r_ncov[i] = ncov;
@@ -1126,7 +1140,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
         }
         // (the windows the lane-per-window kernel takes are not this kernel's: plan.cpp lane_window)
         uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT) &&
-                                     !(d.lane_on && k2l_takes(w7 >> 16, w7 & 0xFFFF)));
+                                     !(d.lane_on && k2l_takes(w7 >> 16, w7 & 0xFFFF, d.lane_hash != 0)));
         while (printing) {
             const uint32_t i = uint32_t(__builtin_ctzll(printing));
             printing &= printing - 1;
@@ -1372,7 +1386,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows_multi(DeviceBatch d) {
         }
         // (the windows the lane-per-window kernel takes are not this kernel's: plan.cpp lane_window)
         uint64_t printing = __ballot(lane < nb && ((w5 >> 8) & SF_PRINT) &&
-                                     !(d.lane_on && k2l_takes(w7 >> 16, w7 & 0xFFFF)));
+                                     !(d.lane_on && k2l_takes(w7 >> 16, w7 & 0xFFFF, d.lane_hash != 0)));
         while (printing) {
             const uint32_t i = uint32_t(__builtin_ctzll(printing));
             printing &= printing - 1;
@@ -2818,13 +2832,18 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream
         HIP_CHECK_LAUNCH();
     }
     if (n_wide) {
+        static const bool wide_gather = std::getenv("MP_K2L_WIDE_GATHER") != nullptr;   // experiments: the 7-8 column class without LDS staging
         const uint32_t tiles = (n_wide + 63) / 64, waves = min(32u, 163840u / lds_wide);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
+        if (wide_gather) hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, 0>), dim3(tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
+        else hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
         HIP_CHECK_LAUNCH();
     }
-    if (n_hash) {   // 9..16 columns: the per-lane hash table (same LDS footprint as the 7-8 column form)
-        const uint32_t tiles = (n_hash + 63) / 64, waves = min(32u, 163840u / lds_wide);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_HASH_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_hash, d, d.n_lane_mid, n_hash);
+    if (n_hash) {   // 9..16 columns: the per-lane hash table (16 KB of LDS per wave, as the 7-8 column form)
+        // These windows are a sparse subset (7.5 % at config C): the 64 windows of a tile come from many exons, their candidate ranges do
+        // not overlap, and staging them through LDS took one pass - barrier, reductions, a round of loads - per WINDOW (1.36 ms for
+        // 0.66 M windows). Every lane reads its own window's records straight from memory instead (two loads in flight ahead).
+        const uint32_t tiles = (n_hash + 63) / 64, waves = min(32u, 163840u / 16384u);
+        hipLaunchKernelGGL((k2l_window_lanes<K2L_HASH_COLS, 0>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_hash, d, d.n_lane_mid, n_hash);
         HIP_CHECK_LAUNCH();
     }
 }

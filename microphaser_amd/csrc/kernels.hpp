@@ -37,7 +37,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const WChunk* wchunks;          // work items of k2w_window_rows (<= 64 candidate reads per window, one mask word)
     const WChunk* wchunks_m;        // work items of k2w_window_rows_multi (deeper exons, or two mask words)
     const WChunk* wchunks_d;        // work items of k2w_window_rows_deep (more than 512 candidate reads per window)
-    uint32_t n_wchunks_d, wchunks_d_pad_;
+    uint32_t n_wchunks_d, lane_hash;   // lane_hash: the lane kernel also takes the windows of 9..16 columns (plan.hpp k2l_takes)
     const uint8_t* step_ncols;
     const uint32_t* step_rlo;
     const uint16_t* step_rn;

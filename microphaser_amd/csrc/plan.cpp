@@ -464,9 +464,7 @@ static void validate_segments(const Batch& b) {
 // Lane-per-window replay (plan.hpp WinW): flatten every eligible printing window of the window-parallel exons, small windows
 // (<= K2L_SMALL_COLS columns) first; the wave-per-window kernels keep only the work items that still hold one of their windows.
 static bool lane_window(const Batch& b, uint32_t si) {
-    static const bool no_hash = std::getenv("MP_NO_LANE_HASH") != nullptr;   // (measurements: the 9..16-column windows back to the wave kernels)
-    if (no_hash && b.step_ncols[si] > K2L_MAX_COLS) return false;
-    return b.lane_on && (b.steps[si].flags & SF_PRINT) && k2l_takes(b.step_ncols[si], b.step_rn[si]);
+    return b.lane_on && (b.steps[si].flags & SF_PRINT) && k2l_takes(b.step_ncols[si], b.step_rn[si], b.lane_hash);
 }
 static void route_lane_windows(Batch& b) {
     b.winw.clear();
@@ -557,6 +555,7 @@ static void route_window_parallel(Batch& b) {
     if (b.seg_info.size() != b.segs.size()) throw Error("internal error: segment info out of step");
     const bool enabled = !b.normal && b.mask_words <= 2 && !std::getenv("MP_SEQUENTIAL_REPLAY");
     b.lane_on = enabled && b.mask_words == 1 && !std::getenv("MP_NO_LANE_KERNEL");
+    b.lane_hash = b.lane_on && !std::getenv("MP_NO_LANE_HASH");   // (measurements: the 9..16-column windows back to the wave kernels)
     b.wchunks_m.clear();
     b.wchunks_d.clear();
     b.achunks.clear();

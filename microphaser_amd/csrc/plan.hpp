@@ -89,8 +89,8 @@ constexpr uint32_t K2L_HASH_ROWS = 63;    // ... which must keep a free slot: at
 #if defined(__HIPCC__) || defined(__CUDACC__)
 __host__ __device__
 #endif
-inline bool k2l_takes(uint32_t ncols, uint32_t rn) {
-    return (ncols <= K2L_MAX_COLS && rn <= K2L_MAX_ROWS) || (ncols <= K2L_HASH_COLS && rn <= K2L_HASH_ROWS);
+inline bool k2l_takes(uint32_t ncols, uint32_t rn, bool hash_form) {
+    return (ncols <= K2L_MAX_COLS && rn <= K2L_MAX_ROWS) || (hash_form && ncols <= K2L_HASH_COLS && rn <= K2L_HASH_ROWS);
 }
 struct WinW {
     uint32_t rr_lo;      // RowRec index of the window's first candidate read
