@@ -179,6 +179,13 @@ int mp_batch_results(mp_ctx* ctx, mp_batch* batch, mp_results** out);
 enum { MP_STREAM_FASTA = 1, MP_STREAM_NORMAL_FASTA = 2, MP_STREAM_TSV = 4, MP_STREAM_ALL = 7 };
 int mp_batch_results_select(mp_ctx* ctx, mp_batch* batch, uint32_t streams, mp_results** out);
 void mp_batch_free(mp_batch* batch);
+/* The seam between the device pass and the host consumer, on disk (diagnostics and CPU-only testing of the consumer - the part of
+ * print_haplotypes / phase_gene that stays on the host, :604-880, :1345-1941): mp_batch_results_dump writes the device results of the
+ * last mp_batch_run (per window: depth and haplotype groups; per group: flags; haplotype records) to a file; mp_batch_results_from_dump
+ * consumes such a file with a batch planned from the same inputs and parameters - no GPU needed, a host-only context does - and yields
+ * the same streams mp_batch_results_select gave on the GPU box. */
+int mp_batch_results_dump(mp_ctx* ctx, mp_batch* batch, const char* path);
+int mp_batch_results_from_dump(mp_ctx* ctx, mp_batch* batch, const char* path, uint32_t streams, mp_results** out);
 
 /* Convenience: create + run + results for all genes (what `microphaser somatic` does). */
 int mp_phase_dataset(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, mp_results** out);

@@ -159,6 +159,8 @@ def lib():
     vp, cp, u32, u64, i32, dbl = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_double
     pp = ctypes.POINTER(vp)
     sig = {
+        "mp_batch_results_dump": (i32, [vp, vp, ctypes.c_char_p]),
+        "mp_batch_results_from_dump": (i32, [vp, vp, ctypes.c_char_p, ctypes.c_uint32, pp]),
         "mp_create": (i32, [i32, pp]),
         "mp_destroy": (None, [vp]),
         "mp_last_error": (cp, [vp]),
@@ -226,6 +228,7 @@ C_ABI_SYMBOLS = [
     "mp_filtered_removed_fasta", "mp_filtered_count", "mp_filtered_free",
     "mp_synth_gene_costs", "mp_dataset_from_arrays", "mp_dataset_to_arrays", "mp_gene_batch_free", "mp_dataset_gene_costs",
     "mp_batch_create_genes", "mp_results_gene_offsets", "mp_translate", "mp_peptides_union", "mp_build_reference_buffer", "mp_peptidome_from_buffer",
+    "mp_batch_results_dump", "mp_batch_results_from_dump",
 ]
 
 
@@ -514,6 +517,16 @@ class Batch:
         """The output streams; `streams` (STREAM_FASTA | STREAM_NORMAL_FASTA | STREAM_TSV) leaves the ones nobody reads unwritten."""
         h = ctypes.c_void_p()
         self.ctx._check(lib().mp_batch_results_select(self.ctx._h, self._h, streams, ctypes.byref(h)))
+        return Results(h)
+
+    def dump_results(self, path):
+        """Write the device results of the last run() to a file (the seam between the device pass and the host consumer)."""
+        self.ctx._check(lib().mp_batch_results_dump(self.ctx._h, self._h, path.encode()))
+
+    def results_from_dump(self, path, streams=STREAM_ALL):
+        """Consume a dump_results() file with this batch (planned from the same inputs): works on a host-only context."""
+        h = ctypes.c_void_p()
+        self.ctx._check(lib().mp_batch_results_from_dump(self.ctx._h, self._h, path.encode(), streams, ctypes.byref(h)))
         return Results(h)
 
     def close(self):

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <chrono>
 #include <unistd.h>
 #include <cerrno>
@@ -289,6 +290,78 @@ int mp_batch_results_select(mp_ctx* ctx, mp_batch* batch, uint32_t streams, mp_r
 }
 
 void mp_batch_free(mp_batch* batch) { delete batch; }   // (a context never dereferences its resident / last_run pointers)
+
+namespace {
+struct DumpHeader {
+    char magic[8];   // "MPRES01\0"
+    uint64_t n_wins, n_group_slots, n_recs;
+    uint32_t seq_cap, rec_stride, group_part_log2, rec_part_log2;
+    uint64_t group_prefix[NPART + 1], rec_prefix[NPART + 1];
+};
+}  // namespace
+
+int mp_batch_results_dump(mp_ctx* ctx, mp_batch* batch, const char* path) {
+    return guarded(ctx, [&] {
+        DeviceContext& dev = need_device(ctx);
+        if (!batch->ran) throw Error("mp_batch_results_dump before mp_batch_run");
+        if (ctx->last_run != batch) throw Error("mp_batch_results_dump: another batch has been created or run on this context since this one ran - run it again");
+        HostResults hr;
+        dev.download(hr);
+        DumpHeader h{};
+        std::memcpy(h.magic, "MPRES01", 8);
+        h.n_wins = hr.win_dyn.size(); h.n_group_slots = hr.n_group_slots; h.n_recs = hr.n_recs;
+        h.seq_cap = hr.seq_cap; h.rec_stride = hr.rec_stride; h.group_part_log2 = hr.group_part_log2; h.rec_part_log2 = hr.rec_part_log2;
+        std::memcpy(h.group_prefix, hr.group_prefix, sizeof h.group_prefix);
+        std::memcpy(h.rec_prefix, hr.rec_prefix, sizeof h.rec_prefix);
+        // (K3 stores only the 16-byte pieces of a record that hold sequence bytes; what lies behind them is whatever the arena held:
+        //  zeroed here so that a dump is a function of the inputs alone)
+        for (uint64_t i = 0; i < hr.n_recs; i++) {
+            uint8_t* r = hr.recs.data() + i * hr.rec_stride;
+            HapRecHdr hd;
+            std::memcpy(&hd, r, sizeof hd);
+            const uint32_t sl = (uint32_t(hd.seq_len) + 15u) & ~15u, gl = (uint32_t(hd.germ_len) + 15u) & ~15u;
+            if (sl < hr.seq_cap) std::memset(r + 32 + sl, 0, hr.seq_cap - sl);
+            if (gl < hr.seq_cap) std::memset(r + 32 + hr.seq_cap + gl, 0, hr.seq_cap - gl);
+        }
+        std::ofstream out(path, std::ios::binary);
+        if (!out) throw Error(std::string("cannot write ") + path);
+        out.write(reinterpret_cast<const char*>(&h), sizeof h);
+        out.write(reinterpret_cast<const char*>(hr.win_dyn.data()), std::streamsize(hr.win_dyn.size() * sizeof(WinDyn)));
+        out.write(reinterpret_cast<const char*>(hr.groups.data()), std::streamsize(hr.groups.size() * sizeof(Group)));
+        out.write(reinterpret_cast<const char*>(hr.gsum.data()), std::streamsize(hr.gsum.size() * sizeof(GroupSum)));
+        out.write(reinterpret_cast<const char*>(hr.recs.data()), std::streamsize(hr.recs.size()));
+        if (!out) throw Error(std::string("cannot write ") + path);
+    });
+}
+
+int mp_batch_results_from_dump(mp_ctx* ctx, mp_batch* batch, const char* path, uint32_t streams, mp_results** out) {
+    return guarded(ctx, [&] {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) throw Error(std::string("cannot open ") + path);
+        DumpHeader h{};
+        in.read(reinterpret_cast<char*>(&h), sizeof h);
+        if (!in || std::memcmp(h.magic, "MPRES01", 8) != 0) throw Error(std::string(path) + " is not a results dump");
+        if (h.n_wins != batch->batch.wins.size()) throw Error("results dump does not belong to this batch (window counts differ)");
+        if (h.seq_cap != batch->batch.seq_cap || h.rec_stride != hap_rec_stride(h.seq_cap)) throw Error("results dump does not belong to this batch (record layout differs)");
+        if (h.n_group_slots > (1ull << 34) || h.n_recs > (1ull << 34) || h.group_part_log2 > 40 || h.rec_part_log2 > 40) throw Error("results dump is damaged");
+        HostResults hr;
+        hr.n_group_slots = h.n_group_slots; hr.n_recs = h.n_recs; hr.seq_cap = h.seq_cap; hr.rec_stride = h.rec_stride;
+        hr.group_part_log2 = h.group_part_log2; hr.rec_part_log2 = h.rec_part_log2;
+        std::memcpy(hr.group_prefix, h.group_prefix, sizeof h.group_prefix);
+        std::memcpy(hr.rec_prefix, h.rec_prefix, sizeof h.rec_prefix);
+        if (hr.group_prefix[NPART] != h.n_group_slots || hr.rec_prefix[NPART] != h.n_recs) throw Error("results dump is damaged");
+        hr.win_dyn.resize(h.n_wins); hr.groups.resize(h.n_group_slots); hr.gsum.resize(h.n_group_slots); hr.recs.resize(h.n_recs * h.rec_stride);
+        in.read(reinterpret_cast<char*>(hr.win_dyn.data()), std::streamsize(hr.win_dyn.size() * sizeof(WinDyn)));
+        in.read(reinterpret_cast<char*>(hr.groups.data()), std::streamsize(hr.groups.size() * sizeof(Group)));
+        in.read(reinterpret_cast<char*>(hr.gsum.data()), std::streamsize(hr.gsum.size() * sizeof(GroupSum)));
+        in.read(reinterpret_cast<char*>(hr.recs.data()), std::streamsize(hr.recs.size()));
+        if (!in) throw Error("results dump is truncated");
+        std::unique_ptr<mp_results> r(new mp_results());
+        if (batch->batch.normal) consume_batch_normal(batch->batch, hr, r->out, streams);
+        else consume_batch(batch->batch, hr, r->out, streams);
+        *out = r.release();
+    });
+}
 
 int mp_phase_dataset(mp_ctx* ctx, const mp_dataset* ds, int mode, uint64_t window_len, mp_results** out) {
     mp_batch* b = nullptr;
