@@ -319,7 +319,8 @@ int mp_batch_results_dump(mp_ctx* ctx, mp_batch* batch, const char* path) {
             uint8_t* r = hr.recs.data() + i * hr.rec_stride;
             HapRecHdr hd;
             std::memcpy(&hd, r, sizeof hd);
-            const uint32_t sl = (uint32_t(hd.seq_len) + 15u) & ~15u, gl = (uint32_t(hd.germ_len) + 15u) & ~15u;
+            // (`normal` records keep the somatic subset of the variant profile in the first 8 bytes of the germline area)
+            const uint32_t sl = (uint32_t(hd.seq_len) + 15u) & ~15u, gl = batch->batch.normal ? 16u : (uint32_t(hd.germ_len) + 15u) & ~15u;
             if (sl < hr.seq_cap) std::memset(r + 32 + sl, 0, hr.seq_cap - sl);
             if (gl < hr.seq_cap) std::memset(r + 32 + hr.seq_cap + gl, 0, hr.seq_cap - gl);
         }

@@ -56,7 +56,7 @@ void* DeviceContext::dalloc(size_t bytes) {
 template <class V>
 typename V::value_type* DeviceContext::up(const V& v) {
     using T = typename V::value_type;
-    T* p = static_cast<T*>(dalloc(v.size() * sizeof(T) + 64));  // +64: kernels stage pools with 16-byte loads
+    T* p = static_cast<T*>(dalloc(v.size() * sizeof(T) + 256));  // +256: kernels stage pools with 16-byte loads at clamped-late addresses (K1: up to 128 bytes of payload / 32 variants past a start)
     allocs_.push_back(p);
     // (copied by upload_impl once every array has its device memory: one pipelined run through the pinned ring)
     if (!v.empty()) pending_up_.push_back(XferSeg{const_cast<char*>(reinterpret_cast<const char*>(v.data())), reinterpret_cast<char*>(p), v.size() * sizeof(T)});

@@ -26,7 +26,7 @@ namespace mp {
 
 // ====================================================================== K1
 // rust-htslib CigarStringView::read_pos(ref_pos, false, false), see model.hpp cigar_read_pos.
-__device__ __forceinline__ int cigar_read_pos_dev(const uint32_t* cig, uint32_t ncig, uint32_t read_start, uint32_t ref_pos) {
+__device__ __attribute__((noinline)) int cigar_read_pos_dev(const uint32_t* cig, uint32_t ncig, uint32_t read_start, uint32_t ref_pos) {
     int64_t rpos = read_start;
     int64_t qpos = 0;
     uint32_t j = 0;
@@ -62,11 +62,26 @@ __device__ __forceinline__ uint8_t decode_base4(uint32_t code) {  // BAM 4-bit c
     return uint8_t(((code & 8) ? hi : lo) >> (8 * (code & 7)));
 }
 
-constexpr uint32_t K1_LANES = 4;    // lanes per read (measured at config C: 1 lane 1.40 ms, 2: 1.07, 4: 1.10, 8: 1.31, 16: 1.71; with the
-                                    // batched rounds below - lanes x rounds = 2 x 12: 1.00 ms, 4 x 6: 0.75, 8 x 3: 0.88)
+constexpr uint32_t K1_LANES = 4;    // lanes per read (measured at config C: 1 lane 1.40 ms, 2: 1.07, 4: 1.10, 8: 1.31, 16: 1.71)
 static_assert(K1_LANES == 4, "the group's lanes combine their bits with quad permutes");
+constexpr uint32_t K1_PAY_DW = 32;      // dwords of a read's payload (low-quality bitmap + packed bases) staged in LDS: reads of up to ~200 nt whole
+constexpr uint32_t K1_PAY_STRIDE = 33;  // odd dword stride: the groups' slots fall into different banks
+struct __attribute__((packed, aligned(4))) K1Quad { uint32_t x, y, z, w; };   // four consecutive dwords at a dword-aligned address (one 16-byte load)
+
+// K1 is bound by the NUMBER of scattered memory instructions, not by bytes or arithmetic (a slimmer instruction stream did not move
+// its time): the round-based form issued 7 + 12 + 12 narrow gathers per wave in three dependent levels (read fields -> variant positions
+// -> base / quality). Now a group of four lanes (one read) fetches
+//   - the read's payload - low-quality bitmap and packed bases, 68 bytes for a 101-nt read - with two 16-byte loads per lane into an LDS
+//     slot (every base / quality look-up is then an LDS read), and
+//   - its next 32 variants - positions and info words - with four 16-byte loads per lane (lane k of the group takes variants 4 k .. 4 k + 3
+//     and 16 + 4 k .. 16 + 4 k + 3),
+// both straight after the read's own fields: two dependent levels, 13 wide loads per wave. A batch of 32 variants is evaluated branch-free
+// for the common case (SNV under a single-M CIGAR); each lane collects coverage / support / low-quality bits of its eight variants in
+// three words at the variants' own bit positions, the rare other cases (indels, SNVs under a CIGAR with clips / indels) are marked and
+// settled in a loop of their own, and the group's four lanes OR their words with two quad permutes each: the batch's 32 mask bits.
 template <int W>
 __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
+    __shared__ uint32_t pay[(256 / K1_LANES) * K1_PAY_STRIDE];
     const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
     const uint32_t sub = threadIdx.x & (K1_LANES - 1);             // lane within the read's group
     const uint64_t i_raw = t / K1_LANES;
@@ -77,90 +92,89 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
     const uint32_t rpos = d.r_pos[i], rend = d.r_end[i], lseq = d.r_lseq[i], ncig = d.r_ncig[i];
     const uint32_t* cig = d.cigar_pool + d.r_cigoff[i];
     const uint32_t* lowq = reinterpret_cast<const uint32_t*>(d.seq_pool + d.r_seqoff[i]);   // bit k: base quality at read offset k below 10
-    const uint8_t* seq4 = reinterpret_cast<const uint8_t*>(lowq + ((lseq + 31) >> 5));
+    const uint32_t nlq = (lseq + 31) >> 5;                                                  // dwords of the bitmap; the packed bases follow
+    const uint8_t* seq4 = reinterpret_cast<const uint8_t*>(lowq + nlq);
     // a variant can be a (stale) column of a window the read encloses without lying inside the read's aligned span;
     // bad_quality still indexes the qualities by reference offset (:82-88): cover max(end, start + l_seq)
     const uint32_t cover_end = max(rend, rpos + lseq);
     const uint32_t maxn = min(rv.y, 64u * W);
+    // ---- second level, all issued together: the payload (-> LDS), the first CIGAR operation, the first batch of variants
+    uint32_t* const slot = pay + (threadIdx.x / K1_LANES) * K1_PAY_STRIDE;
+    const K1Quad pa = reinterpret_cast<const K1Quad*>(lowq)[sub], pb = reinterpret_cast<const K1Quad*>(lowq)[4 + sub];   // (the pools are padded)
     const uint32_t c0 = ncig > 0 ? cig[0] : 0;
+    auto load_variants = [&](uint32_t b0, K1Quad (&vp)[2], K1Quad (&vi)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t at = vfirst + b0 + 16u * uint32_t(h) + 4u * sub;
+            vp[h] = *reinterpret_cast<const K1Quad*>(d.v_pos + at);
+            vi[h] = *reinterpret_cast<const K1Quad*>(d.v_info + at);
+        }
+    };
+    K1Quad vp[2], vi[2];
+    load_variants(0, vp, vi);
+    slot[4 * sub] = pa.x; slot[4 * sub + 1] = pa.y; slot[4 * sub + 2] = pa.z; slot[4 * sub + 3] = pa.w;
+    slot[16 + 4 * sub] = pb.x; slot[16 + 4 * sub + 1] = pb.y; slot[16 + 4 * sub + 2] = pb.z; slot[16 + 4 * sub + 3] = pb.w;
+    __syncthreads();   // (a group's four lanes sit in one wave; the barrier only orders the LDS writes before the reads)
     const bool simple = ncig == 1 && (c0 & 0xF) == 0;  // a single M op: read_pos(p) = p - start
+    const uint32_t len0 = c0 >> 4;
+    // (a wave that holds a read whose payload does not fit the slot - longer than ~200 nt - reads the payloads from memory instead)
+    const bool any_long = __ballot(nlq + ((lseq + 7) >> 3) > K1_PAY_DW) != 0;
     uint64_t sup[W], lq[W];
 #pragma unroll
     for (int w = 0; w < W; w++) { sup[w] = 0; lq[w] = 0; }
     uint32_t ncov = 0;
     bool more = true;   // the group's run may continue (every variant of the previous batch was covered)
-    // The kernel is bound by dependent loads and by instruction issue, not by bytes: (variant position -> base, quality) is a two-level
-    // chain per variant. K1_ROUNDS rounds of K1_LANES variants are therefore taken together - all their positions are loaded first, then all
-    // their bases and qualities, then everything is evaluated - so a typical read (about 20 variants in its span) pays the chain once, not
-    // five times. The evaluation of a batch is branch-free for the common case (SNV under a single-M CIGAR): every lane collects its
-    // coverage / support / low-quality bits of the batch in three 24-bit words (bit 4 r + lane-in-group), the rare other cases (indels,
-    // SNVs under a CIGAR with clips / indels) are marked and settled in a loop of their own, and the group's four lanes OR their words
-    // together with two DPP moves each - no ballots, no 64-bit shifts per round (27 -> ~20 vector instructions per read and round).
-    constexpr uint32_t K1_ROUNDS = 6;
-    constexpr uint32_t K1_BATCH = K1_LANES * K1_ROUNDS;
-    const uint32_t one_sub = 1u << sub;
-    const uint32_t len0 = c0 >> 4;
-    for (uint32_t b0 = 0; b0 < 64u * W; b0 += K1_BATCH) {
+    const uint32_t last_q = lseq ? lseq - 1 : 0;
+    auto run_batches = [&](auto from_memory) {   // from_memory: std::true_type for a wave with a read too long for its LDS slot
+    for (uint32_t b0 = 0; b0 < 64u * W; b0 += 32) {
         if (__ballot(more) == 0) break;   // wave-uniform
-        uint32_t vpos[K1_ROUNDS], info[K1_ROUNDS];
-        bool in[K1_ROUNDS];
-        // (the loads are unconditional, at clamped addresses - the pools are padded -, and their results selected afterwards: a load
-        //  under a branch makes the compiler drain the memory counter at the join, which would serialise the rounds again)
-        const uint32_t last_b = maxn ? maxn - 1 : 0;
-#pragma unroll
-        for (uint32_t r = 0; r < K1_ROUNDS; r++) {
-            const uint32_t b = b0 + r * K1_LANES + sub;
-            in[r] = more && b < maxn;
-            const uint32_t at = vfirst + min(b, last_b);
-            vpos[r] = d.v_pos[at];
-            info[r] = d.v_info[at];
-        }
-        const uint32_t last_q = lseq ? lseq - 1 : 0;
-        uint32_t ql[K1_ROUNDS];
-        uint8_t sl[K1_ROUNDS];
-#pragma unroll
-        for (uint32_t r = 0; r < K1_ROUNDS; r++) {   // second level: qualities and (single-M CIGARs: the common case) bases - all issued first
-            if (!in[r]) { vpos[r] = 0xFFFFFFFFu; info[r] = 0; }
-            const uint32_t relc = min(vpos[r] - rpos, last_q);
-            ql[r] = lowq[relc >> 5];
-            sl[r] = seq4[relc >> 1];
-        }
+        if (b0) load_variants(b0, vp, vi);
+        const uint32_t vpos[8] = {vp[0].x, vp[0].y, vp[0].z, vp[0].w, vp[1].x, vp[1].y, vp[1].z, vp[1].w};
+        const uint32_t info[8] = {vi[0].x, vi[0].y, vi[0].z, vi[0].w, vi[1].x, vi[1].y, vi[1].z, vi[1].w};
         uint32_t acc_c = 0, acc_s = 0, acc_q = 0, slow = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < K1_ROUNDS; r++) {
-            const bool cov = in[r] && vpos[r] < cover_end;
-            const bool snv = cov && (info[r] & VI_KIND_MASK) == 0;
-            const uint32_t rel = vpos[r] - rpos;
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t tb = (k < 4 ? 0u : 16u) + 4u * sub + (k & 3u);   // the variant's place in the batch = its bit in the three words
+            const bool in = more && b0 + tb < maxn;
+            const bool cov = in && vpos[k] < cover_end;
+            const bool snv = cov && (info[k] & VI_KIND_MASK) == 0;
+            const uint32_t rel = vpos[k] - rpos;
+            const uint32_t relc = min(rel, last_q);
+            uint32_t qw, sw;
+            if constexpr (!decltype(from_memory)::value) { qw = slot[relc >> 5]; sw = slot[nlq + (relc >> 3)]; }
+            else { qw = lowq[relc >> 5]; sw = lowq[nlq + (relc >> 3)]; }
             // the reference indexes the qualities by reference offset (:82-88); `normal` has no quality gate (src/normal_microphasing.rs:43-52)
-            const bool q = snv && !d.normal && rel < lseq && ((ql[r] >> (rel & 31u)) & 1u);
+            const bool q = snv && !d.normal && rel < lseq && ((qw >> (rel & 31u)) & 1u);
             const bool fast = snv && simple && rel < len0 && rel < lseq;   // a single M op: read_pos(p) = p - start
-            const uint32_t code = (rel & 1) ? (sl[r] & 0xFu) : (uint32_t(sl[r]) >> 4);
-            const bool s = fast && !q && decode_base4(code) == uint8_t(info[r] >> VI_ALT_SHIFT);   // SNV (:97-112, :80-92)
-            const uint32_t bit = one_sub << (K1_LANES * r);
+            const uint32_t byte = (sw >> (8u * ((relc >> 1) & 3u))) & 0xFFu;
+            const uint32_t code = (rel & 1) ? (byte & 0xFu) : (byte >> 4);
+            const bool sp = fast && !q && decode_base4(code) == uint8_t(info[k] >> VI_ALT_SHIFT);   // SNV (:97-112, :80-92)
+            const uint32_t bit = 1u << tb;
             acc_c |= cov ? bit : 0u;
-            acc_s |= s ? bit : 0u;
+            acc_s |= sp ? bit : 0u;
             acc_q |= q ? bit : 0u;
-            slow |= (cov && ((snv && !simple && !q) || !snv)) ? (1u << r) : 0u;
+            slow |= (cov && ((snv && !simple && !q) || !snv)) ? (1u << k) : 0u;
         }
         if (__ballot(slow != 0)) {   // insertions / deletions, SNVs under a CIGAR with more than one M: rare, settled apart
 #pragma unroll
-            for (uint32_t r = 0; r < K1_ROUNDS; r++) {
-                if (!((slow >> r) & 1u)) continue;
-                bool s = false;
-                if ((info[r] & VI_KIND_MASK) == 0) {
-                    const int p = cigar_read_pos_dev(cig, ncig, rpos, vpos[r]);
+            for (uint32_t k = 0; k < 8; k++) {
+                if (!((slow >> k) & 1u)) continue;
+                const uint32_t tb = (k < 4 ? 0u : 16u) + 4u * sub + (k & 3u);
+                bool sp = false;
+                if ((info[k] & VI_KIND_MASK) == 0) {
+                    const int p = cigar_read_pos_dev(cig, ncig, rpos, vpos[k]);
                     if (p >= 0 && uint32_t(p) < lseq) {
                         const uint8_t byte = seq4[p >> 1];
                         const uint32_t code = (p & 1) ? (byte & 0xFu) : (uint32_t(byte) >> 4);
-                        s = decode_base4(code) == uint8_t(info[r] >> VI_ALT_SHIFT);
+                        sp = decode_base4(code) == uint8_t(info[k] >> VI_ALT_SHIFT);
                     }
                 } else {  // insertion / deletion: any I / D op of exactly that length (:113-137)
-                    const uint32_t want = (info[r] & VI_KIND_MASK) == 1 ? 1u : 2u;
-                    const uint32_t vlen = d.v_len[vfirst + b0 + r * K1_LANES + sub];
+                    const uint32_t want = (info[k] & VI_KIND_MASK) == 1 ? 1u : 2u;
+                    const uint32_t vlen = d.v_len[vfirst + b0 + tb];
                     for (uint32_t c = 0; c < ncig; c++)
-                        if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { s = true; break; }
+                        if ((cig[c] & 0xF) == want && (cig[c] >> 4) == vlen) { sp = true; break; }
                 }
-                acc_s |= s ? (one_sub << (K1_LANES * r)) : 0u;
+                acc_s |= sp ? (1u << tb) : 0u;
             }
         }
         // the four lanes of the group OR their words (quad permutes: lane ^ 1, then lane ^ 2)
@@ -172,15 +186,13 @@ __global__ __launch_bounds__(256) void k1_pileup_bits(DeviceBatch d) {
         acc_c = quad_or(acc_c); acc_s = quad_or(acc_s); acc_q = quad_or(acc_q);
         ncov += __popc(acc_c);
 #pragma unroll
-        for (int w = 0; w < W; w++) {   // the batch's 24 bits start at bit b0 of the mask: one or two of its words
-            const uint32_t lo_bit = 64u * uint32_t(w), hi_bit = lo_bit + 64u;
-            if (b0 + K1_BATCH > lo_bit && b0 < hi_bit) {
-                if (b0 >= lo_bit) { sup[w] |= uint64_t(acc_s) << (b0 - lo_bit); lq[w] |= uint64_t(acc_q) << (b0 - lo_bit); }
-                else { sup[w] |= uint64_t(acc_s) >> (lo_bit - b0); lq[w] |= uint64_t(acc_q) >> (lo_bit - b0); }
-            }
-        }
-        more = more && acc_c == (1u << K1_BATCH) - 1u;
+        for (int w = 0; w < W; w++)
+            if ((b0 >> 6) == uint32_t(w)) { sup[w] |= uint64_t(acc_s) << (b0 & 63u); lq[w] |= uint64_t(acc_q) << (b0 & 63u); }
+        more = more && acc_c == 0xFFFFFFFFu;
     }
+    };
+    if (!any_long) run_batches(std::false_type{});
+    else run_batches(std::true_type{});
     if (valid && sub == 0) {
         d.r_ncov[i] = ncov;
 #pragma unroll
@@ -2832,7 +2844,10 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream
         HIP_CHECK_LAUNCH();
     }
     if (n_wide) {
-        static const bool wide_gather = std::getenv("MP_K2L_WIDE_GATHER") != nullptr;   // experiments: the 7-8 column class without LDS staging
+        // The windows of 7-8 columns are a sparse subset too (a fifth of the lane kernel's windows): their tiles span several exons and
+        // need several staging passes; reading the records straight from memory is faster for them (window phase 1.15 -> 1.05 ms at
+        // config C, same box); MP_K2L_WIDE_STAGED=1 brings the staged form back for comparisons.
+        static const bool wide_gather = std::getenv("MP_K2L_WIDE_STAGED") == nullptr;
         const uint32_t tiles = (n_wide + 63) / 64, waves = min(32u, 163840u / lds_wide);
         if (wide_gather) hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, 0>), dim3(tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
         else hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);

@@ -14,10 +14,19 @@ from conftest import GOLDEN, ORACLE_CLI
 CASES = json.load(open(os.path.join(GOLDEN, "consumer", "cases.json")))
 
 
+def unpack(name, tmp_path):
+    """The committed dumps are gzip-compressed (records are mostly padding): unpack one into the test's directory."""
+    import gzip
+    path = str(tmp_path / (name + ".bin"))
+    with gzip.open(os.path.join(GOLDEN, "consumer", name + ".bin.gz"), "rb") as src, open(path, "wb") as dst:
+        dst.write(src.read())
+    return path
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_consumer_on_recorded_device_results_gives_the_oracle_output(built, tmp_path, case):
     import microphaser_amd as m
-    dump = os.path.join(GOLDEN, "consumer", case["name"] + ".bin")
+    dump = unpack(case["name"], tmp_path)
     prefix = str(tmp_path / "o")
     cmd = [ORACLE_CLI, "synth", "--seed", str(case["seed"]), "--transcripts", str(case["transcripts"]), "--depth", str(case["depth"]),
            "--spacing", str(case["spacing"]), "--indel-rate", str(case["indel_rate"]), "--multiallelic-rate", str(case["multiallelic_rate"]),
@@ -48,7 +57,7 @@ def test_a_dump_of_another_batch_is_refused(built, tmp_path):
     ctx = m.Context(-1)
     b = ctx.synth(5, 4).batch()
     with pytest.raises(m.MicrophaserError):
-        b.results_from_dump(os.path.join(GOLDEN, "consumer", CASES[0]["name"] + ".bin"))
+        b.results_from_dump(unpack(CASES[0]["name"], tmp_path))
     junk = tmp_path / "junk.bin"
     junk.write_bytes(b"not a dump")
     with pytest.raises(m.MicrophaserError):

@@ -12,6 +12,6 @@ import sys; sys.path.insert(0, '.')
 import microphaser_amd as m
 m.Context(-1).synth(2020, $N, 30.0, 5.4).write('/tmp/cb')
 "
-MP_THREADS=1 MP_DEBUG=1 timeout -k 10 300 $BIN somatic /tmp/cb.bam --variants /tmp/cb.vcf --ref /tmp/cb.fa --tsv /tmp/o.tsv --normal-output /tmp/o.n.fa < /tmp/cb.gtf 2> /tmp/err.log > /tmp/o.fa
+MP_CLEAN_EXIT=1 MP_THREADS=1 MP_DEBUG=1 timeout -k 10 300 $BIN somatic /tmp/cb.bam --variants /tmp/cb.vcf --ref /tmp/cb.fa --tsv /tmp/o.tsv --normal-output /tmp/o.n.fa < /tmp/cb.gtf 2> /tmp/err.log > /tmp/o.fa
 grep -E "^\[prof\]|batch_results|batch_create|consume" /tmp/err.log | cut -c1-140
 md5sum /tmp/o.tsv /tmp/o.fa /tmp/o.n.fa

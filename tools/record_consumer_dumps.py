@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Record device-result dumps for the CPU-only consumer tests (run on the GPU box):
 
-  python tools/record_consumer_dumps.py        -> gpurun_out/consumer/<case>.bin (+ cases.json)
+  python tools/record_consumer_dumps.py        -> gpurun_out/consumer/<case>.bin   (commit them as tests/golden/consumer/<case>.bin.gz: gzip -9)
 
 For each small synthetic exome of tests/golden/consumer/cases.json the hot path runs on the GPU and the device results - the seam
 between the device pass and the host consumer - are written with mp_batch_results_dump, after checking that the GPU run's streams
