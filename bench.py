@@ -192,8 +192,15 @@ def main():
         dist.all_reduce(wsum, op=dist.ReduceOp.SUM)
         elapsed_max = float(tmax.item())
         total_windows = float(wsum.item())
+        # every rank's own time and window count, as the process group reports them (a scaling curve is only as good as its slowest rank)
+        mine = torch.tensor([elapsed / max(1, args.steps) * 1e3, float(windows)], dtype=torch.float64, device=red_dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        rank_info = {"world_size_reported_by_process_group": dist.get_world_size(), "backend": dist.get_backend(),
+                     "pass_ms_per_rank": [float(x[0].item()) for x in per_rank], "windows_per_rank": [int(x[1].item()) for x in per_rank]}
     else:
         elapsed_max, total_windows = elapsed, float(windows)
+        rank_info = None
 
     if rank == 0:
         steps = max(1, args.steps)
@@ -309,6 +316,7 @@ def main():
         }
         if world > 1:
             out["partition"] = {"rank0_cost_share": my_cost / total_cost, "ideal_share": 1.0 / world}
+            out["ranks"] = rank_info
         if rehearse:
             out["rehearsal"] = "all ranks on one GPU, gloo reductions: functional check of the N-rank path, not a measurement"
         if world == 1 and args.cpu_sample > 0:
