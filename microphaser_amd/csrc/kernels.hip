@@ -1042,15 +1042,20 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         uint64_t rslot = rpart_lo + rbase + ((scan >> 16) - nneed);
         if (valid) {
             const uint32_t goff = uint32_t(gslot);
-            auto emit = [&](const uint32_t key, const uint32_t cnt) {
+            auto emit = [&](const uint32_t key, const uint32_t cnt) __attribute__((always_inline)) {   // (inlined: the slot cursors it advances stay in registers)
                 const bool need = need_all || (uint64_t(key) & som_mask) != 0;
                 if (can_write) {
                     const bool settled = trivial && !need;   // what K3 would find: valid, no stop, mutant == germline, no record
                     Group G; G.hap = key; G.count = cnt; G.aux = settled ? GROUP_SETTLED : 0u;
                     d.groups[gslot] = G;
                     // the rest is for K3 only: one item (k3_enqueue's layout) in list A or B
-                    if (need) d.k3_items[la_slot++] = make_uint4(uint32_t(gslot), win, rec_ok ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
-                    else if (!settled) d.k3_items[lb_slot--] = make_uint4(uint32_t(gslot), win, 0xFFFFFFFFu, 0u);
+                    // (one store at a selected address and plain cursor arithmetic: with a store per branch the compiler kept the two cursors
+                    //  in a dynamically indexed scratch array - 0.3 GB of private-memory traffic per pass)
+                    const bool to_b = !need && !settled;
+                    const uint64_t at = need ? la_slot : lb_slot;
+                    if (need || to_b) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                    la_slot += need ? 1u : 0u;
+                    lb_slot -= to_b ? 1u : 0u;
                 }
                 gslot++;
                 rslot += need ? 1u : 0u;
