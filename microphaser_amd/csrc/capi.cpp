@@ -231,7 +231,11 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 st->n_steps_seq = seq_steps; st->n_steps_w = w_steps; st->n_adm = b.n_adm;
                 // K2a writes an AdmEntry per (exon, read) and, for the lane-per-window kernel, a RowRec (16 + 8 bytes)
                 const uint64_t rowrec = b.lane_on ? sizeof(RowRecA) + 8 : 0;
-                st->bytes_k2a = b.n_adm * (read_bytes + sizeof(AdmEntry) + rowrec) + b.exons_w.size() * sizeof(ExonW);
+                if (!batch->adm_known) {   // (K2a writes an exon's AdmEntries / RowRecs only if a wave / lane kernel reads them)
+                    for (const ExonW& e : b.exons_w) { if (e.consumers & EW_WAVE) batch->adm_wave += e.n_reads; if (e.consumers & EW_LANE) batch->adm_lane += e.n_reads; }
+                    batch->adm_known = true;
+                }
+                st->bytes_k2a = b.n_adm * read_bytes + batch->adm_wave * sizeof(AdmEntry) + batch->adm_lane * rowrec + b.exons_w.size() * sizeof(ExonW);
                 // window rows: the lane kernel reads a WinW + window index per window and every RowRec once; the wave-per-window kernels
                 // read the steps of their work items and their share of the read fields / admission entries
                 uint64_t wave_steps = 0;
@@ -244,7 +248,7 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
                 st->k2l_ms = t.k2l_ms; st->n_windows_lane = lane_wins; st->n_windows_wave = wave_wins;
                 // the lane kernel writes a Group per group; window / record index / K3-list entry only for the groups it hands on to K3
                 const uint64_t listed_l = t.n_k3 > (t.n_groups - groups_l) ? t.n_k3 - (t.n_groups - groups_l) : 0;
-                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + b.n_adm * rowrec + groups_l * sizeof(Group) + listed_l * 16;
+                st->bytes_k2l = lane_wins * (sizeof(WinW) + 4 + sizeof(WinDyn)) + batch->adm_lane * rowrec + groups_l * sizeof(Group) + listed_l * 16;
                 st->bytes_k2w = wave_steps * (sizeof(Step) + 7) + uint64_t(double(b.n_adm) * wave_share) * (read_bytes + sizeof(AdmEntry)) +
                                 wave_wins * sizeof(WinDyn) + (groups_w - groups_l) * (sizeof(Group) + 16);
                 st->bytes_k2seq = seq_steps * sizeof(Step) + (b.steps.empty() ? 0 : uint64_t(double(b.r_pos.size()) * double(seq_steps) / double(b.steps.size()))) * read_bytes +

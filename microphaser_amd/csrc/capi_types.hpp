@@ -31,6 +31,8 @@ struct mp_batch {
     uint64_t sum_wlen = 0, sum_cols = 0;  // cached for the byte accounting
     uint64_t w_steps = 0, w_wins = 0;     // steps / printing steps replayed window-parallel
     bool w_wins_known = false;
+    uint64_t adm_wave = 0, adm_lane = 0;  // (exon, read) entries K2a writes an AdmEntry / a RowRec for
+    bool adm_known = false;
 };
 struct mp_results {
     PhasedStreams out;   // normal mode: fasta / tsv / n_windows are filled, normal_fasta stays empty

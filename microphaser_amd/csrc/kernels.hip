@@ -798,9 +798,9 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
                 if (try_step(e.step_off + t)) break;
             }
         }
-        d.adm[uint64_t(e.adm_off) + k] = out;
+        if (e.consumers & EW_WAVE) d.adm[uint64_t(e.adm_off) + k] = out;   // (only where a wave-per-window kernel will read it: 145 windows at config C)
         if constexpr (W == 1) {
-            if (d.lane_on) {   // the same facts flattened for the lane-per-window kernel (plan.hpp RowRecA)
+            if (d.lane_on && (e.consumers & EW_LANE)) {   // the same facts flattened for the lane-per-window kernel (plan.hpp RowRecA)
                 uint32_t bad_from = 0xFFFFFFFFu;
                 if (out.ord != 0xFFFFFFFFu) {
                     const uint64_t dm = dirty[0];

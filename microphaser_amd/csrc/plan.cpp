@@ -620,13 +620,17 @@ static void route_window_parallel(Batch& b) {
         if (multi && !deep) P.max_rn_multi = std::max(P.max_rn_multi, si.max_rn);
         // deep windows cost ~RPL x more each and there are few of them: smaller work items keep the chip full
         const uint32_t chunk = deep ? 6 : multi ? CHUNK_STEPS / 4 : CHUNK_STEPS;
+        uint32_t consumers = 0;
         for (uint32_t s0 = 0; s0 < g.n_steps; s0 += chunk) {
             const uint32_t n = std::min(chunk, g.n_steps - s0);
             bool mine = !b.lane_on;   // a printing window the lane kernel does not take
-            for (uint32_t k = 0; k < n && !mine; k++)
-                mine = (b.steps[g.step_off + s0 + k].flags & SF_PRINT) && !lane_window(b, g.step_off + s0 + k);
-            if (mine) (deep ? P.wchunks_d : multi ? P.wchunks_m : P.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0});
+            for (uint32_t k = 0; k < n; k++) {
+                if (!(b.steps[g.step_off + s0 + k].flags & SF_PRINT)) continue;
+                if (lane_window(b, g.step_off + s0 + k)) consumers |= EW_LANE; else mine = true;
+            }
+            if (mine) { (deep ? P.wchunks_d : multi ? P.wchunks_m : P.wchunks).push_back(WChunk{ei, g.step_off + s0, n, 0}); consumers |= EW_WAVE; }
         }
+        P.exons[ei].consumers = consumers;
         }
       } catch (const std::exception& e) { P.error = e.what(); if (P.error.empty()) P.error = "error"; }
     };

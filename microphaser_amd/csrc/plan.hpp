@@ -66,7 +66,10 @@ struct ExonW {
     uint32_t sso0, sso1;            // splice_side_offset of the exon's first and second step
     uint32_t unit_steps;            // steps [0, unit_steps) move by exactly one nt each: '+' sso(t) = sso1 + (t - 1) for t >= 1, '-' sso(t) = sso0 - t -
                                     // K2a then finds a read's first candidate step by arithmetic alone, without looking at the steps
+    uint32_t consumers;             // EW_*: which kernels read K2a's outputs for this exon (it writes only what somebody reads)
 };
+enum : uint32_t { EW_WAVE = 1,      // a wave-per-window kernel has a window here: AdmEntry
+                  EW_LANE = 2 };    // the lane-per-window kernel has one: RowRec
 struct WChunk {                     // K2w work item: a run of steps of one ExonW
     uint32_t exon, step_first, n_steps, pad;
 };
