@@ -2284,8 +2284,9 @@ __device__ __forceinline__ uint64_t haplotype_id60(const DeviceBatch& d, bool ac
 // slot when the id is hashed, so the record is written once, complete, and never read again on the device (a separate id kernel re-read
 // 0.5 GB of records per config C pass and ran at 9 % of the HBM roofline; here its ALU work overlaps the other waves' gathers).
 // !LIST_A: list B - flags only, no record, no id.
-template <int SEQ_CAP, bool LIST_A>
-__global__ __launch_bounds__(K3_THREADS) void k3_window_seq(DeviceBatch d) {
+template <int SEQ_CAP, bool LIST_A, int THREADS>   // THREADS: workgroup size (list A: the waves of a workgroup share the decimal-text table)
+__global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
+    constexpr int K3_THREADS = THREADS;
     // the lane's LDS slot: ref | seq | germ while the sequences are built; list A re-uses it as the SHA-1 message buffer afterwards (the
     // sequences are in registers by then), so it is at least K3B_BUF_WORDS + 1 dwords there (odd stride: bank-conflict free)
     constexpr int K3_SLOT_DW = LIST_A ? ((K3Cfg<SEQ_CAP>::SLOT_DW > int(K3B_BUF_WORDS + 1) ? K3Cfg<SEQ_CAP>::SLOT_DW : int(K3B_BUF_WORDS + 1)) | 1) : K3Cfg<SEQ_CAP>::SLOT_DW;
@@ -2883,13 +2884,20 @@ static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t
     // the grid covers the host's upper bound of the list lengths (surplus waves find nothing and leave; were the bound too low, the
     // waves walk the rest in turn - slower, still complete)
     // one grid row per allocator list; the lists fill evenly (allocator = workgroup index & 63 in the K2 kernels), a quarter more for the spread
-    const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + K3_THREADS;
-    dim3 grid(uint32_t(std::min<uint64_t>((per_list + K3_THREADS - 1) / K3_THREADS, 0x7FFFFFFFull)), NPART), block(K3_THREADS);
+    // one wave per workgroup for both lists. (List A in 256-thread workgroups - four waves sharing one 2 KB decimal-text table, 12
+    // instead of 11 waves per CU - measured 1.55 against 1.46 ms: the four waves of a workgroup start together and stay in step, gather
+    // phase on gather phase. MP_K3A_THREADS=256 brings that form back for comparisons.)
+    static const int a_threads = [] { const char* e = std::getenv("MP_K3A_THREADS"); return e && std::atoi(e) == 256 ? 256 : 64; }();
+    const int T = LIST_A && d.seq_cap <= 48 ? a_threads : K3_THREADS;
+    const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + uint64_t(T);
+    dim3 grid(uint32_t(std::min<uint64_t>((per_list + T - 1) / T, 0x7FFFFFFFull)), NPART), block(T);
     switch (d.seq_cap) {
-        case 32: hipLaunchKernelGGL((k3_window_seq<32, LIST_A>), grid, block, 0, stream, d); break;
-        case 48: hipLaunchKernelGGL((k3_window_seq<48, LIST_A>), grid, block, 0, stream, d); break;
-        case 112: hipLaunchKernelGGL((k3_window_seq<112, LIST_A>), grid, block, 0, stream, d); break;
-        case 240: hipLaunchKernelGGL((k3_window_seq<240, LIST_A>), grid, block, 0, stream, d); break;
+        case 32: if (T == 256) hipLaunchKernelGGL((k3_window_seq<32, LIST_A, 256>), grid, block, 0, stream, d);
+                 else hipLaunchKernelGGL((k3_window_seq<32, LIST_A, 64>), grid, block, 0, stream, d); break;
+        case 48: if (T == 256) hipLaunchKernelGGL((k3_window_seq<48, LIST_A, 256>), grid, block, 0, stream, d);
+                 else hipLaunchKernelGGL((k3_window_seq<48, LIST_A, 64>), grid, block, 0, stream, d); break;
+        case 112: hipLaunchKernelGGL((k3_window_seq<112, LIST_A, 64>), grid, block, 0, stream, d); break;
+        case 240: hipLaunchKernelGGL((k3_window_seq<240, LIST_A, 64>), grid, block, 0, stream, d); break;
         default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
     HIP_CHECK_LAUNCH();
