@@ -151,7 +151,7 @@ typedef struct mp_run_stats {
      * time from the end of k2a until all of them have finished. */
     double k2win_ms;
     uint64_t n_windows_device;             /* printing windows the device computed (main ORF and shifted frames, speculative past a stop) */
-    uint64_t n_groups_k3a;                 /* of n_groups_k3: groups with a record slot (k3_window_seq list A: sequences, records, ids) */
+    uint64_t n_groups_k3a;                 /* of n_groups_k3: groups in k3_window_seq's list A (their ids are hashed) */
     uint64_t n_ids;                        /* haplotype ids hashed (somatic: inside k3_window_seq; normal: k3b_haplotype_ids) */
 } mp_run_stats;
 

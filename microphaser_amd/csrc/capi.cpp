@@ -261,11 +261,11 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
             st->n_ids = t.n_recs;
             // K3 looks at the listed groups only; their windows' static records / reference bytes / columns are shared out by the listed share
             const double k3_share = t.n_groups ? double(t.n_k3) / double(t.n_groups) : 0.0;
-            // item, haplotype word, summary per listed group; a record (written once, complete with its id in somatic mode) per list-A group
-            // that needs one (<= the record slots K2 reserved); the transcript's id text per hashed id
+            // item, haplotype word, summary per listed group; a record (written once, complete with its id in somatic mode) per record slot
+            // the window kernels reserved; the transcript's id text per hashed id
             st->bytes_k3 = t.n_k3 * (16 + 8 + sizeof(GroupSum)) +
                            uint64_t(k3_share * double(b.wins.size() * sizeof(WinStatic) + sum_wlen + sizeof(WinCol) * sum_cols)) +
-                           t.n_k3a * hap_rec_stride(b.seq_cap) + (b.normal ? 0 : t.n_recs * 24);
+                           t.n_rec_slots * hap_rec_stride(b.seq_cap) + (b.normal ? 0 : t.n_recs * 24);
             st->bytes_k3b = b.normal ? t.n_recs * (32 + b.seq_cap + 8) : 0;   // (somatic ids are hashed inside K3: no second pass over the records)
             st->hbm_bytes = dev.hbm_bytes();
             st->rows_per_lane = uint32_t(t.rows_per_lane); st->mask_words = b.mask_words; st->attempts = t.attempts;

@@ -404,6 +404,7 @@ void DeviceContext::run(RunTiming& t) {
         t.n_groups = slots;
         t.n_k3 = n_k3a + n_k3b;
         t.n_k3a = n_k3a;
+        t.n_rec_slots = rec_slots;
         return;
     }
     throw Error("device result buffers kept overflowing");

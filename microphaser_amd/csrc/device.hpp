@@ -33,7 +33,7 @@ struct RunTiming {
     float k1_ms = 0, k2_ms = 0, k3_ms = 0, k3b_ms = 0, total_ms = 0;
     float k2seq_ms = 0, k2a_ms = 0, k2l_ms = 0, k2w_ms = 0;   // the launches inside k2_ms: sequential replay, admission, lane-per-window, wave-per-window
     float k2win_ms = 0;                                        // the lane- and wave-per-window launches run side by side: their joint wall time
-    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0, n_k3 = 0, n_k3a = 0;   // n_k3: groups K3 looked at (the rest were settled by K2l)
+    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0, n_k3 = 0, n_k3a = 0, n_rec_slots = 0;   // n_k3: groups K3 looked at (the rest were settled by K2l)
     int rows_per_lane = 1;
     uint32_t attempts = 0;
 };

@@ -213,11 +213,11 @@ constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: o
 
 // K2 -> K3: the group slots K3 has to look at are appended to two dense lists per output allocator, both inside the allocator's
 // sub-range of k3_items (one 16-byte item {group slot, window, record slot, 0} per listed group):
-//   list A - groups K2 reserved a record slot for (a somatic column is set, or the planner wants every haplotype of the window): K3
-//            builds their sequences, hashes their ids and writes their records; grows upwards from the sub-range's first entry,
-//            length in cursors[p * 32 + 8]
-//   list B - the other listed groups (K3 only decides stop / differs / indel flags for them): grows downwards from the sub-range's
-//            last entry, length in cursors[p * 32 + 12]
+//   list A - groups whose haplotype id K3 hashes: a somatic column is set, or every haplotype of the window gets an id (indel / frameshift
+//            context) - the lane kernel knows which; the wave kernels send every group with a record slot here. K3 builds their sequences,
+//            hashes their ids and writes their records; grows upwards from the sub-range's first entry, length in cursors[p * 32 + 8]
+//   list B - the other listed groups: stop / differs / indel flags, and the record of a group with a slot that needs no id (a window
+//            carried into a splice merge); grows downwards from the sub-range's last entry, length in cursors[p * 32 + 12]
 // so the lanes of a K3 wave all do the same kind of work (the SHA-1 of the ids is two thirds of K3's instructions; in one mixed list
 // 40 % of its lanes would idle through it). The lists cannot meet while the groups fit their sub-range (one entry per group slot at
 // most); one atomic instruction per call (two lanes, one per list). The lane-per-window kernel settles most groups itself (no somatic
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         const uint32_t r_n = pack & 0x3FF, ncols = (pack >> 10) & 0x3F;
         const bool fwd = (pack & WW_FWD) != 0, need_all = (pack & WW_NEED_ALL) != 0;
         const bool trivial = (pack & WW_TRIVIAL) != 0;   // simple window that cannot hold a stop: a group without a somatic column needs no K3
+        const bool all_ids = (pack & WW_ALL_IDS) != 0;   // every haplotype of the window is hashed (else only those that set a somatic column)
         // ---- rows of the window, haplotypes counted as they come (branch-free body: every lane adds 0 or 1 to one counter)
         const uint32_t cmask32 = ncols ? (0xFFFFFFFFu >> (32 - ncols)) : 0u;   // ncols <= 8: the low dword of the shifted mask is enough
         const uint32_t rev_sh = (32u - ncols) & 31u;
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         // ---- groups in ascending key order: key 0 (the reference haplotype) is always listed (:429-431)
         if constexpr (!HASH) touched |= 1ull;
-        uint32_t ng = 0, nneed = 0;
+        uint32_t ng = 0, nneed = 0, nhash = 0;   // groups; those with a record slot; those of them whose id K3 will hash
         bool has_zero = false;   // (hash form) the reference haplotype has an entry of its own
         if (valid) {
             uint64_t tm = touched;
@@ -985,17 +986,21 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                 const uint32_t x = hist[t * 64 + lane];
                 if constexpr (HASH) {
                     const uint32_t key = x >> 8;
-                    ng++; nneed += (need_all || (uint64_t(key) & som_mask)) ? 1u : 0u;
+                    const bool som = (uint64_t(key) & som_mask) != 0;
+                    ng++; nneed += (need_all || som) ? 1u : 0u; nhash += (som || (need_all && all_ids)) ? 1u : 0u;
                     has_zero = has_zero || key == 0;
                 } else {
 #pragma unroll
                     for (uint32_t b = 0; b < 4; b++) {
                         const uint32_t key = 4 * t + b;
-                        if (((x >> (8 * b)) & 0xFF) || key == 0) { ng++; nneed += (need_all || (uint64_t(key) & som_mask)) ? 1u : 0u; }
+                        if (((x >> (8 * b)) & 0xFF) || key == 0) {
+                            const bool som = (uint64_t(key) & som_mask) != 0;
+                            ng++; nneed += (need_all || som) ? 1u : 0u; nhash += (som || (need_all && all_ids)) ? 1u : 0u;
+                        }
                     }
                 }
             }
-            if (HASH && !has_zero) { ng++; nneed += need_all ? 1u : 0u; }   // key 0 is listed with count 0 (:429-431)
+            if (HASH && !has_zero) { ng++; nneed += need_all ? 1u : 0u; nhash += (need_all && all_ids) ? 1u : 0u; }   // key 0 is listed with count 0 (:429-431)
         }
         // wave-inclusive prefix sums of (ng, nneed), packed: ng <= 256 per lane -> sum <= 16384; nneed likewise
         uint32_t scan = ng | (nneed << 16);
@@ -1006,33 +1011,33 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         }
         const uint32_t total = rdlane(scan, 63);
         const uint32_t tot_g = total & 0xFFFF, tot_r = total >> 16;
-        // K3's two lists (k3_enqueue): A = the groups with a record slot (exactly the nneed ones: list A and the record slots advance in
-        // step, so their prefix is the one already at hand), B = the other groups of a window that is not trivial
-        const uint32_t nb = trivial ? 0u : ng - nneed;
-        uint32_t scanb = nb;
+        // K3's two lists (k3_enqueue): A = the groups whose id K3 will hash (a subset of those with a record slot), B = every other
+        // group that is not settled here - with a record slot (a window whose haplotypes are carried into a splice merge) or without
+        const uint32_t nb = (nneed - nhash) + (trivial ? 0u : ng - nneed);
+        uint32_t scanb = nhash | (nb << 16);   // (both sums stay below 2^16)
 #pragma unroll
         for (uint32_t off = 1; off < 64; off <<= 1) {
             const uint32_t up = __shfl_up(scanb, off);
             if (lane >= off) scanb += up;
         }
-        const uint32_t tot_b = rdlane(scanb, 63);
+        const uint32_t tot_a = rdlane(scanb, 63) & 0xFFFFu, tot_b = rdlane(scanb, 63) >> 16;
         // the tile's four allocations - group slots, record slots, entries of K3's two lists - in ONE atomic instruction: lanes 0..3 each
         // add to their own cursor (one after the other, each under its own condition, they were dependent round trips to L2)
         unsigned long long got = 0;
         if (lane < 4) {
             unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : lane == 2 ? gcur + 8 : gcur + 12;
-            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 3 ? tot_b : tot_r));
+            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : lane == 2 ? tot_a : tot_b));
         }
         const uint64_t gbase = (uint64_t(rdlane(uint32_t(got >> 32), 0)) << 32) | rdlane(uint32_t(got), 0);
         const uint64_t rbase = (uint64_t(rdlane(uint32_t(got >> 32), 1)) << 32) | rdlane(uint32_t(got), 1);
         const uint64_t la_base = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
         const uint64_t lb_base = (uint64_t(rdlane(uint32_t(got >> 32), 3)) << 32) | rdlane(uint32_t(got), 3);
-        uint64_t la_slot = gpart_lo + la_base + ((scan >> 16) - nneed);                       // list A: upwards from the sub-range's first entry
-        uint64_t lb_slot = gpart_lo + gpart_size - 1 - (lb_base + (scanb - nb));              // list B: downwards from its last
+        uint64_t la_slot = gpart_lo + la_base + ((scanb & 0xFFFFu) - nhash);                  // list A: upwards from the sub-range's first entry
+        uint64_t lb_slot = gpart_lo + gpart_size - 1 - (lb_base + ((scanb >> 16) - nb));      // list B: downwards from its last
         // (the list cursors also count the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
         //  still find a list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
         //  word makes it leave and the pass is run again with larger arenas. The two lists cannot meet unless the groups overflow.)
-        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_r <= gpart_size && lb_base + tot_b <= gpart_size;
+        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_a <= gpart_size && lb_base + tot_b <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
         if (!can_write) werr |= WD_GROUP_OVERFLOW;
@@ -1051,10 +1056,11 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                     // the rest is for K3 only: one item (k3_enqueue's layout) in list A or B
                     // (one store at a selected address and plain cursor arithmetic: with a store per branch the compiler kept the two cursors
                     //  in a dynamically indexed scratch array - 0.3 GB of private-memory traffic per pass)
-                    const bool to_b = !need && !settled;
-                    const uint64_t at = need ? la_slot : lb_slot;
-                    if (need || to_b) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
-                    la_slot += need ? 1u : 0u;
+                    const bool to_a = (uint64_t(key) & som_mask) != 0 || (need_all && all_ids);   // its id will be hashed
+                    const bool to_b = !to_a && !settled;
+                    const uint64_t at = to_a ? la_slot : lb_slot;
+                    if (to_a || to_b) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                    la_slot += to_a ? 1u : 0u;
                     lb_slot -= to_b ? 1u : 0u;
                 }
                 gslot++;
@@ -2280,10 +2286,10 @@ __device__ __forceinline__ uint64_t haplotype_id60(const DeviceBatch& d, bool ac
     return (uint64_t(o0) << 28) | (uint64_t(o1) >> 4);
 }
 
-// LIST_A: the groups of list A (k3_enqueue) - sequences, flags, the record AND its id in one go: the sequence is still in the lane's LDS
+// LIST_A: the groups of list A (k3_enqueue: those whose id will be hashed) - sequences, flags, the record AND its id in one go: the sequence is still in the lane's LDS
 // slot when the id is hashed, so the record is written once, complete, and never read again on the device (a separate id kernel re-read
 // 0.5 GB of records per config C pass and ran at 9 % of the HBM roofline; here its ALU work overlaps the other waves' gathers).
-// !LIST_A: list B - flags only, no record, no id.
+// !LIST_A: list B - flags, and the record where the window kernel reserved a slot (haplotypes carried into a splice merge); no id.
 template <int SEQ_CAP, bool LIST_A, int THREADS>   // THREADS: workgroup size (list A: the waves of a workgroup share the decimal-text table)
 __global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
     constexpr int K3_THREADS = THREADS;
@@ -2525,15 +2531,23 @@ __global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
     }
     // the record slot (if any) was assigned by K2; a slot K3 turns out not to need is marked "no id"
     uint32_t recidx = 0;
-    if constexpr (LIST_A) {
-        // sequences -> registers (the slot becomes the message buffer), id, then the whole record in one run of 16-byte stores
+    {
+        // sequences -> registers (list A: the slot becomes the message buffer), id, then the whole record in one run of 16-byte stores
         // (records are 16-byte aligned: rec_stride and the header are multiples of 16)
         uint32_t sqr[2 * SEQ_CAP / 4];
 #pragma unroll
         for (int k = 0; k < 2 * SEQ_CAP / 4; k++) sqr[k] = slot[K3_REFCAP / 4 + k];
         const bool has_slot = live && rec_pre != 0xFFFFFFFFu;
         const bool hash = has_slot && need_rec && want_id;
-        const uint64_t id60 = haplotype_id60<SEQ_CAP>(d, hash, sqr, seq_len, id_off, id_len, idw, id_mis, rec_sso, slot, byte_text);
+        uint64_t id60 = 0;
+        if constexpr (LIST_A) {
+            id60 = haplotype_id60<SEQ_CAP>(d, hash, sqr, seq_len, id_off, id_len, idw, id_mis, rec_sso, slot, byte_text);
+            // the number of ids of the pass (statistics only: one wave-aggregated add without a return value)
+            const uint64_t hm = __ballot(hash);
+            if (hm && (tid & 63u) == uint32_t(__builtin_ctzll(hm))) atomicAdd(d.cursors + ((blockIdx.x + blockIdx.y) & (NPART - 1)) * 32 + 24, (unsigned long long)__popcll(hm));
+        } else if (hash) {
+            atomicOr(d.err, WD_REC_OVERFLOW);   // a haplotype that wants an id was listed without one (must not happen: the window kernels send every such group to list A)
+        }
         if (has_slot) {
             uint32_t* out = reinterpret_cast<uint32_t*>(d.recs + uint64_t(rec_pre) * d.rec_stride);
             if (need_rec) {
@@ -2550,19 +2564,14 @@ __global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
                         out4[2 + G + k] = make_uint4(sqr[4 * (G + k)], sqr[4 * (G + k) + 1], sqr[4 * (G + k) + 2], sqr[4 * (G + k) + 3]);
                     }
                 }
-                sumflags |= GS_HAS_REC | (want_id ? uint32_t(GS_ID_VALID) : 0u);
+                sumflags |= GS_HAS_REC | ((LIST_A && want_id) ? uint32_t(GS_ID_VALID) : 0u);
                 recidx = rec_pre;
             } else {
                 out[7] = 0;
             }
         } else if (live && need_rec) {
-            atomicOr(d.err, WD_REC_OVERFLOW);  // the record buffer is full (K2 flagged it too)
+            atomicOr(d.err, WD_REC_OVERFLOW);  // the record buffer is full (K2 flagged it too), or K2's superset rule missed a haplotype (must not happen)
         }
-        // the number of ids of the pass (statistics only: one wave-aggregated add without a return value)
-        const uint64_t hm = __ballot(hash);
-        if (hm && (tid & 63u) == uint32_t(__builtin_ctzll(hm))) atomicAdd(d.cursors + ((blockIdx.x + blockIdx.y) & (NPART - 1)) * 32 + 24, (unsigned long long)__popcll(hm));
-    } else {
-        if (live && need_rec) atomicOr(d.err, WD_REC_OVERFLOW);  // K2's superset rule missed a haplotype (must not happen)
     }
     if (live) {
         GroupSum gs;

@@ -495,7 +495,8 @@ static void route_lane_windows(Batch& b) {
                 WinW w{};
                 w.rr_lo = rn ? e.adm_off + (b.step_rlo[si] - e.read_lo) : 0;
                 const bool trivial = (b.win_trivial[st.win >> 5] >> (st.win & 31)) & 1u;
-                w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u) | (trivial ? WW_TRIVIAL : 0u);
+                w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u) | (trivial ? WW_TRIVIAL : 0u) |
+                         ((b.wins[st.win].need_recs & WS_ALL_IDS) ? WW_ALL_IDS : 0u);
                 w.wkey = rev ? ~st.sso : st.sso + uint32_t(st.wlen);
                 w.step = si;
                 w.col_hi = st.col_hi;

@@ -106,7 +106,9 @@ struct WinW {
 };
 static_assert(sizeof(WinW) == 32, "WinW layout");
 enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17,
-                  WW_TRIVIAL = 1u << 18 };   // WSF_SIMPLE && WSF_NOSTOP and no record demand of its own: a group without a somatic column is settled by K2l
+                  WW_TRIVIAL = 1u << 18,     // WSF_SIMPLE && WSF_NOSTOP and no record demand of its own: a group without a somatic column is settled by K2l
+                  WW_ALL_IDS = 1u << 19 };   // WS_ALL_IDS: every haplotype of the window gets an id (indel / frameshift context); without it only a
+                                             // haplotype that sets a somatic column is hashed - the others go to K3's list B even when they need a record
 struct RowRecA {         // K2a output per (ExonW, read), first half (the second is the 64-bit support mask)
     uint32_t key;        // '+': end_pos, '-': ~start
     uint32_t ord;        // AdmEntry::ord
