@@ -237,6 +237,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.mask_words = b.mask_words;
     d_.normal = b.normal ? 1u : 0u;
     d_.normal_large = 0;
+    d_.timing_skip_ids = std::getenv("MP_TIMING_SKIP_IDS") ? 1u : 0u;
     d_.seq_cap = b.seq_cap;
     d_.rec_stride = hap_rec_stride(b.seq_cap);
     // K1 outputs

@@ -2290,8 +2290,8 @@ __device__ __forceinline__ uint64_t haplotype_id60(const DeviceBatch& d, bool ac
 // slot when the id is hashed, so the record is written once, complete, and never read again on the device (a separate id kernel re-read
 // 0.5 GB of records per config C pass and ran at 9 % of the HBM roofline; here its ALU work overlaps the other waves' gathers).
 // !LIST_A: list B - flags, and the record where the window kernel reserved a slot (haplotypes carried into a splice merge); no id.
-template <int SEQ_CAP, bool LIST_A, int THREADS>   // THREADS: workgroup size (list A: the waves of a workgroup share the decimal-text table)
-__global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
+template <int SEQ_CAP, bool LIST_A, int THREADS, int K3_ITEMS>   // THREADS: workgroup size; K3_ITEMS: list entries per lane, loaded together
+__global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceBatch d) {   // (list A's message buffers allow < 3 waves per SIMD anyway: registers are free there)
     constexpr int K3_THREADS = THREADS;
     // the lane's LDS slot: ref | seq | germ while the sequences are built; list A re-uses it as the SHA-1 message buffer afterwards (the
     // sequences are in registers by then), so it is at least K3B_BUF_WORDS + 1 dwords there (odd stride: bank-conflict free)
@@ -2306,65 +2306,95 @@ __global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
     if (pass_overflowed(d)) return;
     const uint64_t part_size = 1ull << d.group_part_log2;
     const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST_A ? 8 : 12)], (unsigned long long)part_size);
-    for (uint64_t tile = blockIdx.x; tile * K3_THREADS < n_slots; tile += gridDim.x) {
-    const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue: A upwards, B downwards)
-    const uint64_t lidx = li < n_slots ? li : 0;   // (a clamped index for the lanes past the end)
-    const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST_A ? lidx : part_size - 1 - lidx);
-    // the item K2 listed: group slot, window, reserved record slot (one 16-byte load)
-    const uint4 item = d.k3_items[lpos];
-    const uint64_t g = li < n_slots ? item.x : 0;
-    uint32_t* slot = lds_slots + tid * K3_SLOT_DW;
-    uint8_t* refb = reinterpret_cast<uint8_t*>(slot);
-    uint8_t* seq = refb + K3_REFCAP;
-    uint8_t* germ = seq + SEQ_CAP;
-    const uint32_t w = li < n_slots ? item.y : 0xFFFFFFFFu;
-    const uint32_t rec_pre = li < n_slots ? item.z : 0xFFFFFFFFu;
-    // the haplotype word is fetched beside the window's static record (both addresses come from the item)
-    const uint64_t hap_pre = d.groups[g].hap;
+    // Every wave takes K3_ITEMS tiles at once - K3_ITEMS list entries per lane - and issues the loads of ALL of them level by level (entry,
+    // then window record + haplotype word, then reference bytes + columns + transcript, then the id's characters) before it works through
+    // them one after the other: the kernel's time without the SHA-1 arithmetic was 0.91 of 1.42 ms, all of it dependent-load latency at
+    // the 11 waves per CU the message buffers allow, and a wave with twice the loads in flight per level needs half the waves.
+    struct K3In {
+        bool in_list;
+        uint64_t g;
+        uint32_t w, rec_pre;
+        uint64_t hap;
+        WinStatic ws;
+        const uint8_t* wref;
+        uint32_t mis;
+        uint32_t refw[K3_REFCAP / 4];
+        uint32_t cp[8], ci[8];
+        uint32_t id_off, id_len, id_mis;
+        uint32_t idw[6];
+    };
+    auto load_entry = [&](K3In& I, uint64_t tile) __attribute__((always_inline)) {
+        const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue: A upwards, B downwards)
+        I.in_list = li < n_slots;
+        const uint64_t lidx = I.in_list ? li : 0;      // (a clamped index for the lanes past the end)
+        const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST_A ? lidx : part_size - 1 - lidx);
+        // the item K2 listed: group slot, window, reserved record slot (one 16-byte load)
+        const uint4 item = d.k3_items[lpos];
+        I.g = item.x; I.w = item.y; I.rec_pre = item.z;
+    };
+    auto load_window = [&](K3In& I) __attribute__((always_inline)) {   // the window's static record and the haplotype word (both addresses come from the item)
+        if (!I.in_list) { I.g = 0; I.w = 0xFFFFFFFFu; I.rec_pre = 0xFFFFFFFFu; }
+        I.ws = d.wins[I.w != 0xFFFFFFFFu ? I.w : 0u];
+        I.hap = d.groups[I.g].hap;
+    };
+    auto load_payload = [&](K3In& I) __attribute__((always_inline)) {
+        // (all loads of this level - the transcript's id position first, the staged reference dwords and the first eight columns - are
+        //  issued together and unconditionally, at clamped addresses into padded pools: a load under a branch makes the compiler drain the
+        //  memory counter at the join)
+        const WinStatic& ws = I.ws;
+        I.id_off = 0; I.id_len = 0;
+        if constexpr (LIST_A) { const TxDev* T = d.tx + ws.tx; I.id_off = T->id_off; I.id_len = T->id_len; }
+        I.wref = d.ref_pool + ws.ref_off;
+        I.mis = uint32_t(reinterpret_cast<uintptr_t>(I.wref) & 3u);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(I.wref - I.mis);
+#pragma unroll
+        for (int k = 0; k < K3_REFCAP / 4; k++) I.refw[k] = src[k];
+        const uint32_t ncols = ws.ncols, last_c = ncols ? ncols - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const WinCol* wc = d.win_cols + ws.col_off + min(uint32_t(k), last_c); I.cp[k] = wc->pos; I.ci[k] = wc->info; }
+    };
+    auto load_id_text = [&](K3In& I) __attribute__((always_inline)) {   // the id's first 20+ characters as six aligned dwords, fetched together (the pool is padded); used after the walk
+        I.id_mis = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) I.idw[k] = 0;
+        if constexpr (LIST_A) {
+            const uint8_t* idp = d.str_pool + I.id_off;
+            I.id_mis = uint32_t(reinterpret_cast<uintptr_t>(idp) & 3u);
+#pragma unroll
+            for (int k = 0; k < 6; k++) I.idw[k] = reinterpret_cast<const uint32_t*>(idp - I.id_mis)[k];
+        }
+    };
+    uint32_t* const slot = lds_slots + tid * K3_SLOT_DW;
+    uint8_t* const refb = reinterpret_cast<uint8_t*>(slot);
+    uint8_t* const seq = refb + K3_REFCAP;
+    uint8_t* const germ = seq + SEQ_CAP;
+    auto process = [&](K3In& I) __attribute__((always_inline)) {
+    const uint64_t g = I.g;
+    const uint32_t w = I.w, rec_pre = I.rec_pre;
     const bool live = w != 0xFFFFFFFFu;
+    const uint32_t id_off = I.id_off, id_len = I.id_len, id_mis = I.id_mis;
+    const uint32_t* const idw = I.idw;
     uint32_t sumflags = 0;
     bool need_rec = false;
     uint64_t prof_set = 0;
     bool want_id = false;
     uint32_t seq_len = 0, germ_len = 0, prof_len = 0, nvar = 0, nsom = 0, first_fs = 0, first_fs_j = 0;
     uint32_t rec_sso = 0;
-    uint32_t id_off = 0, id_len = 0, id_mis = 0;
-    uint32_t idw[6] = {0, 0, 0, 0, 0, 0};
     if (live) {
-        const WinStatic ws = d.wins[w];
+        const WinStatic& ws = I.ws;
         rec_sso = ws.sso;
-        if constexpr (LIST_A) {   // the transcript's id: issued first (loads complete in order), its characters are fetched below, beside the sequence work
-            const TxDev* T = d.tx + ws.tx;
-            id_off = T->id_off; id_len = T->id_len;
-        }
         const uint32_t vbase = ws.vbase;
-        const uint64_t hap = hap_pre;
+        const uint64_t hap = I.hap;
         const bool is_rev = (ws.flags & WSF_REVERSE) != 0;
         const uint32_t ncols = ws.ncols;
         const uint32_t window_end = ws.sso + ws.wlen;
-        // stage the reference window [sso, sso + wlen) with aligned dword loads
-        const uint8_t* wref = d.ref_pool + ws.ref_off;
-        const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(wref) & 3u);
-        // (all loads of this level - the staged reference dwords and the first eight columns - are issued together and unconditionally, at
-        //  clamped addresses into padded pools: a load under a branch makes the compiler drain the memory counter at the join)
-        uint32_t refw[K3_REFCAP / 4];
-        uint32_t cp[8], ci[8];
-        {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(wref - mis);
+        // the reference window [sso, sso + wlen), staged with aligned dword loads (load_payload), goes to the lane's slot
+        const uint8_t* const wref = I.wref;
+        const uint32_t mis = I.mis;
+        const uint32_t* const cp = I.cp;
+        const uint32_t* const ci = I.ci;
 #pragma unroll
-            for (int k = 0; k < K3_REFCAP / 4; k++) refw[k] = src[k];
-            const uint32_t last_c = ncols ? ncols - 1 : 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const WinCol* wc = d.win_cols + ws.col_off + min(uint32_t(k), last_c); cp[k] = wc->pos; ci[k] = wc->info; }
-#pragma unroll
-            for (int k = 0; k < K3_REFCAP / 4; k++) slot[k] = refw[k];
-        }
-        if constexpr (LIST_A) {   // the id's first 20+ characters as six aligned dwords, fetched together (the pool is padded); used after the walk
-            const uint8_t* idp = d.str_pool + id_off;
-            id_mis = uint32_t(reinterpret_cast<uintptr_t>(idp) & 3u);
-#pragma unroll
-            for (int k = 0; k < 6; k++) idw[k] = reinterpret_cast<const uint32_t*>(idp - id_mis)[k];
-        }
+        for (int k = 0; k < K3_REFCAP / 4; k++) slot[k] = I.refw[k];
         const uint32_t staged = min(uint32_t(ws.wlen), uint32_t(K3_REFCAP) - mis);
         auto ref_at = [&](uint32_t pos) -> uint8_t {  // reference base at absolute position pos (>= sso)
             uint32_t k = pos - ws.sso;
@@ -2541,7 +2571,7 @@ __global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
         const bool hash = has_slot && need_rec && want_id;
         uint64_t id60 = 0;
         if constexpr (LIST_A) {
-            id60 = haplotype_id60<SEQ_CAP>(d, hash, sqr, seq_len, id_off, id_len, idw, id_mis, rec_sso, slot, byte_text);
+            id60 = haplotype_id60<SEQ_CAP>(d, hash && !d.timing_skip_ids, sqr, seq_len, id_off, id_len, idw, id_mis, rec_sso, slot, byte_text);
             // the number of ids of the pass (statistics only: one wave-aggregated add without a return value)
             const uint64_t hm = __ballot(hash);
             if (hm && (tid & 63u) == uint32_t(__builtin_ctzll(hm))) atomicAdd(d.cursors + ((blockIdx.x + blockIdx.y) & (NPART - 1)) * 32 + 24, (unsigned long long)__popcll(hm));
@@ -2579,7 +2609,21 @@ __global__ __launch_bounds__(THREADS) void k3_window_seq(DeviceBatch d) {
         gs.rec = recidx;
         d.gsum[g] = gs;
     }
-    }   // tiles of this wave
+    };   // process
+    for (uint64_t tile0 = uint64_t(blockIdx.x) * K3_ITEMS; tile0 * K3_THREADS < n_slots; tile0 += uint64_t(gridDim.x) * K3_ITEMS) {
+        static_assert(K3_ITEMS == 1 || K3_ITEMS == 2, "entries per lane");
+        K3In in0, in1;   // (named objects, every use spelled out: a loop over an array of them kept the array in scratch)
+        load_entry(in0, tile0);
+        if constexpr (K3_ITEMS == 2) load_entry(in1, tile0 + 1);
+        load_window(in0);
+        if constexpr (K3_ITEMS == 2) load_window(in1);
+        load_payload(in0);
+        if constexpr (K3_ITEMS == 2) load_payload(in1);
+        load_id_text(in0);
+        if constexpr (K3_ITEMS == 2) load_id_text(in1);
+        process(in0);
+        if constexpr (K3_ITEMS == 2) process(in1);
+    }
 }
 
 // K3 for `microphaser normal` (reference: src/normal_microphasing.rs:341-647): same slots and record layout, but the
@@ -2897,18 +2941,21 @@ static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t
     // instead of 11 waves per CU - measured 1.55 against 1.46 ms: the four waves of a workgroup start together and stay in step, gather
     // phase on gather phase. MP_K3A_THREADS=256 brings that form back for comparisons.)
     static const int a_threads = [] { const char* e = std::getenv("MP_K3A_THREADS"); return e && std::atoi(e) == 256 ? 256 : 64; }();
+    static const int items = [] { const char* e = std::getenv("MP_K3_ITEMS"); return e && std::atoi(e) == 1 ? 1 : 2; }();   // list entries per lane (1: the round-2 form)
     const int T = LIST_A && d.seq_cap <= 48 ? a_threads : K3_THREADS;
-    const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + uint64_t(T);
-    dim3 grid(uint32_t(std::min<uint64_t>((per_list + T - 1) / T, 0x7FFFFFFFull)), NPART), block(T);
+    const int U = d.seq_cap <= 48 ? items : 1;
+    const uint64_t per_wave = uint64_t(T) * uint64_t(U);
+    const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + per_wave;
+    dim3 grid(uint32_t(std::min<uint64_t>((per_list + per_wave - 1) / per_wave, 0x7FFFFFFFull)), NPART), block(T);
+#define K3_LAUNCH(CAP, TT, UU) hipLaunchKernelGGL((k3_window_seq<CAP, LIST_A, TT, UU>), grid, block, 0, stream, d)
     switch (d.seq_cap) {
-        case 32: if (T == 256) hipLaunchKernelGGL((k3_window_seq<32, LIST_A, 256>), grid, block, 0, stream, d);
-                 else hipLaunchKernelGGL((k3_window_seq<32, LIST_A, 64>), grid, block, 0, stream, d); break;
-        case 48: if (T == 256) hipLaunchKernelGGL((k3_window_seq<48, LIST_A, 256>), grid, block, 0, stream, d);
-                 else hipLaunchKernelGGL((k3_window_seq<48, LIST_A, 64>), grid, block, 0, stream, d); break;
-        case 112: hipLaunchKernelGGL((k3_window_seq<112, LIST_A, 64>), grid, block, 0, stream, d); break;
-        case 240: hipLaunchKernelGGL((k3_window_seq<240, LIST_A, 64>), grid, block, 0, stream, d); break;
+        case 32: if (T == 256) { if (U == 2) K3_LAUNCH(32, 256, 2); else K3_LAUNCH(32, 256, 1); } else { if (U == 2) K3_LAUNCH(32, 64, 2); else K3_LAUNCH(32, 64, 1); } break;
+        case 48: if (T == 256) { if (U == 2) K3_LAUNCH(48, 256, 2); else K3_LAUNCH(48, 256, 1); } else { if (U == 2) K3_LAUNCH(48, 64, 2); else K3_LAUNCH(48, 64, 1); } break;
+        case 112: K3_LAUNCH(112, 64, 1); break;
+        case 240: K3_LAUNCH(240, 64, 1); break;
         default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
+#undef K3_LAUNCH
     HIP_CHECK_LAUNCH();
 }
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, hipStream_t stream_a, hipStream_t stream_b) {

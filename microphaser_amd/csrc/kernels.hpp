@@ -57,6 +57,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     uint32_t n_reads, n_tx, n_wins, mask_words;
     uint32_t normal;              // 1: `microphaser normal` semantics (src/normal_microphasing.rs)
     uint32_t normal_large;        // k2n_window_replay with the large per-wave tables (set after the small ones overflowed)
+    uint32_t timing_skip_ids;     // MP_TIMING_SKIP_IDS=1 (measurements only, WRONG ids): K3 skips the SHA-1 arithmetic - what is left is its gather / walk / store time
+    uint32_t timing_pad_;
     const uint32_t* r_varlo;      // planner: gene-relative index of the first variant with pos >= r_pos
     // K1 output
     uint32_t* r_ncov;             // number of variants (from r_varlo on) whose bits K1 evaluated
