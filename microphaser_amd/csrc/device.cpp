@@ -208,6 +208,12 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.rows_per_lane_w = b.rows_per_lane_w;
     d_.achunks = up(b.achunks);
     d_.n_achunks = uint32_t(b.achunks.size());
+    {   // K2a's waves are short and bound by dependent loads: every work item gets its exon's record beside it (one level of scalar loads
+        // instead of work item -> exon), and the batch index of its first read in the item itself (its read fields can be fetched at once)
+        achunk_exons_.resize(b.achunks.size());
+        for (size_t k = 0; k < b.achunks.size(); k++) achunk_exons_[k] = b.exons_w[b.achunks[k].exon];
+        d_.achunk_exons = up(achunk_exons_);
+    }
     d_.step_ncols = up(b.step_ncols);
     d_.step_rlo = up(b.step_rlo);
     d_.step_rn = up(b.step_rn);
@@ -264,6 +270,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     alloc_outputs();
     xfer(pending_up_, true);
     pending_up_.clear();
+    achunk_exons_ = PodVec<ExonW>();
     HIP_OK(hipStreamSynchronize(stream_));
 }
 

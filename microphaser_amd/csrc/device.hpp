@@ -66,6 +66,7 @@ class DeviceContext {
     hipEvent_t pin_ev_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t xfer_stream_ = nullptr;
     std::vector<XferSeg> pending_up_;     // upload(): the arrays to copy once everything is allocated
+    PodVec<ExonW> achunk_exons_;          // upload(): staging of DeviceBatch::achunk_exons
     void xfer(const std::vector<XferSeg>& segs, bool to_device);
     void* dalloc(size_t bytes);
     template <class V> typename V::value_type* up(const V& v);

@@ -735,7 +735,7 @@ __device__ __forceinline__ uint64_t mask_extract(const uint64_t (&m)[W], uint32_
 template <int W>
 __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
     const WChunk A = d.achunks[blockIdx.x];   // one wave per 64 candidate reads of an exon: step_first = first read, n_steps = count
-    const ExonW e = d.exons_w[A.exon];
+    const ExonW e = d.achunk_exons[blockIdx.x];   // (= exons_w[A.exon], stored beside the work item: both loads go out together)
     const bool is_rev = e.strand != 0;
     const uint32_t rbase = e.rbase + e.read_lo;
     const uint32_t sso0 = e.sso0, sso1 = e.sso1;
@@ -2303,8 +2303,9 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
     // blockIdx.y = the output allocator whose list this workgroup walks; the list's length is only known on the device - one scalar
     // load of its cursor (no prefix table, no search) - and the grid's x extent covers the host's upper bound of it
     const uint32_t lpart = blockIdx.y;
-    if (pass_overflowed(d)) return;
     const uint64_t part_size = 1ull << d.group_part_log2;
+    // (the list's length and the pass's error word are needed only to VALIDATE entries: the first entries are fetched beside them, at
+    //  addresses that depend on the workgroup's indices alone - one dependent load level less for every wave)
     const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST_A ? 8 : 12)], (unsigned long long)part_size);
     // Every wave takes K3_ITEMS tiles at once - K3_ITEMS list entries per lane - and issues the loads of ALL of them level by level (entry,
     // then window record + haplotype word, then reference bytes + columns + transcript, then the id's characters) before it works through
@@ -2312,6 +2313,7 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
     // the 11 waves per CU the message buffers allow, and a wave with twice the loads in flight per level needs half the waves.
     struct K3In {
         bool in_list;
+        uint64_t li;
         uint64_t g;
         uint32_t w, rec_pre;
         uint64_t hap;
@@ -2325,15 +2327,18 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
     };
     auto load_entry = [&](K3In& I, uint64_t tile) __attribute__((always_inline)) {
         const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue: A upwards, B downwards)
-        I.in_list = li < n_slots;
-        const uint64_t lidx = I.in_list ? li : 0;      // (a clamped index for the lanes past the end)
+        I.li = li;
+        const uint64_t lidx = li < part_size ? li : part_size - 1;   // (inside the allocator's sub-range whatever the list's length: validated in load_window)
         const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST_A ? lidx : part_size - 1 - lidx);
         // the item K2 listed: group slot, window, reserved record slot (one 16-byte load)
         const uint4 item = d.k3_items[lpos];
         I.g = item.x; I.w = item.y; I.rec_pre = item.z;
     };
     auto load_window = [&](K3In& I) __attribute__((always_inline)) {   // the window's static record and the haplotype word (both addresses come from the item)
+        I.in_list = I.li < n_slots;
         if (!I.in_list) { I.g = 0; I.w = 0xFFFFFFFFu; I.rec_pre = 0xFFFFFFFFu; }
+        if (I.w != 0xFFFFFFFFu && I.w >= d.n_wins) { I.w = 0xFFFFFFFFu; I.g = 0; }   // (never true for a written entry)
+        if (I.g >= d.group_cap) I.g = 0;
         I.ws = d.wins[I.w != 0xFFFFFFFFu ? I.w : 0u];
         I.hap = d.groups[I.g].hap;
     };
@@ -2610,11 +2615,13 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
         d.gsum[g] = gs;
     }
     };   // process
-    for (uint64_t tile0 = uint64_t(blockIdx.x) * K3_ITEMS; tile0 * K3_THREADS < n_slots; tile0 += uint64_t(gridDim.x) * K3_ITEMS) {
+    for (uint64_t tile0 = uint64_t(blockIdx.x) * K3_ITEMS;; tile0 += uint64_t(gridDim.x) * K3_ITEMS) {
         static_assert(K3_ITEMS == 1 || K3_ITEMS == 2, "entries per lane");
         K3In in0, in1;   // (named objects, every use spelled out: a loop over an array of them kept the array in scratch)
         load_entry(in0, tile0);
         if constexpr (K3_ITEMS == 2) load_entry(in1, tile0 + 1);
+        if (tile0 * K3_THREADS >= n_slots) break;   // (checked once the entry loads are on their way)
+        if (pass_overflowed(d)) return;             // (a discarded pass: its lists have holes)
         load_window(in0);
         if constexpr (K3_ITEMS == 2) load_window(in1);
         load_payload(in0);

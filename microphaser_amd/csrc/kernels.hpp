@@ -51,6 +51,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint32_t* win_trivial;    // bit per window: WSF_SIMPLE && WSF_NOSTOP and no record demand of its own (plan.hpp WW_TRIVIAL)
     uint32_t n_lane_small, n_lane_all, lane_on, n_lane_mid;   // winw[0, small): <= 6 columns, [small, mid): 7-8, [mid, all): 9-16 (hash form)
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
+    const ExonW* achunk_exons;      // the exon record of every admission work item, beside it (one load level less in a latency-bound kernel)
     uint32_t n_exons_w, n_wchunks, n_wchunks_m, n_achunks;
     uint32_t rows_per_lane_w;       // RPL of k2w_window_rows_multi: 64 * RPL >= candidate reads of any of its windows
     uint64_t n_adm;
