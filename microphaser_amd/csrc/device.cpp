@@ -25,6 +25,7 @@ DeviceContext::DeviceContext(int device) : device_(device) {
     HIP_OK(hipEventCreateWithFlags(&cleared_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&k3_fork_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&k3_join_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&k3_join2_, hipEventDisableTiming));
     for (auto& ev : join_) HIP_OK(hipEventCreate(&ev));
 }
 
@@ -39,6 +40,7 @@ DeviceContext::~DeviceContext() {
     if (cleared_) (void)hipEventDestroy(cleared_);
     if (k3_fork_) (void)hipEventDestroy(k3_fork_);
     if (k3_join_) (void)hipEventDestroy(k3_join_);
+    if (k3_join2_) (void)hipEventDestroy(k3_join2_);
     for (auto& ev : join_) if (ev) (void)hipEventDestroy(ev);
     for (auto& st : side_) if (st) (void)hipStreamDestroy(st);
     if (stream_) hipStreamDestroy(stream_);
@@ -227,6 +229,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.winw = up(b.winw);
     d_.lane_win = up(b.lane_win);
     d_.win_trivial = up(b.win_trivial);
+    d_.win_simple = up(b.win_simple);
     d_.n_lane_small = b.n_lane_small;
     d_.n_lane_mid = b.n_lane_mid;
     d_.n_lane_all = uint32_t(b.winw.size());
@@ -255,7 +258,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.err = reinterpret_cast<uint32_t*>(d_.cursors + NPART * 32);   // the error word sits behind the cursors: one memset, one copy back per pass
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
-    last_slots_ = last_recs_ = last_want_ = last_k3a_ = last_k3b_ = 0;
+    last_slots_ = last_recs_ = last_want_ = last_k3a_ = last_k3b_ = last_k3c_ = 0;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
@@ -282,7 +285,7 @@ void DeviceContext::alloc_outputs() {
     rec_cap_ = uint64_t(NPART) << rlog_;
     auto oalloc = [&](size_t bytes) { void* p = dalloc(bytes); out_allocs_.push_back(p); out_bytes_ += bytes; return p; };
     d_.groups = static_cast<Group*>(oalloc(group_cap_ * sizeof(Group)));
-    d_.k3_items = static_cast<uint4*>(oalloc(group_cap_ * sizeof(uint4)));
+    d_.k3_items = static_cast<uint4*>(oalloc(2 * group_cap_ * sizeof(uint4)));   // lists A / B in the first half, list C in the second
     d_.gsum = static_cast<GroupSum*>(oalloc(group_cap_ * sizeof(GroupSum)));
     d_.recs = static_cast<uint8_t*>(oalloc(rec_cap_ * d_.rec_stride));
     d_.want_recs = static_cast<uint32_t*>(oalloc(rec_cap_ * 4));
@@ -337,15 +340,19 @@ void DeviceContext::run(RunTiming& t) {
         // (the grids cover an upper bound of the list lengths: the previous pass's counts of this batch plus a margin, else an estimate)
         const uint64_t a_bound = last_slots_ ? last_k3a_ + last_k3a_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * (d_.normal ? 8 : 2) + 65536);
         const uint64_t b_bound = last_slots_ ? last_k3b_ + last_k3b_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 2 + 65536);
+        const uint64_t c_bound = last_slots_ ? (last_k3c_ ? last_k3c_ + last_k3c_ / 16 + 4096 : 0) : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) / 4 + 65536);
         const uint64_t want_bound = last_slots_ ? last_want_ + last_want_ / 16 + 4096 : std::min<uint64_t>(rec_cap_, uint64_t(d_.n_wins) * 2 + 65536);
         if (!d_.normal) {
             HIP_OK(hipEventRecord(k3_fork_, stream_));
             HIP_OK(hipStreamWaitEvent(side_[0], k3_fork_, 0));
+            HIP_OK(hipStreamWaitEvent(side_[1], k3_fork_, 0));
         }
-        launch_k3_window_seq(d_, a_bound, b_bound, stream_, side_[0]);
+        launch_k3_window_seq(d_, a_bound, b_bound, c_bound, stream_, side_[0], side_[1]);
         if (!d_.normal) {
             HIP_OK(hipEventRecord(k3_join_, side_[0]));
             HIP_OK(hipStreamWaitEvent(stream_, k3_join_, 0));
+            HIP_OK(hipEventRecord(k3_join2_, side_[1]));
+            HIP_OK(hipStreamWaitEvent(stream_, k3_join2_, 0));
         }
         HIP_OK(hipEventRecord(ev_[3], stream_));
         if (d_.normal) launch_k3b_haplotype_ids(d_, want_bound, stream_);
@@ -364,7 +371,8 @@ void DeviceContext::run(RunTiming& t) {
         if (err & WD_HAP_OVERFLOW) throw Error("normal mode: more than 2048 distinct haplotypes in one window");
         uint64_t max_g = 0, max_r = 0, max_w = 0;
         for (uint32_t p = 0; p < NPART; p++) {
-            max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]); max_w = std::max<uint64_t>(max_w, cur[p * 32 + 24]);
+            max_g = std::max<uint64_t>(max_g, cur[p * 32]); max_r = std::max<uint64_t>(max_r, cur[p * 32 + 16]);
+            if (d_.normal) max_w = std::max<uint64_t>(max_w, cur[p * 32 + 24]);   // (`normal`: the length of K3n's wanted list; somatic: a count of ids, not a list)
         }
         if ((err & (WD_GROUP_OVERFLOW | WD_REC_OVERFLOW)) || max_g > (1ull << glog_) || max_r > (1ull << rlog_) || max_w > (1ull << rlog_)) {
             const uint32_t g0 = glog_, r0 = rlog_;
@@ -377,7 +385,7 @@ void DeviceContext::run(RunTiming& t) {
             continue;
         }
         if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
-        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3a = 0, n_k3b = 0;
+        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3a = 0, n_k3b = 0, n_k3c = 0;
         for (uint32_t p = 0; p < NPART; p++) {
             used_g_[p] = cur[p * 32];
             used_r_[p] = cur[p * 32 + 16];
@@ -386,6 +394,7 @@ void DeviceContext::run(RunTiming& t) {
             n_want += cur[p * 32 + 24];
             n_k3a += cur[p * 32 + 8];
             n_k3b += cur[p * 32 + 12];
+            n_k3c += cur[p * 32 + 20];
         }
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
@@ -407,10 +416,11 @@ void DeviceContext::run(RunTiming& t) {
         last_want_ = n_want;
         last_k3a_ = n_k3a;
         last_k3b_ = n_k3b;
+        last_k3c_ = n_k3c;
         t.n_group_slots = slots;    // group slots K3 walked (incl. the unused tail of each wave's last chunk) / records K3b hashed
         t.n_recs = n_want;
         t.n_groups = slots;
-        t.n_k3 = n_k3a + n_k3b;
+        t.n_k3 = n_k3a + n_k3b + n_k3c;
         t.n_k3a = n_k3a;
         t.n_rec_slots = rec_slots;
         return;

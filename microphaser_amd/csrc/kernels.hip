@@ -223,22 +223,30 @@ constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: o
 // most); one atomic instruction per call (two lanes, one per list). The lane-per-window kernel settles most groups itself (no somatic
 // column set, simple window without a possible stop: GroupSum = {GS_VALID}) and lists only the rest.
 __device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, bool on, uint64_t slot, uint32_t win, uint32_t rec) {
-    const bool to_a = on && rec != 0xFFFFFFFFu;
-    const uint64_t ma = __ballot(to_a), mb = __ballot(on && !to_a);
-    if (!(ma | mb)) return;
+    // list C: the groups of windows whose sequences need the general walk (indel / multi-allelic columns, long windows). One such lane
+    // makes its whole K3 wave run the per-base walk - at config C 0.8 % of the windows did that to 40 % of the waves - so they get a
+    // list (and a launch) of their own, in the second half of k3_items. (`normal` mode has one K3 kernel for everything: list A.)
+    const uint32_t wbit = on ? d.win_simple[win >> 5] : 0u;
+    const bool simple = d.normal || ((wbit >> (win & 31u)) & 1u);
+    const bool to_c = on && !simple;
+    const bool to_a = on && simple && rec != 0xFFFFFFFFu;
+    const bool to_b = on && simple && rec == 0xFFFFFFFFu;
+    const uint64_t ma = __ballot(to_a), mb = __ballot(to_b), mc = __ballot(to_c);
+    if (!(ma | mb | mc)) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t la = ma ? uint32_t(__builtin_ctzll(ma)) : 64u, lb = mb ? uint32_t(__builtin_ctzll(mb)) : 64u;
+    const uint32_t la = ma ? uint32_t(__builtin_ctzll(ma)) : 64u, lb = mb ? uint32_t(__builtin_ctzll(mb)) : 64u, lc = mc ? uint32_t(__builtin_ctzll(mc)) : 64u;
     unsigned long long base = 0;
-    if (lane == la || lane == lb)
-        base = atomicAdd(d.cursors + part * 32 + (lane == la ? 8 : 12), (unsigned long long)__popcll(lane == la ? ma : mb));
-    const uint32_t src = to_a ? (la & 63u) : (lb & 63u);
+    if (lane == la || lane == lb || lane == lc)   // one atomic instruction, a lane per list
+        base = atomicAdd(d.cursors + part * 32 + (lane == la ? 8 : lane == lb ? 12 : 20), (unsigned long long)__popcll(lane == la ? ma : lane == lb ? mb : mc));
+    const uint32_t src = (to_a ? la : to_b ? lb : lc) & 63u;
     const uint64_t b0 = (uint64_t(uint32_t(__shfl(int(uint32_t(base >> 32)), int(src)))) << 32) | uint32_t(__shfl(int(uint32_t(base)), int(src)));
     // (the cursors also count the entries of waves whose groups did NOT fit their sub-range: never store outside the sub-range, flag
     //  the pass instead; it is run again with larger arenas and K3 never walks the lists of a flagged pass)
     if (on) {
         const uint64_t size = 1ull << d.group_part_log2;
-        const uint64_t at = b0 + lanes_below(to_a ? ma : mb, lane);
-        if (at < size) d.k3_items[(uint64_t(part) << d.group_part_log2) + (to_a ? at : size - 1 - at)] = make_uint4(uint32_t(slot), win, rec, 0u);
+        const uint64_t at = b0 + lanes_below(to_a ? ma : to_b ? mb : mc, lane);
+        const uint64_t sub = (uint64_t(part) << d.group_part_log2) + (to_c ? d.group_cap : 0ull);
+        if (at < size) d.k3_items[sub + (to_b ? size - 1 - at : at)] = make_uint4(uint32_t(slot), win, rec, 0u);
         else atomicOr(d.err, WD_GROUP_OVERFLOW);
     }
 }
@@ -882,6 +890,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         const bool fwd = (pack & WW_FWD) != 0, need_all = (pack & WW_NEED_ALL) != 0;
         const bool trivial = (pack & WW_TRIVIAL) != 0;   // simple window that cannot hold a stop: a group without a somatic column needs no K3
         const bool all_ids = (pack & WW_ALL_IDS) != 0;   // every haplotype of the window is hashed (else only those that set a somatic column)
+        const bool simple = (pack & WW_SIMPLE) != 0;     // K3 builds the sequences by byte substitution; every group of another window goes to K3's list C
         // ---- rows of the window, haplotypes counted as they come (branch-free body: every lane adds 0 or 1 to one counter)
         const uint32_t cmask32 = ncols ? (0xFFFFFFFFu >> (32 - ncols)) : 0u;   // ncols <= 8: the low dword of the shifted mask is enough
         const uint32_t rev_sh = (32u - ncols) & 31u;
@@ -1013,31 +1022,44 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         const uint32_t tot_g = total & 0xFFFF, tot_r = total >> 16;
         // K3's two lists (k3_enqueue): A = the groups whose id K3 will hash (a subset of those with a record slot), B = every other
         // group that is not settled here - with a record slot (a window whose haplotypes are carried into a splice merge) or without
-        const uint32_t nb = (nneed - nhash) + (trivial ? 0u : ng - nneed);
-        uint32_t scanb = nhash | (nb << 16);   // (both sums stay below 2^16)
+        const uint32_t na = simple ? nhash : 0u;
+        const uint32_t nb = simple ? (nneed - nhash) + (trivial ? 0u : ng - nneed) : 0u;
+        const uint32_t nc = simple ? 0u : ng;   // (a window that is not simple is never trivial: all its groups are listed)
+        uint32_t scanb = na | (nb << 16);   // (both sums stay below 2^16)
 #pragma unroll
         for (uint32_t off = 1; off < 64; off <<= 1) {
             const uint32_t up = __shfl_up(scanb, off);
             if (lane >= off) scanb += up;
         }
         const uint32_t tot_a = rdlane(scanb, 63) & 0xFFFFu, tot_b = rdlane(scanb, 63) >> 16;
+        uint32_t scanc = nc, tot_c = 0;
+        if (__ballot(nc != 0)) {   // (wave-uniform: most tiles hold simple windows only)
+#pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(scanc, off);
+                if (lane >= off) scanc += up;
+            }
+            tot_c = rdlane(scanc, 63);
+        }
         // the tile's four allocations - group slots, record slots, entries of K3's two lists - in ONE atomic instruction: lanes 0..3 each
         // add to their own cursor (one after the other, each under its own condition, they were dependent round trips to L2)
         unsigned long long got = 0;
-        if (lane < 4) {
-            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : lane == 2 ? gcur + 8 : gcur + 12;
-            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : lane == 2 ? tot_a : tot_b));
+        if (lane < 5) {
+            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : lane == 2 ? gcur + 8 : lane == 3 ? gcur + 12 : gcur + 20;
+            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : lane == 2 ? tot_a : lane == 3 ? tot_b : tot_c));
         }
         const uint64_t gbase = (uint64_t(rdlane(uint32_t(got >> 32), 0)) << 32) | rdlane(uint32_t(got), 0);
         const uint64_t rbase = (uint64_t(rdlane(uint32_t(got >> 32), 1)) << 32) | rdlane(uint32_t(got), 1);
         const uint64_t la_base = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
         const uint64_t lb_base = (uint64_t(rdlane(uint32_t(got >> 32), 3)) << 32) | rdlane(uint32_t(got), 3);
-        uint64_t la_slot = gpart_lo + la_base + ((scanb & 0xFFFFu) - nhash);                  // list A: upwards from the sub-range's first entry
+        const uint64_t lc_base = (uint64_t(rdlane(uint32_t(got >> 32), 4)) << 32) | rdlane(uint32_t(got), 4);
+        uint64_t lc_slot = d.group_cap + gpart_lo + lc_base + (scanc - nc);                   // list C: upwards in the second array
+        uint64_t la_slot = gpart_lo + la_base + ((scanb & 0xFFFFu) - na);                     // list A: upwards from the sub-range's first entry
         uint64_t lb_slot = gpart_lo + gpart_size - 1 - (lb_base + ((scanb >> 16) - nb));      // list B: downwards from its last
         // (the list cursors also count the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
         //  still find a list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
         //  word makes it leave and the pass is run again with larger arenas. The two lists cannot meet unless the groups overflow.)
-        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_a <= gpart_size && lb_base + tot_b <= gpart_size;
+        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_a <= gpart_size && lb_base + tot_b <= gpart_size && lc_base + tot_c <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
         if (!can_write) werr |= WD_GROUP_OVERFLOW;
@@ -1056,12 +1078,13 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                     // the rest is for K3 only: one item (k3_enqueue's layout) in list A or B
                     // (one store at a selected address and plain cursor arithmetic: with a store per branch the compiler kept the two cursors
                     //  in a dynamically indexed scratch array - 0.3 GB of private-memory traffic per pass)
-                    const bool to_a = (uint64_t(key) & som_mask) != 0 || (need_all && all_ids);   // its id will be hashed
-                    const bool to_b = !to_a && !settled;
-                    const uint64_t at = to_a ? la_slot : lb_slot;
-                    if (to_a || to_b) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                    const bool hashes = (uint64_t(key) & som_mask) != 0 || (need_all && all_ids);   // its id will be hashed
+                    const bool to_a = simple && hashes, to_b = simple && !hashes && !settled, to_c = !simple;
+                    const uint64_t at = to_a ? la_slot : to_b ? lb_slot : lc_slot;
+                    if (to_a || to_b || to_c) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
                     la_slot += to_a ? 1u : 0u;
                     lb_slot -= to_b ? 1u : 0u;
+                    lc_slot += to_c ? 1u : 0u;
                 }
                 gslot++;
                 rslot += need ? 1u : 0u;
@@ -2290,9 +2313,11 @@ __device__ __forceinline__ uint64_t haplotype_id60(const DeviceBatch& d, bool ac
 // slot when the id is hashed, so the record is written once, complete, and never read again on the device (a separate id kernel re-read
 // 0.5 GB of records per config C pass and ran at 9 % of the HBM roofline; here its ALU work overlaps the other waves' gathers).
 // !LIST_A: list B - flags, and the record where the window kernel reserved a slot (haplotypes carried into a splice merge); no id.
-template <int SEQ_CAP, bool LIST_A, int THREADS, int K3_ITEMS>   // THREADS: workgroup size; K3_ITEMS: list entries per lane, loaded together
-__global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceBatch d) {   // (list A's message buffers allow < 3 waves per SIMD anyway: registers are free there)
+template <int SEQ_CAP, int LIST, int THREADS, int K3_ITEMS>   // LIST: 0 = A, 1 = B, 2 = C; THREADS: workgroup size; K3_ITEMS: list entries per lane, loaded together
+__global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(DeviceBatch d) {   // (the message buffers of A and C allow < 3 waves per SIMD anyway: registers are free there)
     constexpr int K3_THREADS = THREADS;
+    constexpr bool LIST_A = LIST != 1;        // this launch hashes ids (lists A and C)
+    constexpr bool GENERAL = LIST == 2;       // ... and carries the general sequence walk (list C only: A and B hold simple windows)
     // the lane's LDS slot: ref | seq | germ while the sequences are built; list A re-uses it as the SHA-1 message buffer afterwards (the
     // sequences are in registers by then), so it is at least K3B_BUF_WORDS + 1 dwords there (odd stride: bank-conflict free)
     constexpr int K3_SLOT_DW = LIST_A ? ((K3Cfg<SEQ_CAP>::SLOT_DW > int(K3B_BUF_WORDS + 1) ? K3Cfg<SEQ_CAP>::SLOT_DW : int(K3B_BUF_WORDS + 1)) | 1) : K3Cfg<SEQ_CAP>::SLOT_DW;
@@ -2306,7 +2331,7 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
     const uint64_t part_size = 1ull << d.group_part_log2;
     // (the list's length and the pass's error word are needed only to VALIDATE entries: the first entries are fetched beside them, at
     //  addresses that depend on the workgroup's indices alone - one dependent load level less for every wave)
-    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST_A ? 8 : 12)], (unsigned long long)part_size);
+    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST == 0 ? 8 : LIST == 1 ? 12 : 20)], (unsigned long long)part_size);
     // Every wave takes K3_ITEMS tiles at once - K3_ITEMS list entries per lane - and issues the loads of ALL of them level by level (entry,
     // then window record + haplotype word, then reference bytes + columns + transcript, then the id's characters) before it works through
     // them one after the other: the kernel's time without the SHA-1 arithmetic was 0.91 of 1.42 ms, all of it dependent-load latency at
@@ -2329,7 +2354,7 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
         const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue: A upwards, B downwards)
         I.li = li;
         const uint64_t lidx = li < part_size ? li : part_size - 1;   // (inside the allocator's sub-range whatever the list's length: validated in load_window)
-        const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST_A ? lidx : part_size - 1 - lidx);
+        const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST == 1 ? part_size - 1 - lidx : lidx) + (LIST == 2 ? d.group_cap : 0ull);
         // the item K2 listed: group slot, window, reserved record slot (one 16-byte load)
         const uint4 item = d.k3_items[lpos];
         I.g = item.x; I.w = item.y; I.rec_pre = item.z;
@@ -2351,12 +2376,20 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
         if constexpr (LIST_A) { const TxDev* T = d.tx + ws.tx; I.id_off = T->id_off; I.id_len = T->id_len; }
         I.wref = d.ref_pool + ws.ref_off;
         I.mis = uint32_t(reinterpret_cast<uintptr_t>(I.wref) & 3u);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(I.wref - I.mis);
+        // wide loads at dword-aligned addresses (the kernel is bound by the number of scattered memory instructions as much as by their
+        // latency): the 36 reference bytes as 2 x 16 + 4, the first eight 12-byte columns as 6 x 16 bytes - 9 instructions instead of 25.
+        // (Columns behind the window's own are read too - the pools are padded - and never looked at: every use is guarded by ncols.)
+        static_assert(K3_REFCAP == 36 && sizeof(WinCol) == 12, "payload layout");
+        const K1Quad* src = reinterpret_cast<const K1Quad*>(I.wref - I.mis);
+        const K1Quad r0 = src[0], r1 = src[1];
+        I.refw[0] = r0.x; I.refw[1] = r0.y; I.refw[2] = r0.z; I.refw[3] = r0.w; I.refw[4] = r1.x; I.refw[5] = r1.y; I.refw[6] = r1.z; I.refw[7] = r1.w;
+        I.refw[8] = reinterpret_cast<const uint32_t*>(I.wref - I.mis)[8];
+        const K1Quad* cq = reinterpret_cast<const K1Quad*>(d.win_cols + ws.col_off);
+        uint32_t cw[24];
 #pragma unroll
-        for (int k = 0; k < K3_REFCAP / 4; k++) I.refw[k] = src[k];
-        const uint32_t ncols = ws.ncols, last_c = ncols ? ncols - 1 : 0;
+        for (int k = 0; k < 6; k++) { const K1Quad q = cq[k]; cw[4 * k] = q.x; cw[4 * k + 1] = q.y; cw[4 * k + 2] = q.z; cw[4 * k + 3] = q.w; }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const WinCol* wc = d.win_cols + ws.col_off + min(uint32_t(k), last_c); I.cp[k] = wc->pos; I.ci[k] = wc->info; }
+        for (int k = 0; k < 8; k++) { I.cp[k] = cw[3 * k + 1]; I.ci[k] = cw[3 * k + 2]; }   // WinCol {f, pos, info}
     };
     auto load_id_text = [&](K3In& I) __attribute__((always_inline)) {   // the id's first 20+ characters as six aligned dwords, fetched together (the pool is padded); used after the walk
         I.id_mis = 0;
@@ -2438,6 +2471,8 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
                 if ((hap >> (ncols - 1 - k)) & 1) { const WinCol wc = d.win_cols[ws.col_off + k]; substitute(k, wc.pos, wc.info); }
             ns = ngm = ws.wlen;
             j = vis;
+        } else if constexpr (!GENERAL) {
+            atomicOr(d.err, WD_INTERNAL);   // a window that needs the general walk in list A / B (the window kernels send those to list C)
         } else {
             uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
             // the first 8 columns (in walk order) are fetched up front so their loads overlap instead of forming a dependent chain
@@ -2551,7 +2586,7 @@ __global__ __launch_bounds__(THREADS, LIST_A ? 2 : 4) void k3_window_seq(DeviceB
             }
         }
         bool differs;
-        if (ws.flags & WSF_SIMPLE) differs = nsom > 0;   // a set somatic SNV always changes its byte (base or case)
+        if (!GENERAL || (ws.flags & WSF_SIMPLE)) differs = nsom > 0;   // a set somatic SNV always changes its byte (base or case)
         else {
             differs = seq_len != germ_len;
             if (!differs)
@@ -2938,23 +2973,23 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipS
     }
 }
 
-template <bool LIST_A>
+template <int LIST>
 static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t stream) {
     if (max_items == 0) return;
     // the grid covers the host's upper bound of the list lengths (surplus waves find nothing and leave; were the bound too low, the
     // waves walk the rest in turn - slower, still complete)
     // one grid row per allocator list; the lists fill evenly (allocator = workgroup index & 63 in the K2 kernels), a quarter more for the spread
-    // one wave per workgroup for both lists. (List A in 256-thread workgroups - four waves sharing one 2 KB decimal-text table, 12
+    // one wave per workgroup for all lists. (List A in 256-thread workgroups - four waves sharing one 2 KB decimal-text table, 12
     // instead of 11 waves per CU - measured 1.55 against 1.46 ms: the four waves of a workgroup start together and stay in step, gather
     // phase on gather phase. MP_K3A_THREADS=256 brings that form back for comparisons.)
     static const int a_threads = [] { const char* e = std::getenv("MP_K3A_THREADS"); return e && std::atoi(e) == 256 ? 256 : 64; }();
     static const int items = [] { const char* e = std::getenv("MP_K3_ITEMS"); return e && std::atoi(e) == 1 ? 1 : 2; }();   // list entries per lane (1: the round-2 form)
-    const int T = LIST_A && d.seq_cap <= 48 ? a_threads : K3_THREADS;
+    const int T = LIST == 0 && d.seq_cap <= 48 ? a_threads : K3_THREADS;
     const int U = d.seq_cap <= 48 ? items : 1;
     const uint64_t per_wave = uint64_t(T) * uint64_t(U);
     const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + per_wave;
     dim3 grid(uint32_t(std::min<uint64_t>((per_list + per_wave - 1) / per_wave, 0x7FFFFFFFull)), NPART), block(T);
-#define K3_LAUNCH(CAP, TT, UU) hipLaunchKernelGGL((k3_window_seq<CAP, LIST_A, TT, UU>), grid, block, 0, stream, d)
+#define K3_LAUNCH(CAP, TT, UU) hipLaunchKernelGGL((k3_window_seq<CAP, LIST, TT, UU>), grid, block, 0, stream, d)
     switch (d.seq_cap) {
         case 32: if (T == 256) { if (U == 2) K3_LAUNCH(32, 256, 2); else K3_LAUNCH(32, 256, 1); } else { if (U == 2) K3_LAUNCH(32, 64, 2); else K3_LAUNCH(32, 64, 1); } break;
         case 48: if (T == 256) { if (U == 2) K3_LAUNCH(48, 256, 2); else K3_LAUNCH(48, 256, 1); } else { if (U == 2) K3_LAUNCH(48, 64, 2); else K3_LAUNCH(48, 64, 1); } break;
@@ -2965,7 +3000,7 @@ static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t
 #undef K3_LAUNCH
     HIP_CHECK_LAUNCH();
 }
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, hipStream_t stream_a, hipStream_t stream_b) {
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c) {
     if (d.normal) {   // `microphaser normal`: every group has a record (all of them are in list A); ids by k3b_haplotype_ids afterwards
         if (max_list_a == 0) return;
         const uint64_t per_list = max_list_a / NPART + max_list_a / (4 * NPART) + K3_THREADS;
@@ -2980,8 +3015,9 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t ma
         HIP_CHECK_LAUNCH();
         return;
     }
-    launch_k3_list<true>(d, max_list_a, stream_a);    // sequences + records + ids
-    launch_k3_list<false>(d, max_list_b, stream_b);   // flags only; independent of list A's groups, may run beside it
+    launch_k3_list<0>(d, max_list_a, stream_a);   // simple windows: sequences + records + ids
+    launch_k3_list<1>(d, max_list_b, stream_b);   // simple windows: flags, carried records; independent of list A's groups, may run beside it
+    launch_k3_list<2>(d, max_list_c, stream_c);   // windows that need the general walk: everything
 }
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {

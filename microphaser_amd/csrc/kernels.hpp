@@ -49,6 +49,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const WinW* winw;
     const uint32_t* lane_win;
     const uint32_t* win_trivial;    // bit per window: WSF_SIMPLE && WSF_NOSTOP and no record demand of its own (plan.hpp WW_TRIVIAL)
+    const uint32_t* win_simple;     // bit per window: WSF_SIMPLE
     uint32_t n_lane_small, n_lane_all, lane_on, n_lane_mid;   // winw[0, small): <= 6 columns, [small, mid): 7-8, [mid, all): 9-16 (hash form)
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
     const ExonW* achunk_exons;      // the exon record of every admission work item, beside it (one load level less in a latency-bound kernel)
@@ -67,14 +68,15 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     // K2 output
     WinDyn* win_dyn;
     Group* groups;
-    uint4* k3_items;              // K2 -> K3: per allocator two dense lists of 16-byte items {group slot, window, record slot K2 reserved or 0xFFFFFFFF, 0}: list A
-                                  // (with a record slot) upwards from the sub-range's start, list B downwards from its end (kernels.hip k3_enqueue)
+    uint4* k3_items;              // K2 -> K3: per allocator three dense lists of 16-byte items {group slot, window, record slot K2 reserved or 0xFFFFFFFF, 0}: list A
+                                  // (ids hashed) upwards from the sub-range's start, list B downwards from its end, list C (windows whose sequences need the
+                                  // general walk) upwards in a second array of the same size behind the first (kernels.hip k3_enqueue)
     uint32_t* want_recs;          // normal mode, K3n: NPART dense lists of the records that need a SHA-1 id (K3b runs over them)
     // Output slots are handed out by NPART independent allocators (a wave uses allocator blockIdx & (NPART - 1)), each with
     // its own cursors in their own 128-byte lines and its own power-of-two sub-range of the output arrays: slot =
     // (partition << log2 size) + offset. One shared cursor serialises in L2 at ~60 atomics/us - with one wave per run of
     // windows that alone would bound the replay.
-    unsigned long long* cursors;  // [p * 32] group-slot cursor of partition p, [p * 32 + 8] / [p * 32 + 12] length of its K3 lists A / B, [p * 32 + 16] record-slot
+    unsigned long long* cursors;  // [p * 32] group-slot cursor of partition p, [p * 32 + 8] / [p * 32 + 12] / [p * 32 + 20] length of its K3 lists A / B / C, [p * 32 + 16] record-slot
                                   // cursor, [p * 32 + 24] somatic: ids hashed by K3's workgroups & 63 == p (statistics); normal: length of K3n's wanted list p
     uint32_t group_part_log2, rec_part_log2;
     uint64_t group_cap, rec_cap;  // NPART << log2
@@ -95,9 +97,10 @@ void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream);   // K2w, 
 void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide, hipStream_t stream_hash);
 // K3 / K3b: one grid row per output allocator; a row reads its list's length from the allocator's cursor on the device, the host only
 // passes an upper bound of the total that sizes the rows.
-// somatic: two launches - list A (sequences, records AND their SHA-1 ids) and list B (flags only) - independent, may go to two streams;
+// somatic: three launches - list A (simple windows: sequences, records AND their SHA-1 ids), list B (simple windows: flags, carried records) and list C
+// (windows that need the general sequence walk: everything) - independent, may go to three streams;
 // normal: k3_window_seq_normal over list A on stream_a, ids by launch_k3b_haplotype_ids afterwards
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, hipStream_t stream_a, hipStream_t stream_b);
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c);
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream);   // `microphaser normal` only
 
 }  // namespace mp

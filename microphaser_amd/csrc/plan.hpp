@@ -107,6 +107,7 @@ struct WinW {
 static_assert(sizeof(WinW) == 32, "WinW layout");
 enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17,
                   WW_TRIVIAL = 1u << 18,     // WSF_SIMPLE && WSF_NOSTOP and no record demand of its own: a group without a somatic column is settled by K2l
+                  WW_SIMPLE = 1u << 20,      // WSF_SIMPLE: K3 builds the window's sequences by byte substitution; the groups of other windows go to K3's list C
                   WW_ALL_IDS = 1u << 19 };   // WS_ALL_IDS: every haplotype of the window gets an id (indel / frameshift context); without it only a
                                              // haplotype that sets a somatic column is hashed - the others go to K3's list B even when they need a record
 struct RowRecA {         // K2a output per (ExonW, read), first half (the second is the 64-bit support mask)
@@ -188,7 +189,8 @@ struct WinDyn {          // K2 output per printing step
     uint32_t flags;      // WD_*
 };
 enum : uint32_t { WD_DONE = 1, WD_ROW_OVERFLOW = 2, WD_GROUP_OVERFLOW = 4, WD_REC_OVERFLOW = 8,
-                  WD_EPOCH_OVERFLOW = 16, WD_HAP_OVERFLOW = 32 };  // normal mode: column-epoch ring / haplotype table full
+                  WD_EPOCH_OVERFLOW = 16, WD_HAP_OVERFLOW = 32,    // normal mode: column-epoch ring / haplotype table full
+                  WD_INTERNAL = 64 };                              // a kernel met something the planner promised it would not
 
 struct Group {           // K2 output: one distinct (haplotype, frame.0, frame.1 != 0) key of one window, ascending
     uint64_t hap;
