@@ -223,9 +223,10 @@ constexpr uint32_t REC_CHUNK = 128;     // HapRec slots per allocation (>= 64: o
 // most); one atomic instruction per call (two lanes, one per list). The lane-per-window kernel settles most groups itself (no somatic
 // column set, simple window without a possible stop: GroupSum = {GS_VALID}) and lists only the rest.
 __device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, bool on, uint64_t slot, uint32_t win, uint32_t rec) {
-    // list C: the groups of windows whose sequences need the general walk (indel / multi-allelic columns, long windows). One such lane
-    // makes its whole K3 wave run the per-base walk - at config C 0.8 % of the windows did that to 40 % of the waves - so they get a
-    // list (and a launch) of their own, in the second half of k3_items. (`normal` mode has one K3 kernel for everything: list A.)
+    // list C: the groups of windows whose sequences need the general walk (indel / multi-allelic columns, long windows) or a stop scan
+    // (a stop codon is possible). One such lane makes its whole K3 wave run the per-base walk / the codon loop - at config C 0.8 % of the
+    // windows did the former to 40 % of the waves, 6 % the latter to nearly all - so they get a list (and a launch) of their own, in the
+    // second half of k3_items. (`normal` mode has one K3 kernel for everything: list A.)
     const uint32_t wbit = on ? d.win_simple[win >> 5] : 0u;
     const bool simple = d.normal || ((wbit >> (win & 31u)) & 1u);
     const bool to_c = on && !simple;
@@ -1053,8 +1054,8 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         const uint64_t la_base = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
         const uint64_t lb_base = (uint64_t(rdlane(uint32_t(got >> 32), 3)) << 32) | rdlane(uint32_t(got), 3);
         const uint64_t lc_base = (uint64_t(rdlane(uint32_t(got >> 32), 4)) << 32) | rdlane(uint32_t(got), 4);
-        uint64_t lc_slot = d.group_cap + gpart_lo + lc_base + (scanc - nc);                   // list C: upwards in the second array
-        uint64_t la_slot = gpart_lo + la_base + ((scanb & 0xFFFFu) - na);                     // list A: upwards from the sub-range's first entry
+        // list A: upwards from the sub-range's first entry; list C: upwards in the second array (a lane needs one of the two)
+        uint64_t up_slot = simple ? gpart_lo + la_base + ((scanb & 0xFFFFu) - na) : d.group_cap + gpart_lo + lc_base + (scanc - nc);
         uint64_t lb_slot = gpart_lo + gpart_size - 1 - (lb_base + ((scanb >> 16) - nb));      // list B: downwards from its last
         // (the list cursors also count the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
         //  still find a list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
@@ -1079,12 +1080,12 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                     // (one store at a selected address and plain cursor arithmetic: with a store per branch the compiler kept the two cursors
                     //  in a dynamically indexed scratch array - 0.3 GB of private-memory traffic per pass)
                     const bool hashes = (uint64_t(key) & som_mask) != 0 || (need_all && all_ids);   // its id will be hashed
-                    const bool to_a = simple && hashes, to_b = simple && !hashes && !settled, to_c = !simple;
-                    const uint64_t at = to_a ? la_slot : to_b ? lb_slot : lc_slot;
-                    if (to_a || to_b || to_c) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
-                    la_slot += to_a ? 1u : 0u;
+                    // (a lane's window is simple or it is not: the lane walks list A or list C - one upward cursor - and list B)
+                    const bool to_up = !simple || hashes, to_b = simple && !hashes && !settled;
+                    const uint64_t at = to_up ? up_slot : lb_slot;
+                    if (to_up || to_b) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
+                    up_slot += to_up ? 1u : 0u;
                     lb_slot -= to_b ? 1u : 0u;
-                    lc_slot += to_c ? 1u : 0u;
                 }
                 gslot++;
                 rslot += need ? 1u : 0u;
@@ -2576,7 +2577,9 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
         else if (ws.splice_pos == 0 && !insertion) nhi = this_len;
         bool stop = false;
         uint32_t nlen = nhi - nlo;
-        if (nlen >= 3 && !(ws.flags & WSF_NOSTOP)) {   // WSF_NOSTOP: planner proved that no haplotype of this window can hold a stop
+        if constexpr (!GENERAL) {   // lists A / B hold windows for which the planner proved that no haplotype can hold a stop (WSF_NOSTOP): no codon loop in these kernels
+            if (!(ws.flags & WSF_NOSTOP)) atomicOr(d.err, WD_INTERNAL);
+        } else if (nlen >= 3 && !(ws.flags & WSF_NOSTOP)) {   // WSF_NOSTOP: planner proved that no haplotype of this window can hold a stop
             if (!is_rev) {
                 for (uint32_t c = 0; c + 3 <= nlen; c += 3)
                     if (stop_codon_at(seq + nlo, c, true)) { stop = true; break; }

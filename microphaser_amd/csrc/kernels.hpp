@@ -49,7 +49,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const WinW* winw;
     const uint32_t* lane_win;
     const uint32_t* win_trivial;    // bit per window: WSF_SIMPLE && WSF_NOSTOP and no record demand of its own (plan.hpp WW_TRIVIAL)
-    const uint32_t* win_simple;     // bit per window: WSF_SIMPLE
+    const uint32_t* win_simple;     // bit per window: WSF_SIMPLE && WSF_NOSTOP
     uint32_t n_lane_small, n_lane_all, lane_on, n_lane_mid;   // winw[0, small): <= 6 columns, [small, mid): 7-8, [mid, all): 9-16 (hash form)
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
     const ExonW* achunk_exons;      // the exon record of every admission work item, beside it (one load level less in a latency-bound kernel)

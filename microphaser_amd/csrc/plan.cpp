@@ -475,7 +475,7 @@ static void route_lane_windows(Batch& b) {
     b.win_simple.assign(b.wins.size() / 32 + 2, 0u);
     for (size_t w = 0; w < b.wins.size(); w++) {
         const WinStatic& ws = b.wins[w];
-        if (ws.flags & WSF_SIMPLE) b.win_simple[w >> 5] |= 1u << (w & 31);
+        if ((ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP)) b.win_simple[w >> 5] |= 1u << (w & 31);
         if (!b.normal && (ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP) && !(ws.need_recs & WS_MASK) && !(b.steps[ws.step].flags & SF_NEED_RECS))
             b.win_trivial[w >> 5] |= 1u << (w & 31);
     }
@@ -498,7 +498,7 @@ static void route_lane_windows(Batch& b) {
                 w.rr_lo = rn ? e.adm_off + (b.step_rlo[si] - e.read_lo) : 0;
                 const bool trivial = (b.win_trivial[st.win >> 5] >> (st.win & 31)) & 1u;
                 w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u) | (trivial ? WW_TRIVIAL : 0u) |
-                         ((b.wins[st.win].need_recs & WS_ALL_IDS) ? WW_ALL_IDS : 0u) | ((b.wins[st.win].flags & WSF_SIMPLE) ? WW_SIMPLE : 0u);
+                         ((b.wins[st.win].need_recs & WS_ALL_IDS) ? WW_ALL_IDS : 0u) | (((b.wins[st.win].flags & WSF_SIMPLE) && (b.wins[st.win].flags & WSF_NOSTOP)) ? WW_SIMPLE : 0u);
                 w.wkey = rev ? ~st.sso : st.sso + uint32_t(st.wlen);
                 w.step = si;
                 w.col_hi = st.col_hi;

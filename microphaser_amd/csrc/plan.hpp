@@ -107,7 +107,8 @@ struct WinW {
 static_assert(sizeof(WinW) == 32, "WinW layout");
 enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17,
                   WW_TRIVIAL = 1u << 18,     // WSF_SIMPLE && WSF_NOSTOP and no record demand of its own: a group without a somatic column is settled by K2l
-                  WW_SIMPLE = 1u << 20,      // WSF_SIMPLE: K3 builds the window's sequences by byte substitution; the groups of other windows go to K3's list C
+                  WW_SIMPLE = 1u << 20,      // WSF_SIMPLE && WSF_NOSTOP: K3 builds the window's sequences by byte substitution and needs no stop scan; the groups of
+                                             // other windows go to K3's list C (one such lane would make its whole K3 wave run the per-base walk / the codon loop)
                   WW_ALL_IDS = 1u << 19 };   // WS_ALL_IDS: every haplotype of the window gets an id (indel / frameshift context); without it only a
                                              // haplotype that sets a somatic column is hashed - the others go to K3's list B even when they need a record
 struct RowRecA {         // K2a output per (ExonW, read), first half (the second is the 64-bit support mask)
