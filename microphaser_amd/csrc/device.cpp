@@ -270,10 +270,13 @@ void DeviceContext::upload_impl(const Batch& b) {
     while ((uint64_t(NPART) << glog_) < g_need + g_need / 4) glog_++;
     while ((uint64_t(NPART) << rlog_) < r_need + r_need / 4) rlog_++;
     if (std::getenv("MP_TEST_SMALL_CAPS")) glog_ = rlog_ = 8;   // tests: start far too small, so that run() has to grow the buffers
+    d_.win_blobs = nullptr;
+    if (!b.normal && d_.n_wins) { d_.win_blobs = static_cast<WinBlob*>(dalloc(size_t(d_.n_wins) * sizeof(WinBlob))); allocs_.push_back(d_.win_blobs); }
     alloc_outputs();
     xfer(pending_up_, true);
     pending_up_.clear();
     achunk_exons_ = PodVec<ExonW>();
+    if (d_.win_blobs) launch_k0_pack_windows(d_, stream_);   // (once per batch: K3's per-window records, plan.hpp WinBlob)
     HIP_OK(hipStreamSynchronize(stream_));
 }
 

@@ -24,6 +24,33 @@ namespace mp {
 
 [[noreturn]] void throw_hip(hipError_t e, const char* file, int line);
 
+// ====================================================================== K0 (layout, once per batch)
+__global__ __launch_bounds__(256) void k0_pack_windows(DeviceBatch d) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= d.n_wins) return;
+    WinBlob B;
+    B.ws = d.wins[w];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d.ref_pool + (B.ws.ref_off & ~3u));   // (the pool is padded and 256-byte aligned)
+#pragma unroll
+    for (int k = 0; k < 10; k++) B.ref[k] = src[k];
+    const uint32_t ncols = B.ws.ncols;
+#pragma unroll
+    for (uint32_t k = 0; k < WINBLOB_COLS; k++) {
+        const WinCol c = d.win_cols[B.ws.col_off + (k < ncols ? k : 0u)];
+        B.cpi[2 * k] = k < ncols ? c.pos : 0xFFFFFFFFu;
+        B.cpi[2 * k + 1] = k < ncols ? c.info : 0u;
+    }
+    const TxDev T = d.tx[B.ws.tx];
+    B.id_off = T.id_off; B.id_len = T.id_len;
+    d.win_blobs[w] = B;
+}
+void launch_k0_pack_windows(const DeviceBatch& d, hipStream_t stream) {
+    if (!d.n_wins || !d.win_blobs) return;
+    hipLaunchKernelGGL(k0_pack_windows, dim3((d.n_wins + 255) / 256), dim3(256), 0, stream, d);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__);
+}
+
 // ====================================================================== K1
 // rust-htslib CigarStringView::read_pos(ref_pos, false, false), see model.hpp cigar_read_pos.
 __device__ __attribute__((noinline)) int cigar_read_pos_dev(const uint32_t* cig, uint32_t ncig, uint32_t read_start, uint32_t ref_pos) {
@@ -2360,37 +2387,37 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
         const uint4 item = d.k3_items[lpos];
         I.g = item.x; I.w = item.y; I.rec_pre = item.z;
     };
-    auto load_window = [&](K3In& I) __attribute__((always_inline)) {   // the window's static record and the haplotype word (both addresses come from the item)
+    auto load_window = [&](K3In& I) __attribute__((always_inline)) {   // the window's record (plan.hpp WinBlob: eight 16-byte loads) and the haplotype word (both addresses come from the item)
         I.in_list = I.li < n_slots;
         if (!I.in_list) { I.g = 0; I.w = 0xFFFFFFFFu; I.rec_pre = 0xFFFFFFFFu; }
         if (I.w != 0xFFFFFFFFu && I.w >= d.n_wins) { I.w = 0xFFFFFFFFu; I.g = 0; }   // (never true for a written entry)
         if (I.g >= d.group_cap) I.g = 0;
-        I.ws = d.wins[I.w != 0xFFFFFFFFu ? I.w : 0u];
+        const uint4* bp = reinterpret_cast<const uint4*>(d.win_blobs + (I.w != 0xFFFFFFFFu ? I.w : 0u));
+        uint4 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = bp[k];
         I.hap = d.groups[I.g].hap;
+        static_assert(sizeof(WinStatic) == 32 && K3_REFCAP == 36, "WinBlob unpacking");
+        uint32_t wsw[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+        __builtin_memcpy(&I.ws, wsw, 32);
+        I.refw[0] = q[2].x; I.refw[1] = q[2].y; I.refw[2] = q[2].z; I.refw[3] = q[2].w; I.refw[4] = q[3].x; I.refw[5] = q[3].y; I.refw[6] = q[3].z; I.refw[7] = q[3].w;
+        I.refw[8] = q[4].x;   // (q[4].y = the tenth reference dword: K3_REFCAP is 36 bytes)
+        const uint32_t cw[12] = {q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y};
+#pragma unroll
+        for (int k = 0; k < int(WINBLOB_COLS); k++) { I.cp[k] = cw[2 * k]; I.ci[k] = cw[2 * k + 1]; }
+        I.id_off = q[7].z; I.id_len = q[7].w;
     };
     auto load_payload = [&](K3In& I) __attribute__((always_inline)) {
-        // (all loads of this level - the transcript's id position first, the staged reference dwords and the first eight columns - are
-        //  issued together and unconditionally, at clamped addresses into padded pools: a load under a branch makes the compiler drain the
-        //  memory counter at the join)
+        // what the record does not hold: the window's seventh and eighth column (a wave-uniform branch: most windows have at most six)
         const WinStatic& ws = I.ws;
-        I.id_off = 0; I.id_len = 0;
-        if constexpr (LIST_A) { const TxDev* T = d.tx + ws.tx; I.id_off = T->id_off; I.id_len = T->id_len; }
         I.wref = d.ref_pool + ws.ref_off;
-        I.mis = uint32_t(reinterpret_cast<uintptr_t>(I.wref) & 3u);
-        // wide loads at dword-aligned addresses (the kernel is bound by the number of scattered memory instructions as much as by their
-        // latency): the 36 reference bytes as 2 x 16 + 4, the first eight 12-byte columns as 6 x 16 bytes - 9 instructions instead of 25.
-        // (Columns behind the window's own are read too - the pools are padded - and never looked at: every use is guarded by ncols.)
-        static_assert(K3_REFCAP == 36 && sizeof(WinCol) == 12, "payload layout");
-        const K1Quad* src = reinterpret_cast<const K1Quad*>(I.wref - I.mis);
-        const K1Quad r0 = src[0], r1 = src[1];
-        I.refw[0] = r0.x; I.refw[1] = r0.y; I.refw[2] = r0.z; I.refw[3] = r0.w; I.refw[4] = r1.x; I.refw[5] = r1.y; I.refw[6] = r1.z; I.refw[7] = r1.w;
-        I.refw[8] = reinterpret_cast<const uint32_t*>(I.wref - I.mis)[8];
-        const K1Quad* cq = reinterpret_cast<const K1Quad*>(d.win_cols + ws.col_off);
-        uint32_t cw[24];
+        I.mis = ws.ref_off & 3u;   // (= the address's misalignment: the pool is 256-byte aligned)
+        I.cp[6] = I.cp[7] = 0xFFFFFFFFu; I.ci[6] = I.ci[7] = 0;
+        if (__ballot(I.w != 0xFFFFFFFFu && ws.ncols > WINBLOB_COLS)) {
+            const uint32_t ncols = ws.ncols, last_c = ncols ? ncols - 1 : 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { const K1Quad q = cq[k]; cw[4 * k] = q.x; cw[4 * k + 1] = q.y; cw[4 * k + 2] = q.z; cw[4 * k + 3] = q.w; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { I.cp[k] = cw[3 * k + 1]; I.ci[k] = cw[3 * k + 2]; }   // WinCol {f, pos, info}
+            for (uint32_t k = WINBLOB_COLS; k < 8; k++) { const WinCol* wc = d.win_cols + ws.col_off + min(k, last_c); I.cp[k] = wc->pos; I.ci[k] = wc->info; }
+        }
     };
     auto load_id_text = [&](K3In& I) __attribute__((always_inline)) {   // the id's first 20+ characters as six aligned dwords, fetched together (the pool is padded); used after the walk
         I.id_mis = 0;
@@ -2984,20 +3011,19 @@ static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t
     // one grid row per allocator list; the lists fill evenly (allocator = workgroup index & 63 in the K2 kernels), a quarter more for the spread
     // one wave per workgroup for all lists. (List A in 256-thread workgroups - four waves sharing one 2 KB decimal-text table, 12
     // instead of 11 waves per CU - measured 1.55 against 1.46 ms: the four waves of a workgroup start together and stay in step, gather
-    // phase on gather phase. MP_K3A_THREADS=256 brings that form back for comparisons.)
-    static const int a_threads = [] { const char* e = std::getenv("MP_K3A_THREADS"); return e && std::atoi(e) == 256 ? 256 : 64; }();
+    // phase on gather phase; the instantiations were dropped again.)
     static const int items = [] { const char* e = std::getenv("MP_K3_ITEMS"); return e && std::atoi(e) == 1 ? 1 : 2; }();   // list entries per lane (1: the round-2 form)
-    const int T = LIST == 0 && d.seq_cap <= 48 ? a_threads : K3_THREADS;
+    const int T = K3_THREADS;
     const int U = d.seq_cap <= 48 ? items : 1;
     const uint64_t per_wave = uint64_t(T) * uint64_t(U);
     const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + per_wave;
     dim3 grid(uint32_t(std::min<uint64_t>((per_list + per_wave - 1) / per_wave, 0x7FFFFFFFull)), NPART), block(T);
-#define K3_LAUNCH(CAP, TT, UU) hipLaunchKernelGGL((k3_window_seq<CAP, LIST, TT, UU>), grid, block, 0, stream, d)
+#define K3_LAUNCH(CAP, UU) hipLaunchKernelGGL((k3_window_seq<CAP, LIST, K3_THREADS, UU>), grid, block, 0, stream, d)
     switch (d.seq_cap) {
-        case 32: if (T == 256) { if (U == 2) K3_LAUNCH(32, 256, 2); else K3_LAUNCH(32, 256, 1); } else { if (U == 2) K3_LAUNCH(32, 64, 2); else K3_LAUNCH(32, 64, 1); } break;
-        case 48: if (T == 256) { if (U == 2) K3_LAUNCH(48, 256, 2); else K3_LAUNCH(48, 256, 1); } else { if (U == 2) K3_LAUNCH(48, 64, 2); else K3_LAUNCH(48, 64, 1); } break;
-        case 112: K3_LAUNCH(112, 64, 1); break;
-        case 240: K3_LAUNCH(240, 64, 1); break;
+        case 32: if (U == 2) K3_LAUNCH(32, 2); else K3_LAUNCH(32, 1); break;
+        case 48: if (U == 2) K3_LAUNCH(48, 2); else K3_LAUNCH(48, 1); break;
+        case 112: K3_LAUNCH(112, 1); break;
+        case 240: K3_LAUNCH(240, 1); break;
         default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
 #undef K3_LAUNCH

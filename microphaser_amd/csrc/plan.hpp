@@ -176,6 +176,19 @@ constexpr uint8_t WSF_SIMPLE = 1;     // (replaces SF_PRINT, always set for a wi
                                       // prefix of the columns (walk order), all SNVs at strictly increasing positions inside the window - the
                                       // next column, if any, lies behind the cursor or beyond the window (a stale column, :1159) and blocks
                                       // everything after it: K3 builds the sequences by byte substitution instead of walking
+// What K3 reads per listed haplotype, in ONE 128-byte record per window (built on the device once per batch by k0_pack_windows from wins, the
+// reference bytes, win_cols and the transcripts: a layout transformation, not part of the pass). K3 was bound by the number of scattered
+// loads and their dependent levels - entry -> window record -> reference bytes / columns / transcript -> id text; with the record the
+// second and third level are eight 16-byte loads of two adjacent cache lines.
+struct WinBlob {
+    WinStatic ws;
+    uint32_t ref[10];    // the 40 bytes from the dword at or before the window's first reference base (ws.ref_off & ~3)
+    uint32_t cpi[12];    // (pos, info) of the window's first six columns, deque order (the others: win_cols)
+    uint32_t id_off, id_len;   // the transcript's id in str_pool
+};
+static_assert(sizeof(WinBlob) == 128, "WinBlob layout");
+constexpr uint32_t WINBLOB_COLS = 6;
+
 struct WinCol {          // one live variant column of a printing window
     uint32_t f;          // gene-relative forward variant index
     uint32_t pos;        // v_pos
