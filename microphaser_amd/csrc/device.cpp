@@ -272,10 +272,17 @@ void DeviceContext::upload_impl(const Batch& b) {
     if (std::getenv("MP_TEST_SMALL_CAPS")) glog_ = rlog_ = 8;   // tests: start far too small, so that run() has to grow the buffers
     d_.win_blobs = nullptr;
     if (!b.normal && d_.n_wins) { d_.win_blobs = static_cast<WinBlob*>(dalloc(size_t(d_.n_wins) * sizeof(WinBlob))); allocs_.push_back(d_.win_blobs); }
+    d_.exons_a = nullptr; d_.adm_map = nullptr;
+    d_.k2a_flat = !std::getenv("MP_K2A_CHUNKS") && d_.n_exons_w && b.n_adm && b.n_adm < 0xFFFFFF00ull ? 1u : 0u;
+    if (d_.k2a_flat) {
+        d_.exons_a = static_cast<ExonA*>(dalloc(size_t(d_.n_exons_w) * sizeof(ExonA))); allocs_.push_back(d_.exons_a);
+        d_.adm_map = static_cast<AdmMap*>(dalloc(size_t(b.n_adm) * sizeof(AdmMap))); allocs_.push_back(d_.adm_map);
+    }
     alloc_outputs();
     xfer(pending_up_, true);
     pending_up_.clear();
     achunk_exons_ = PodVec<ExonW>();
+    if (d_.k2a_flat) launch_k0_pack_admission(d_, stream_);
     if (d_.win_blobs) launch_k0_pack_windows(d_, stream_);   // (once per batch: K3's per-window records, plan.hpp WinBlob)
     HIP_OK(hipStreamSynchronize(stream_));
 }

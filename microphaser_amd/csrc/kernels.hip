@@ -19,12 +19,19 @@
 
 namespace mp {
 
+// This file is compiled in parts (Makefile: -DMP_KPART=0..5, one object each, side by side): every part holds all the templates and
+// the launchers - hence the kernel instantiations - of its share. Without MP_KPART it is one translation unit.
+#ifndef MP_KPART
+#define MP_KPART -1
+#endif
+#define MP_IN_PART(n) (MP_KPART == -1 || MP_KPART == (n))
 #define HIP_CHECK_LAUNCH() \
     do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { throw_hip(e_, __FILE__, __LINE__); } } while (0)
 
 [[noreturn]] void throw_hip(hipError_t e, const char* file, int line);
 
 // ====================================================================== K0 (layout, once per batch)
+#if MP_IN_PART(0)
 __global__ __launch_bounds__(256) void k0_pack_windows(DeviceBatch d) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= d.n_wins) return;
@@ -50,6 +57,7 @@ void launch_k0_pack_windows(const DeviceBatch& d, hipStream_t stream) {
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__);
 }
+#endif
 
 // ====================================================================== K1
 // rust-htslib CigarStringView::read_pos(ref_pos, false, false), see model.hpp cigar_read_pos.
@@ -865,6 +873,184 @@ __global__ __launch_bounds__(64) void k2a_admission(DeviceBatch d) {
     }
 }
 
+// The flat form: a lane per admission-table entry (exon, read), whatever exon it belongs to - the chunk form above leaves a third of its
+// lanes empty (60 candidate reads per exon on average) and every wave has ONE chain of dependent loads in flight; here a lane holds
+// ITEMS entries and the loads of each level - entry -> exon fields + read fields -> the first step to try - go out for all of them
+// before anything is used. Same decisions, same outputs (the table index IS the entry).
+#if MP_IN_PART(0)
+__global__ __launch_bounds__(256) void k0_pack_admission(DeviceBatch d) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (i < d.n_exons_w) {
+        const ExonW e = d.exons_w[i];
+        ExonA a;
+        a.step_off = e.step_off; a.n_steps = e.n_steps; a.unit_steps = e.unit_steps; a.sso0 = e.sso0;
+        a.sso1 = e.sso1; a.first_key_lo = e.first_key_lo; a.range = e.range; a.tr0 = e.tr0;
+        a.f0 = e.f0; a.sl_f_lo = e.sl_f_lo; a.sl_f_hi = e.sl_f_hi; a.flags = (e.strand ? 1u : 0u) | (e.consumers << 8);
+        a.adm_off = e.adm_off; a.read0 = e.rbase + e.read_lo; a.pad0 = a.pad1 = 0;
+        d.exons_a[i] = a;
+    }
+    if (i < d.n_adm) {   // the last exon whose first entry is at or before this one (offsets ascend; exons without reads share their successor's)
+        uint32_t lo = 0, hi = d.n_exons_w;   // exons_w[lo].adm_off <= i < exons_w[hi].adm_off (hi == n: beyond the table)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (d.exons_w[mid].adm_off <= i) lo = mid; else hi = mid;
+        }
+        const ExonW* e = d.exons_w + lo;
+        AdmMap m;
+        m.exon = lo;
+        m.read = e->rbase + e->read_lo + uint32_t(i - e->adm_off);
+        d.adm_map[i] = m;
+    }
+}
+void launch_k0_pack_admission(const DeviceBatch& d, hipStream_t stream) {
+    if (!d.k2a_flat) return;
+    const uint64_t n = d.n_adm > d.n_exons_w ? d.n_adm : d.n_exons_w;
+    hipLaunchKernelGGL(k0_pack_admission, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, stream, d);
+    HIP_CHECK_LAUNCH();
+}
+#endif
+
+template <int W, int ITEMS>
+__global__ __launch_bounds__(64) void k2a_admission_flat(DeviceBatch d) {
+    struct In {
+        bool on, rev, go;
+        uint32_t entry, t;
+        AdmMap xr;
+        ExonA e;
+        uint32_t start, end, rvl;
+        uint64_t sup[W], dirty[W];
+        uint32_t s_sso, s_col_hi, s_w4, s_w5, nc;
+        AdmEntry out;
+    };
+    const uint32_t n_adm = uint32_t(d.n_adm);
+    auto load_entry = [&](In& I, uint32_t tile) __attribute__((always_inline)) {
+        const uint64_t entry = uint64_t(tile) * 64u + threadIdx.x;
+        I.on = entry < n_adm;
+        I.entry = I.on ? uint32_t(entry) : n_adm - 1u;   // (idle lanes repeat the last entry and store nothing)
+        I.xr = d.adm_map[I.entry];
+    };
+    auto load_fields = [&](In& I) __attribute__((always_inline)) {
+        const uint4* ep = reinterpret_cast<const uint4*>(d.exons_a + I.xr.exon);
+        const uint4 q0 = ep[0], q1 = ep[1], q2 = ep[2], q3 = ep[3];
+        const uint32_t gi = I.xr.read;
+        I.start = d.r_pos[gi]; I.end = d.r_end[gi]; I.rvl = d.r_varlo[gi];
+#pragma unroll
+        for (int w = 0; w < W; w++) { I.sup[w] = d.r_sup[uint64_t(gi) * W + w]; I.dirty[w] = d.r_lq[uint64_t(gi) * W + w]; }
+        I.e.step_off = q0.x; I.e.n_steps = q0.y; I.e.unit_steps = q0.z; I.e.sso0 = q0.w;
+        I.e.sso1 = q1.x; I.e.first_key_lo = q1.y; I.e.range = q1.z; I.e.tr0 = q1.w;
+        I.e.f0 = q2.x; I.e.sl_f_lo = q2.y; I.e.sl_f_hi = q2.z; I.e.flags = q2.w;
+        I.e.adm_off = q3.x; I.e.read0 = q3.y;
+    };
+    auto load_step = [&](In& I, uint32_t si) __attribute__((always_inline)) {   // the fields push_read's decision needs, in one round of loads
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + si);
+        I.s_sso = sp[0]; I.s_col_hi = sp[2]; I.s_w4 = sp[4]; I.s_w5 = sp[5];   // [4]: cand_n | wlen << 16 | n_del << 24; [5]: n_add | ...
+        I.nc = d.step_ncols[si];
+    };
+    auto eval_step = [&](In& I, uint32_t si) __attribute__((always_inline)) -> bool {   // push_read at step si (after shrink_left, before extend_right), branch-free
+        const uint32_t s_wlen = (I.s_w4 >> 16) & 0xFFu, s_nadd = I.s_w5 & 0xFFu;
+        const uint32_t tlo = I.s_col_hi - I.nc, thi = I.s_col_hi - s_nadd;
+        uint32_t flo = tlo, fhi = thi;
+        if (I.rev) { flo = I.e.f0 - (thi - 1 - I.e.tr0); fhi = I.e.f0 - (tlo - I.e.tr0) + 1; }
+        if (thi <= tlo) flo = fhi = 0;
+        const bool encloses = !(I.end < I.s_sso + s_wlen) & !(I.start > I.s_sso);
+        const bool clean = !mask_hits<W>(I.dirty, flo, fhi, I.rvl);
+        const bool ok = encloses & clean;
+        I.out.ord = ok ? si : I.out.ord;
+        I.out.seen_lo = ok ? tlo : I.out.seen_lo;
+        return ok;
+    };
+    auto first_step = [&](In& I) __attribute__((always_inline)) {   // the first step at which the read is offered (:1191-1249), by arithmetic where the steps move by one nt
+        const ExonA& e = I.e;
+        I.rev = (e.flags & 1u) != 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) I.dirty[w] |= I.sup[w] & bit_range(e.sl_f_lo, e.sl_f_hi, I.rvl + 64u * w);   // low quality, or support of a start-loss variant
+        I.out.ord = 0xFFFFFFFFu; I.out.seen_lo = 0;
+        I.go = false; I.t = 0;
+        const uint32_t start = I.start;
+        if (!I.rev) {
+            if (start >= e.first_key_lo && start <= e.sso0) {
+                I.go = true;                                  // the first window's candidate range (:1229-1240)
+            } else if (start > e.sso0 && e.n_steps > 1 && start >= e.sso1) {
+                uint32_t t = 1 + (start - e.sso1);            // afterwards only the reads that start exactly at sso (:1241-1248)
+                if (t < e.unit_steps) { I.go = true; I.t = t; }
+                else if (t < e.n_steps) {
+                    uint32_t s_t = d.steps[e.step_off + t].sso;
+                    while (s_t > start && t > 1) s_t = d.steps[e.step_off + --t].sso;            // (never taken for unit steps)
+                    while (s_t < start && t + 1 < e.n_steps) s_t = d.steps[e.step_off + ++t].sso;
+                    if (s_t == start) { I.go = true; I.t = t; }
+                }
+            }
+        } else {
+            // candidate while sso - R <= start <= sso; sso never increases along the exon (one nt per step, repeats at the end)
+            const uint32_t top = start + e.range;
+            uint32_t t = e.sso0 > top ? e.sso0 - top : 0;   // first step with sso <= start + R if every step moved by one
+            if (t >= e.unit_steps) {                        // beyond the arithmetic stretch: look at the steps
+                if (t >= e.n_steps) t = e.n_steps - 1;
+                while (t > 0 && d.steps[e.step_off + t - 1].sso <= top) t--;
+                while (t < e.n_steps && d.steps[e.step_off + t].sso > top) t++;
+            }
+            I.go = t < e.n_steps; I.t = I.go ? t : 0;
+        }
+    };
+    auto finish = [&](In& I) __attribute__((always_inline)) {
+        const ExonA& e = I.e;
+        if (I.go) {
+            if (!I.rev) eval_step(I, e.step_off + I.t);
+            else {
+                // offered again at every step until it is inserted or sso has passed its start (the first step's fields are already here)
+                uint32_t t = I.t;
+                for (;;) {
+                    if (I.s_sso < I.start) break;
+                    if (eval_step(I, e.step_off + t)) break;
+                    if (++t >= e.n_steps) break;
+                    load_step(I, e.step_off + t);
+                }
+            }
+        }
+        if (!I.on) return;
+        const uint32_t consumers = e.flags >> 8;
+        if (consumers & EW_WAVE) d.adm[I.entry] = I.out;
+        if constexpr (W == 1) {
+            if (d.lane_on && (consumers & EW_LANE)) {   // the same facts flattened for the lane-per-window kernel (plan.hpp RowRecA)
+                uint32_t bad_from = 0xFFFFFFFFu;
+                if (I.out.ord != 0xFFFFFFFFu) {
+                    const uint64_t dm = I.dirty[0];
+                    if (!I.rev) {
+                        const uint32_t from = max(I.out.seen_lo, I.rvl), sh = from - I.rvl;
+                        const uint64_t m = sh < 64 ? dm >> sh : 0ull;
+                        if (m) bad_from = from + uint32_t(__builtin_ctzll(m));
+                    } else {
+                        const uint32_t f_hi = e.f0 - (I.out.seen_lo - e.tr0);
+                        if (f_hi >= I.rvl) {
+                            const uint32_t rel = f_hi - I.rvl;
+                            const uint64_t m = rel >= 63 ? dm : (dm & ((2ull << rel) - 1ull));
+                            if (m) bad_from = e.tr0 + (e.f0 - (I.rvl + 63u - uint32_t(__builtin_clzll(m))));
+                        }
+                    }
+                }
+                RowRecA a;
+                a.key = I.rev ? ~I.start : I.end;
+                a.ord = I.out.ord;
+                a.bad_from = bad_from;
+                a.rvl = I.rvl;
+                d.rr_a[I.entry] = a;
+                d.rr_sup[I.entry] = I.sup[0];
+            }
+        }
+    };
+    In in0, in1;
+    load_entry(in0, blockIdx.x * ITEMS);
+    if constexpr (ITEMS == 2) load_entry(in1, blockIdx.x * ITEMS + 1);
+    load_fields(in0);
+    if constexpr (ITEMS == 2) load_fields(in1);
+    first_step(in0);
+    if constexpr (ITEMS == 2) first_step(in1);
+    load_step(in0, in0.e.step_off + in0.t);   // (t = 0 where no step is tried: a valid address, the fields unused)
+    if constexpr (ITEMS == 2) load_step(in1, in1.e.step_off + in1.t);
+    finish(in0);
+    if constexpr (ITEMS == 2) finish(in1);
+}
+
 // ====================================================================== K2l (lane-per-window replay)
 // One lane = one printing window (plan.hpp WinW). The lane walks the window's candidate reads - consecutive RowRecs, shared
 // with the neighbouring lanes' windows, so the gathers hit L1 / L2 - and counts the haplotype words of the rows that are not
@@ -1164,6 +1350,7 @@ constexpr uint32_t K2W_ITEMS = 1;       // work items per wave: with the lane ke
                                         // one item per wave keeps four times as many waves in flight (window phase 1.14 -> 1.10 ms; four were
                                         // right while K3 had to skip the unused tail of every wave's last slot chunk)
 constexpr uint32_t K2W_HIST_BITS = 6;   // windows with at most this many columns count their haplotypes in a 64-entry LDS table
+#if MP_IN_PART(2)
 __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
     constexpr uint32_t GROUP_CHUNK = 64, REC_CHUNK_W = 64;   // small chunks: 64 allocators share the atomics; the unused tail of a
                                                              // wave's last chunk is capacity only (K3 walks dense lists)
@@ -1379,6 +1566,7 @@ __global__ __launch_bounds__(64) void k2w_window_rows(DeviceBatch d) {
     }   // work items of this wave
     if (sticky_err && lane == 0) atomicOr(d.err, sticky_err);
 }
+#endif
 
 // K2w for deeper data: RPL reads per lane (a block of 64 * RPL consecutive reads) and W mask words per read. Same row
 // derivation as k2w_window_rows; the haplotypes are counted by repeated minimum extraction (bitwise descent with ballots),
@@ -2882,6 +3070,7 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_haplotype_ids(DeviceBatch d) 
 }
 
 // ====================================================================== launchers
+#if MP_IN_PART(0)
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
     if (d.n_reads == 0) return;
     dim3 grid(uint32_t((uint64_t(d.n_reads) * K1_LANES + 255) / 256)), block(256);
@@ -2899,6 +3088,8 @@ void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream) {
     HIP_CHECK_LAUNCH();
 }
 
+#endif
+#if MP_IN_PART(1)
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream) {
     if (d.n_segs == 0) return;
     dim3 grid(d.n_segs), block(64);
@@ -2924,14 +3115,28 @@ void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_
     HIP_CHECK_LAUNCH();
 }
 
+#endif
+#if MP_IN_PART(0)
 void launch_k2_admission(const DeviceBatch& d, hipStream_t stream) {
     if (!d.n_exons_w) return;
     if (!d.n_achunks) return;
+    if (d.k2a_flat && d.mask_words <= 2) {
+        // (entries per lane: 1 measured 0.389 ms, 2 0.405 ms, the chunk form 0.418 ms on one box - the kernel is not short of loads in flight)
+        const char* env_items = std::getenv("MP_K2A_ITEMS");
+        const int items = env_items && std::atoi(env_items) == 2 ? 2 : 1;
+        const uint32_t waves = uint32_t((d.n_adm + 63) / 64), grid = (waves + items - 1) / items;
+        if (d.mask_words == 1) { if (items == 2) hipLaunchKernelGGL((k2a_admission_flat<1, 2>), dim3(grid), dim3(64), 0, stream, d); else hipLaunchKernelGGL((k2a_admission_flat<1, 1>), dim3(grid), dim3(64), 0, stream, d); }
+        else { if (items == 2) hipLaunchKernelGGL((k2a_admission_flat<2, 2>), dim3(grid), dim3(64), 0, stream, d); else hipLaunchKernelGGL((k2a_admission_flat<2, 1>), dim3(grid), dim3(64), 0, stream, d); }
+        HIP_CHECK_LAUNCH();
+        return;
+    }
     if (d.mask_words == 1) hipLaunchKernelGGL(k2a_admission<1>, dim3(d.n_achunks), dim3(64), 0, stream, d);
     else if (d.mask_words == 2) hipLaunchKernelGGL(k2a_admission<2>, dim3(d.n_achunks), dim3(64), 0, stream, d);
     else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     HIP_CHECK_LAUNCH();
 }
+#endif
+#if MP_IN_PART(2)
 template <int W>
 static void launch_k2w_multi(const DeviceBatch& d, hipStream_t stream) {
     dim3 grid(d.n_wchunks_m), block(64);
@@ -2962,6 +3167,8 @@ void launch_k2_window_rows(const DeviceBatch& d, hipStream_t stream) {
     }
 }
 
+#endif
+#if MP_IN_PART(0)
 template <int STAGE>
 static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream_t stream_wide, hipStream_t stream_hash) {
     // one wave per tile of 64 windows: a wave that walked several tiles would wait for its own result stores to drain before the
@@ -3003,8 +3210,9 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipS
     }
 }
 
+#endif
 template <int LIST>
-static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t stream) {
+void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t stream) {
     if (max_items == 0) return;
     // the grid covers the host's upper bound of the list lengths (surplus waves find nothing and leave; were the bound too low, the
     // waves walk the rest in turn - slower, still complete)
@@ -3029,6 +3237,18 @@ static void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t
 #undef K3_LAUNCH
     HIP_CHECK_LAUNCH();
 }
+#if MP_KPART != -1   // the three lists' kernels are compiled in a part each
+#if MP_KPART == 3
+template void launch_k3_list<0>(const DeviceBatch&, uint64_t, hipStream_t);
+#elif MP_KPART == 4
+template void launch_k3_list<1>(const DeviceBatch&, uint64_t, hipStream_t);
+extern template void launch_k3_list<0>(const DeviceBatch&, uint64_t, hipStream_t);
+extern template void launch_k3_list<2>(const DeviceBatch&, uint64_t, hipStream_t);
+#elif MP_KPART == 5
+template void launch_k3_list<2>(const DeviceBatch&, uint64_t, hipStream_t);
+#endif
+#endif
+#if MP_IN_PART(4)
 void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c) {
     if (d.normal) {   // `microphaser normal`: every group has a record (all of them are in list A); ids by k3b_haplotype_ids afterwards
         if (max_list_a == 0) return;
@@ -3062,5 +3282,6 @@ void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream
     }
     HIP_CHECK_LAUNCH();
 }
+#endif
 
 }  // namespace mp

@@ -28,6 +28,9 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint16_t* step_aux;     // normal mode: per Step, candidate key range | 0x8000 = new column epoch
     const WinStatic* wins;
     const WinCol* win_cols;
+    ExonA* exons_a;               // per window-parallel exon / per admission-table entry, packed on the device at upload (launch_k0_pack_admission)
+    AdmMap* adm_map;
+    uint32_t k2a_flat, k2a_pad_;  // the flat form of K2a (a lane per table entry across exon boundaries); MP_K2A_CHUNKS=1: a wave per <= 64 reads of ONE exon
     WinBlob* win_blobs;           // one per window, packed on the device at upload (launch_k0_pack_windows); somatic mode only
     const uint8_t* str_pool;
     const SegDev* segs;           // replay units (K2 / K2n launch one wave per segment)
@@ -90,6 +93,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
 };
 
 // rows_per_lane in {1,2,4,8,16}. All launches are asynchronous on `stream`.
+void launch_k0_pack_admission(const DeviceBatch& d, hipStream_t stream); // once per batch, after the upload: fills exons_a and adm_map
 void launch_k0_pack_windows(const DeviceBatch& d, hipStream_t stream);   // once per batch, after the upload: fills win_blobs
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);

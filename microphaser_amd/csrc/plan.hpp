@@ -70,6 +70,17 @@ struct ExonW {
 };
 enum : uint32_t { EW_WAVE = 1,      // a wave-per-window kernel has a window here: AdmEntry
                   EW_LANE = 2 };    // the lane-per-window kernel has one: RowRec
+// What K2a needs of an ExonW, in four 16-byte loads (packed on the device at upload, k0_pack_admission); the flat form of K2a gives every
+// lane one (exon, read) entry of the admission table, whatever exon it belongs to, so the exon's fields are per-lane values there.
+struct ExonA {
+    uint32_t step_off, n_steps, unit_steps, sso0;
+    uint32_t sso1, first_key_lo, range, tr0;
+    uint32_t f0, sl_f_lo, sl_f_hi, flags;      // flags: strand | consumers << 8
+    uint32_t adm_off, read0, pad0, pad1;       // read0: batch index of the first read of the exon's range
+};
+static_assert(sizeof(ExonA) == 64, "ExonA layout");
+struct AdmMap { uint32_t exon, read; };        // per admission-table entry: its exon and the batch index of its read
+
 struct WChunk {                     // K2w work item: a run of steps of one ExonW
     uint32_t exon, step_first, n_steps, pad;
 };

@@ -710,6 +710,31 @@ def test_gpu_lane_per_window_and_wave_per_window_replay_agree(ctx, monkeypatch):
     monkeypatch.delenv("MP_NO_LANE_KERNEL", raising=False)
 
 
+def test_gpu_flat_and_per_exon_admission_agree(ctx, monkeypatch):
+    """K2a in its flat form (a lane per (exon, read) entry across exon boundaries, the exon's fields packed on the device at upload)
+    against the form with a wave per <= 64 reads of ONE exon (MP_K2A_CHUNKS=1), one and two entries per lane: same bytes - on an exome
+    with both strands, indels, multi-allelic sites and soft-masked reference (exons of both kinds: window-parallel and sequential)
+    and on a deep one (two mask words per read)."""
+    for seed, n, depth, spacing, kw in ((5151, 60, 30.0, 5.4, {}), (5152, 40, 35.0, 6.0, dict(indel_rate=0.05, multiallelic_rate=0.05, softmask_rate=0.1)),
+                                        (5153, 6, 400.0, 1.6, {})):
+        ds = ctx.synth(seed, n, depth, spacing, **kw)
+        got = []
+        for env in ({}, {"MP_K2A_ITEMS": "2"}, {"MP_K2A_CHUNKS": "1"}):
+            for k in ("MP_K2A_ITEMS", "MP_K2A_CHUNKS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            b = ds.batch()
+            b.run()
+            r = b.results()
+            got.append((r.fasta, r.normal_fasta, r.tsv, r.windows))
+            r.close(); b.close()
+        assert got[0] == got[1] == got[2]
+        assert got[0][2].count(b"\n") > 100
+    for k in ("MP_K2A_ITEMS", "MP_K2A_CHUNKS"):
+        monkeypatch.delenv(k, raising=False)
+
+
 # ---- the phase_gene-level boundary, cost-balanced shards and the multi-rank config E driver
 @pytest.mark.parametrize("name", ["test_reverse", "splice_reverse_test", "splice_forward_test"])
 def test_gpu_decoded_records_in_reference_output_out(ctx, name):
