@@ -213,11 +213,11 @@ def main():
         # Roofline units: kernels that run one after the other on the launch stream, except the window phase - k2l (two launches) and k2w are
         # launched side by side on separate streams, so their HIP-event intervals overlap (each spans most of the phase); the phase is
         # priced as ONE unit: the three launches' bytes over the phase's wall time (first start to last end, HIP events)
-        k3_name = "k3_window_seq (sequences + records + SHA-1 ids: list A | flags: list B, concurrent)"
+        k3_name = "k3_window_seq (sequences + records + SHA-1 ids: list A | flags: list B | + stop scan: list C | general walk: list D, concurrent)"
         kern[k3_name] = kern.pop("k3_window_seq")
         units = {"k1_pileup_bits": kern["k1_pileup_bits"] + (["k1_pileup_bits"],),
                  "k2a_admission": kern["k2a_admission"] + (["k2a_admission"],),
-                 "k2_window_phase (k2l_window_lanes<6> | k2l_window_lanes<8> | k2w_window_rows, concurrent)":
+                 "k2_window_phase (k2l_window_lanes<6> | <8> | <16> | k2w_window_rows, concurrent)":
                      (k2win / steps, st.bytes_k2l + st.bytes_k2w, ["k2l_window_lanes", "k2w_window_rows"]),
                  k3_name: kern[k3_name] + (["k3_window_seq"],)}
         if kern["k3b_haplotype_ids"][0] > 0:   # (`normal` mode only: somatic ids are hashed inside K3)
@@ -225,7 +225,7 @@ def main():
         else:
             del kern["k3b_haplotype_ids"]
         if k2win <= 0:   # no window-parallel work in this batch: the sequential replay is the K2 unit
-            del units["k2_window_phase (k2l_window_lanes<6> | k2l_window_lanes<8> | k2w_window_rows, concurrent)"]
+            del units["k2_window_phase (k2l_window_lanes<6> | <8> | <16> | k2w_window_rows, concurrent)"]
             units["k2_window_replay"] = kern["k2_window_replay"] + (["k2_window_replay"],)
         dom = max(units, key=lambda k: units[k][0])
         dom_ms, dom_bytes, dom_kernels = units[dom]
@@ -244,6 +244,7 @@ def main():
             if args.transcripts or world != 1:
                 break
             traffic_src = os.path.relpath(path, ROOT)
+            pt = {k: e for k, e in pt.items() if not k.startswith("k0_")}   # (the layout kernels run once per batch, at upload: not part of a pass)
             pass_pmc = {"fetch_raw": sum(e.get("fetch_bytes_raw", 0.0) for e in pt.values()), "write": sum(e.get("write_bytes", 0.0) for e in pt.values())}
             hit = [k for k in pt if any(k.split("<")[0].startswith(x) for x in dom_kernels) and "fetch_bytes_raw" in pt[k]]   # (k2w_window_rows[_multi|_deep])
             if hit:
@@ -269,7 +270,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "ONE synthetic %d-transcript exome, %gx, SNV every %g nt, 101-nt reads (SURVEY 8d config %s, seed %d, per-gene random streams)%s; "
-                                   "step = K1 + K2 (k2a admission, k2l one lane per window, k2w one wave per window for the wide ones; sequential k2 replay for the "
+                                   "step = K1 + K2 (k2a admission, k2l one lane per window, k2w one wave per window for the widest / deepest ones; sequential k2 replay for the "
                                    "segments that need it) + K3 (window sequences, records and their SHA-1 ids) over the HBM-resident batch"
                                    % (n_tx, depth, spacing, args.config, seed,
                                       "" if world == 1 else ", its genes dealt to the %d GPUs by estimated cost (LPT on CDS nt x depth)" % world),
@@ -293,10 +294,12 @@ def main():
             "valu_issue": None if not valu else {
                 "wave_instructions_per_pass": int(sum(valu.values())), "source": traffic_src,
                 "peak_per_s": VALU_PEAK_PER_S, "pass_frac": sum(valu.values()) / t_pass / VALU_PEAK_PER_S,
+                "measured_int_peak_per_s": 661e9, "pass_frac_of_measured_int_peak": sum(valu.values()) / t_pass / 661e9,
+                "measured_peak_source": "profiles/r05d_issue_rate.txt (tools/ubench/issue_rate.hip: integer add / xor / shift with every wave slot occupied)",
                 "note": "SQ_INSTS_VALU of every kernel of one pass (committed PMC summary) over the live pass time, against 256 CUs x 4 SIMDs x "
                         "one wave64 VALU instruction per 2 cycles x 2.4 GHz: the pass is integer / bitset work bound by instruction issue and latency"},
             "kernels_ms": {k: v[0] for k, v in kern.items()},
-            "kernels_note": "k2l_window_lanes (its two launches) and k2w_window_rows run side by side on separate streams after k2a (and k2_window_replay beside k2a): "
+            "kernels_note": "k2l_window_lanes (its three launches) and k2w_window_rows run side by side on separate streams after k2a (and k2_window_replay beside k2a): "
                             "their intervals overlap; k2_window_phase_ms is the wall time of that phase",
             "k2_window_phase_ms": k2win / steps,
             "kernels_algorithmic_bytes": {k: int(v[1]) for k, v in kern.items()},
@@ -304,7 +307,7 @@ def main():
             "rows_per_lane": int(st.rows_per_lane), "mask_words": int(st.mask_words),
             "replay": {"steps_window_parallel": int(st.n_steps_w), "steps_sequential": int(st.n_steps_seq), "admission_entries": int(st.n_adm),
                        "windows_lane_kernel": int(st.n_windows_lane), "windows_wave_kernel": int(st.n_windows_wave),
-                       "groups": int(st.n_groups), "groups_k3": int(st.n_groups_k3), "groups_k3_list_a": int(st.n_groups_k3a), "ids_hashed": int(st.n_ids),
+                       "groups": int(st.n_groups), "groups_k3": int(st.n_groups_k3), "groups_k3_list_a": int(st.n_groups_k3a), "groups_k3_list_c": int(st.n_groups_k3c), "groups_k3_list_d": int(st.n_groups_k3d), "ids_hashed": int(st.n_ids),
                        "emitted_haplotypes": emitted},
             "hbm_resident_bytes": int(st.hbm_bytes),
             "end_to_end": {"generate_s": t_gen, "plan_pack_h2d_s": t_plan, "pass_s": t_pass, "d2h_consume_s": None if args.no_consume else t_consume,

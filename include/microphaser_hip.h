@@ -153,6 +153,7 @@ typedef struct mp_run_stats {
     uint64_t n_windows_device;             /* printing windows the device computed (main ORF and shifted frames, speculative past a stop) */
     uint64_t n_groups_k3a;                 /* of n_groups_k3: groups in k3_window_seq's list A (their ids are hashed) */
     uint64_t n_ids;                        /* haplotype ids hashed (somatic: inside k3_window_seq; normal: k3b_haplotype_ids) */
+    uint64_t n_groups_k3c, n_groups_k3d;   /* of n_groups_k3: list C (simple windows that may hold a stop codon), list D (general sequence walk) */
 } mp_run_stats;
 
 /* Plan + pack genes [gene_lo, gene_hi) of a data set and make them resident in HBM

@@ -138,6 +138,7 @@ class RunStats(ctypes.Structure):
         ("k2l_ms", ctypes.c_double), ("bytes_k2l", ctypes.c_uint64), ("n_windows_lane", ctypes.c_uint64), ("n_windows_wave", ctypes.c_uint64),
         ("n_groups_k3", ctypes.c_uint64), ("k2win_ms", ctypes.c_double),
         ("n_windows_device", ctypes.c_uint64), ("n_groups_k3a", ctypes.c_uint64), ("n_ids", ctypes.c_uint64),
+        ("n_groups_k3c", ctypes.c_uint64), ("n_groups_k3d", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -81,6 +81,7 @@ struct Batch {
     uint32_t n_lane_mid = 0;             // the rest: 9..K2L_HASH_COLS columns (the lane kernel's hash-table form)
     PodVec<uint32_t> lane_win;           // window index of each winw entry
     PodVec<uint32_t> win_trivial;        // bit per window, see kernels.hpp
+    PodVec<uint32_t> win_walk;           // bit per window: !WSF_SIMPLE (the general sequence walk: K3's list D)
     PodVec<uint32_t> win_simple;         // bit per window: WSF_SIMPLE && WSF_NOSTOP (the wave-per-window kernels route a window's groups to K3's list A / B or C by it)
     bool lane_on = false;                // K2a writes RowRecs and the lane kernel takes the eligible windows
     bool lane_hash = false;              // ... including those of 9..16 columns (its hash-table form)

@@ -257,6 +257,8 @@ int mp_batch_run(mp_ctx* ctx, mp_batch* batch, mp_run_stats* st) {
             }
             st->n_groups_k3 = t.n_k3;
             st->n_groups_k3a = t.n_k3a;
+            st->n_groups_k3c = t.n_k3c;
+            st->n_groups_k3d = t.n_k3d;
             st->n_windows_device = b.wins.size();
             st->n_ids = t.n_recs;
             // K3 looks at the listed groups only; their windows' static records / reference bytes / columns are shared out by the listed share

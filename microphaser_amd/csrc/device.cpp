@@ -26,6 +26,7 @@ DeviceContext::DeviceContext(int device) : device_(device) {
     HIP_OK(hipEventCreateWithFlags(&k3_fork_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&k3_join_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&k3_join2_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&k3_join3_, hipEventDisableTiming));
     for (auto& ev : join_) HIP_OK(hipEventCreate(&ev));
 }
 
@@ -41,6 +42,7 @@ DeviceContext::~DeviceContext() {
     if (k3_fork_) (void)hipEventDestroy(k3_fork_);
     if (k3_join_) (void)hipEventDestroy(k3_join_);
     if (k3_join2_) (void)hipEventDestroy(k3_join2_);
+    if (k3_join3_) (void)hipEventDestroy(k3_join3_);
     for (auto& ev : join_) if (ev) (void)hipEventDestroy(ev);
     for (auto& st : side_) if (st) (void)hipStreamDestroy(st);
     if (stream_) hipStreamDestroy(stream_);
@@ -210,8 +212,10 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.rows_per_lane_w = b.rows_per_lane_w;
     d_.achunks = up(b.achunks);
     d_.n_achunks = uint32_t(b.achunks.size());
-    {   // K2a's waves are short and bound by dependent loads: every work item gets its exon's record beside it (one level of scalar loads
-        // instead of work item -> exon), and the batch index of its first read in the item itself (its read fields can be fetched at once)
+    d_.k2a_flat = !std::getenv("MP_K2A_CHUNKS") && !b.exons_w.empty() && b.n_adm && b.n_adm < 0xFFFFFF00ull ? 1u : 0u;
+    d_.achunk_exons = nullptr;
+    if (!d_.k2a_flat) {   // the form with a wave per work item: every work item gets its exon's record beside it (one level of scalar loads
+        // instead of work item -> exon)
         achunk_exons_.resize(b.achunks.size());
         for (size_t k = 0; k < b.achunks.size(); k++) achunk_exons_[k] = b.exons_w[b.achunks[k].exon];
         d_.achunk_exons = up(achunk_exons_);
@@ -230,6 +234,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.lane_win = up(b.lane_win);
     d_.win_trivial = up(b.win_trivial);
     d_.win_simple = up(b.win_simple);
+    d_.win_walk = up(b.win_walk);
     d_.n_lane_small = b.n_lane_small;
     d_.n_lane_mid = b.n_lane_mid;
     d_.n_lane_all = uint32_t(b.winw.size());
@@ -258,7 +263,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.err = reinterpret_cast<uint32_t*>(d_.cursors + NPART * 32);   // the error word sits behind the cursors: one memset, one copy back per pass
     d_.tx_first_stop = static_cast<uint32_t*>(dalloc(size_t(d_.n_tx) * 4)); allocs_.push_back(d_.tx_first_stop);
     max_rows_bound_ = b.max_rows_bound;
-    last_slots_ = last_recs_ = last_want_ = last_k3a_ = last_k3b_ = last_k3c_ = 0;
+    last_slots_ = last_recs_ = last_want_ = last_k3a_ = last_k3b_ = last_k3c_ = last_k3d_ = 0;
     rpl_ = 1;
     while (rpl_ < 16 && uint32_t(64 * rpl_) < max_rows_bound_) rpl_ *= 2;  // overflow -> run() retries with more
     // first guess: 6 distinct haplotypes per window + one partly used chunk per wave, split over the NPART allocators
@@ -273,7 +278,6 @@ void DeviceContext::upload_impl(const Batch& b) {
     d_.win_blobs = nullptr;
     if (!b.normal && d_.n_wins) { d_.win_blobs = static_cast<WinBlob*>(dalloc(size_t(d_.n_wins) * sizeof(WinBlob))); allocs_.push_back(d_.win_blobs); }
     d_.exons_a = nullptr; d_.adm_map = nullptr;
-    d_.k2a_flat = !std::getenv("MP_K2A_CHUNKS") && d_.n_exons_w && b.n_adm && b.n_adm < 0xFFFFFF00ull ? 1u : 0u;
     if (d_.k2a_flat) {
         d_.exons_a = static_cast<ExonA*>(dalloc(size_t(d_.n_exons_w) * sizeof(ExonA))); allocs_.push_back(d_.exons_a);
         d_.adm_map = static_cast<AdmMap*>(dalloc(size_t(b.n_adm) * sizeof(AdmMap))); allocs_.push_back(d_.adm_map);
@@ -351,14 +355,18 @@ void DeviceContext::run(RunTiming& t) {
         const uint64_t a_bound = last_slots_ ? last_k3a_ + last_k3a_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * (d_.normal ? 8 : 2) + 65536);
         const uint64_t b_bound = last_slots_ ? last_k3b_ + last_k3b_ / 16 + 4096 : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) * 2 + 65536);
         const uint64_t c_bound = last_slots_ ? (last_k3c_ ? last_k3c_ + last_k3c_ / 16 + 4096 : 0) : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) / 4 + 65536);
+        const uint64_t d_bound = last_slots_ ? (last_k3d_ ? last_k3d_ + last_k3d_ / 16 + 4096 : 0) : std::min<uint64_t>(group_cap_, uint64_t(d_.n_wins) / 8 + 65536);
         const uint64_t want_bound = last_slots_ ? last_want_ + last_want_ / 16 + 4096 : std::min<uint64_t>(rec_cap_, uint64_t(d_.n_wins) * 2 + 65536);
         if (!d_.normal) {
             HIP_OK(hipEventRecord(k3_fork_, stream_));
             HIP_OK(hipStreamWaitEvent(side_[0], k3_fork_, 0));
             HIP_OK(hipStreamWaitEvent(side_[1], k3_fork_, 0));
+            HIP_OK(hipStreamWaitEvent(side_[3], k3_fork_, 0));
         }
-        launch_k3_window_seq(d_, a_bound, b_bound, c_bound, stream_, side_[0], side_[1]);
+        launch_k3_window_seq(d_, a_bound, b_bound, c_bound, d_bound, stream_, side_[0], side_[1], side_[3]);
         if (!d_.normal) {
+            HIP_OK(hipEventRecord(k3_join3_, side_[3]));
+            HIP_OK(hipStreamWaitEvent(stream_, k3_join3_, 0));
             HIP_OK(hipEventRecord(k3_join_, side_[0]));
             HIP_OK(hipStreamWaitEvent(stream_, k3_join_, 0));
             HIP_OK(hipEventRecord(k3_join2_, side_[1]));
@@ -395,7 +403,7 @@ void DeviceContext::run(RunTiming& t) {
             continue;
         }
         if (err) throw Error("device kernels reported an internal inconsistency (error word " + std::to_string(err) + ")");
-        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3a = 0, n_k3b = 0, n_k3c = 0;
+        uint64_t slots = 0, rec_slots = 0, n_want = 0, n_k3a = 0, n_k3b = 0, n_k3c = 0, n_k3d = 0;
         for (uint32_t p = 0; p < NPART; p++) {
             used_g_[p] = cur[p * 32];
             used_r_[p] = cur[p * 32 + 16];
@@ -405,6 +413,7 @@ void DeviceContext::run(RunTiming& t) {
             n_k3a += cur[p * 32 + 8];
             n_k3b += cur[p * 32 + 12];
             n_k3c += cur[p * 32 + 20];
+            n_k3d += cur[p * 32 + 28];
         }
         HIP_OK(hipEventElapsedTime(&t.k3b_ms, ev_[3], ev_[4]));
         HIP_OK(hipEventElapsedTime(&t.k1_ms, ev_[0], ev_[1]));
@@ -427,10 +436,13 @@ void DeviceContext::run(RunTiming& t) {
         last_k3a_ = n_k3a;
         last_k3b_ = n_k3b;
         last_k3c_ = n_k3c;
+        last_k3d_ = n_k3d;
         t.n_group_slots = slots;    // group slots K3 walked (incl. the unused tail of each wave's last chunk) / records K3b hashed
         t.n_recs = n_want;
         t.n_groups = slots;
-        t.n_k3 = n_k3a + n_k3b + n_k3c;
+        t.n_k3 = n_k3a + n_k3b + n_k3c + n_k3d;
+        t.n_k3c = n_k3c;
+        t.n_k3d = n_k3d;
         t.n_k3a = n_k3a;
         t.n_rec_slots = rec_slots;
         return;

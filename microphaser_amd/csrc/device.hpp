@@ -33,7 +33,7 @@ struct RunTiming {
     float k1_ms = 0, k2_ms = 0, k3_ms = 0, k3b_ms = 0, total_ms = 0;
     float k2seq_ms = 0, k2a_ms = 0, k2l_ms = 0, k2w_ms = 0;   // the launches inside k2_ms: sequential replay, admission, lane-per-window, wave-per-window
     float k2win_ms = 0;                                        // the lane- and wave-per-window launches run side by side: their joint wall time
-    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0, n_k3 = 0, n_k3a = 0, n_rec_slots = 0;   // n_k3: groups K3 looked at (the rest were settled by K2l)
+    uint64_t n_group_slots = 0, n_recs = 0, n_groups = 0, n_k3 = 0, n_k3a = 0, n_k3c = 0, n_k3d = 0, n_rec_slots = 0;   // n_k3: groups K3 looked at (the rest were settled by K2l)
     int rows_per_lane = 1;
     uint32_t attempts = 0;
 };
@@ -77,7 +77,7 @@ class DeviceContext {
     hipStream_t stream_ = nullptr;
     hipStream_t side_[4] = {nullptr, nullptr, nullptr, nullptr};   // the independent launches of the window phase run side by side (run())
     hipEvent_t fork_[2] = {nullptr, nullptr}, join_[4] = {nullptr, nullptr, nullptr, nullptr}, cleared_ = nullptr;
-    hipEvent_t k3_fork_ = nullptr, k3_join_ = nullptr, k3_join2_ = nullptr;    // K3's lists B and C run beside list A on side_[0] / side_[1]
+    hipEvent_t k3_fork_ = nullptr, k3_join_ = nullptr, k3_join2_ = nullptr, k3_join3_ = nullptr;    // K3's lists B and C run beside list A on side_[0] / side_[1]
     hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs_, out_allocs_;
     DeviceBatch d_{};
@@ -87,7 +87,7 @@ class DeviceContext {
     uint64_t used_g_[NPART] = {0}, used_r_[NPART] = {0};   // slots used by each allocator in the last run()
     int rpl_ = 1;
     uint32_t max_rows_bound_ = 0;
-    uint64_t last_slots_ = 0, last_recs_ = 0, last_want_ = 0, last_k3a_ = 0, last_k3b_ = 0, last_k3c_ = 0;
+    uint64_t last_slots_ = 0, last_recs_ = 0, last_want_ = 0, last_k3a_ = 0, last_k3b_ = 0, last_k3c_ = 0, last_k3d_ = 0;
 };
 
 }  // namespace mp

@@ -19,7 +19,7 @@
 
 namespace mp {
 
-// This file is compiled in parts (Makefile: -DMP_KPART=0..5, one object each, side by side): every part holds all the templates and
+// This file is compiled in parts (Makefile: -DMP_KPART=0..6, one object each, side by side): every part holds all the templates and
 // the launchers - hence the kernel instantiations - of its share. Without MP_KPART it is one translation unit.
 #ifndef MP_KPART
 #define MP_KPART -1
@@ -262,27 +262,33 @@ __device__ __forceinline__ void k3_enqueue(const DeviceBatch& d, uint32_t part, 
     // (a stop codon is possible). One such lane makes its whole K3 wave run the per-base walk / the codon loop - at config C 0.8 % of the
     // windows did the former to 40 % of the waves, 6 % the latter to nearly all - so they get a list (and a launch) of their own, in the
     // second half of k3_items. (`normal` mode has one K3 kernel for everything: list A.)
-    const uint32_t wbit = on ? d.win_simple[win >> 5] : 0u;
+    // The two kinds are kept apart as well: list C (upwards) = simple windows that may hold a stop, list D (downwards from the second
+    // half's end) = windows that need the general walk - 11 % of what was one list made nearly all of its waves run the per-base walk.
+    const uint32_t wbit = on ? d.win_simple[win >> 5] : 0u, kbit = on ? d.win_walk[win >> 5] : 0u;
     const bool simple = d.normal || ((wbit >> (win & 31u)) & 1u);
-    const bool to_c = on && !simple;
+    const bool walk = !d.normal && ((kbit >> (win & 31u)) & 1u);
+    const bool to_d = on && !simple && walk;
+    const bool to_c = on && !simple && !walk;
     const bool to_a = on && simple && rec != 0xFFFFFFFFu;
     const bool to_b = on && simple && rec == 0xFFFFFFFFu;
-    const uint64_t ma = __ballot(to_a), mb = __ballot(to_b), mc = __ballot(to_c);
-    if (!(ma | mb | mc)) return;
+    const uint64_t ma = __ballot(to_a), mb = __ballot(to_b), mc = __ballot(to_c), md = __ballot(to_d);
+    if (!(ma | mb | mc | md)) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t la = ma ? uint32_t(__builtin_ctzll(ma)) : 64u, lb = mb ? uint32_t(__builtin_ctzll(mb)) : 64u, lc = mc ? uint32_t(__builtin_ctzll(mc)) : 64u;
+    const uint32_t la = ma ? uint32_t(__builtin_ctzll(ma)) : 64u, lb = mb ? uint32_t(__builtin_ctzll(mb)) : 64u, lc = mc ? uint32_t(__builtin_ctzll(mc)) : 64u,
+                   ld = md ? uint32_t(__builtin_ctzll(md)) : 64u;
     unsigned long long base = 0;
-    if (lane == la || lane == lb || lane == lc)   // one atomic instruction, a lane per list
-        base = atomicAdd(d.cursors + part * 32 + (lane == la ? 8 : lane == lb ? 12 : 20), (unsigned long long)__popcll(lane == la ? ma : lane == lb ? mb : mc));
-    const uint32_t src = (to_a ? la : to_b ? lb : lc) & 63u;
+    if (lane == la || lane == lb || lane == lc || lane == ld)   // one atomic instruction, a lane per list
+        base = atomicAdd(d.cursors + part * 32 + (lane == la ? 8 : lane == lb ? 12 : lane == lc ? 20 : 28),
+                         (unsigned long long)__popcll(lane == la ? ma : lane == lb ? mb : lane == lc ? mc : md));
+    const uint32_t src = (to_a ? la : to_b ? lb : to_c ? lc : ld) & 63u;
     const uint64_t b0 = (uint64_t(uint32_t(__shfl(int(uint32_t(base >> 32)), int(src)))) << 32) | uint32_t(__shfl(int(uint32_t(base)), int(src)));
     // (the cursors also count the entries of waves whose groups did NOT fit their sub-range: never store outside the sub-range, flag
     //  the pass instead; it is run again with larger arenas and K3 never walks the lists of a flagged pass)
     if (on) {
         const uint64_t size = 1ull << d.group_part_log2;
-        const uint64_t at = b0 + lanes_below(to_a ? ma : to_b ? mb : mc, lane);
-        const uint64_t sub = (uint64_t(part) << d.group_part_log2) + (to_c ? d.group_cap : 0ull);
-        if (at < size) d.k3_items[sub + (to_b ? size - 1 - at : at)] = make_uint4(uint32_t(slot), win, rec, 0u);
+        const uint64_t at = b0 + lanes_below(to_a ? ma : to_b ? mb : to_c ? mc : md, lane);
+        const uint64_t sub = (uint64_t(part) << d.group_part_log2) + ((to_c || to_d) ? d.group_cap : 0ull);
+        if (at < size) d.k3_items[sub + ((to_b || to_d) ? size - 1 - at : at)] = make_uint4(uint32_t(slot), win, rec, 0u);
         else atomicOr(d.err, WD_GROUP_OVERFLOW);
     }
 }
@@ -886,7 +892,7 @@ __global__ __launch_bounds__(256) void k0_pack_admission(DeviceBatch d) {
         a.step_off = e.step_off; a.n_steps = e.n_steps; a.unit_steps = e.unit_steps; a.sso0 = e.sso0;
         a.sso1 = e.sso1; a.first_key_lo = e.first_key_lo; a.range = e.range; a.tr0 = e.tr0;
         a.f0 = e.f0; a.sl_f_lo = e.sl_f_lo; a.sl_f_hi = e.sl_f_hi; a.flags = (e.strand ? 1u : 0u) | (e.consumers << 8);
-        a.adm_off = e.adm_off; a.read0 = e.rbase + e.read_lo; a.pad0 = a.pad1 = 0;
+        a.adm_off = e.adm_off; a.read0 = e.rbase + e.read_lo; a.wlen_min = e.wlen_min; a.pad1 = 0;
         d.exons_a[i] = a;
     }
     if (i < d.n_adm) {   // the last exon whose first entry is at or before this one (offsets ascend; exons without reads share their successor's)
@@ -939,7 +945,7 @@ __global__ __launch_bounds__(64) void k2a_admission_flat(DeviceBatch d) {
         I.e.step_off = q0.x; I.e.n_steps = q0.y; I.e.unit_steps = q0.z; I.e.sso0 = q0.w;
         I.e.sso1 = q1.x; I.e.first_key_lo = q1.y; I.e.range = q1.z; I.e.tr0 = q1.w;
         I.e.f0 = q2.x; I.e.sl_f_lo = q2.y; I.e.sl_f_hi = q2.z; I.e.flags = q2.w;
-        I.e.adm_off = q3.x; I.e.read0 = q3.y;
+        I.e.adm_off = q3.x; I.e.read0 = q3.y; I.e.wlen_min = q3.z;
     };
     auto load_step = [&](In& I, uint32_t si) __attribute__((always_inline)) {   // the fields push_read's decision needs, in one round of loads
         const uint32_t* sp = reinterpret_cast<const uint32_t*>(d.steps + si);
@@ -988,6 +994,13 @@ __global__ __launch_bounds__(64) void k2a_admission_flat(DeviceBatch d) {
                 if (t >= e.n_steps) t = e.n_steps - 1;
                 while (t > 0 && d.steps[e.step_off + t - 1].sso <= top) t--;
                 while (t < e.n_steps && d.steps[e.step_off + t].sso > top) t++;
+            }
+            if (t < e.unit_steps) {
+                // a read is offered from the step at which sso has come down to start + R - R steps before a window can lie inside the
+                // read -, so the first offers would all fail `encloses`: the steps at which even the exon's shortest window sticks out
+                // beyond the read's end are skipped by arithmetic (one dependent round of step loads less for nearly every '-' read)
+                const uint32_t need = e.sso0 + e.wlen_min > I.end ? e.sso0 + e.wlen_min - I.end : 0u;   // first t with sso0 - t + wlen_min <= end
+                t = max(t, min(need, e.unit_steps));
             }
             I.go = t < e.n_steps; I.t = I.go ? t : 0;
         }
@@ -1104,7 +1117,8 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         const bool fwd = (pack & WW_FWD) != 0, need_all = (pack & WW_NEED_ALL) != 0;
         const bool trivial = (pack & WW_TRIVIAL) != 0;   // simple window that cannot hold a stop: a group without a somatic column needs no K3
         const bool all_ids = (pack & WW_ALL_IDS) != 0;   // every haplotype of the window is hashed (else only those that set a somatic column)
-        const bool simple = (pack & WW_SIMPLE) != 0;     // K3 builds the sequences by byte substitution; every group of another window goes to K3's list C
+        const bool simple = (pack & WW_SIMPLE) != 0;     // K3 builds the sequences by byte substitution; every group of another window goes to K3's list C ...
+        const bool walk = (pack & WW_WALK) != 0;         // ... or, when its sequences need the general walk, to list D (walk implies !simple)
         // ---- rows of the window, haplotypes counted as they come (branch-free body: every lane adds 0 or 1 to one counter)
         const uint32_t cmask32 = ncols ? (0xFFFFFFFFu >> (32 - ncols)) : 0u;   // ncols <= 8: the low dword of the shifted mask is enough
         const uint32_t rev_sh = (32u - ncols) & 31u;
@@ -1151,17 +1165,20 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
             return rdlane(v, 0);
         };
         if constexpr (STAGE_ == 0) {
+            // (rows straight from memory: the loads of GATHER_BLK rows go out together, at clamped indices and unconditionally - a lane
+            //  walks ~30 rows, and with one or two rows in flight every few rows cost a full memory round trip)
+            constexpr uint32_t GATHER_BLK = 8;
             const uint32_t rn_max = wave_max(r_n);
-            uint4 a_next = make_uint4(0, 0, 0, 0), a_next2 = a_next;
-            uint64_t s_next = 0, s_next2 = 0;
-            if (r_n) { a_next = *reinterpret_cast<const uint4*>(d.rr_a + rr_lo); s_next = d.rr_sup[rr_lo]; }
-            if (r_n > 1) { a_next2 = *reinterpret_cast<const uint4*>(d.rr_a + rr_lo + 1); s_next2 = d.rr_sup[rr_lo + 1]; }
-            for (uint32_t k = 0; k < rn_max; k++) {
-                const uint4 a = a_next;
-                const uint64_t sup = s_next;
-                a_next = a_next2; s_next = s_next2;
-                if (k + 2 < r_n) { a_next2 = *reinterpret_cast<const uint4*>(d.rr_a + rr_lo + k + 2); s_next2 = d.rr_sup[rr_lo + k + 2]; }
-                count_row(a, sup, k < r_n);
+            const uint32_t r_last = r_n ? r_n - 1 : 0u;
+            const uint4* const ra = reinterpret_cast<const uint4*>(d.rr_a) + rr_lo;
+            const uint64_t* const rs = d.rr_sup + rr_lo;
+            for (uint32_t k0 = 0; k0 < rn_max; k0 += GATHER_BLK) {
+                uint4 va[GATHER_BLK];
+                uint64_t vs[GATHER_BLK];
+#pragma unroll
+                for (uint32_t u = 0; u < GATHER_BLK; u++) { const uint32_t i = min(k0 + u, r_last); va[u] = ra[i]; vs[u] = rs[i]; }
+#pragma unroll
+                for (uint32_t u = 0; u < GATHER_BLK; u++) count_row(va[u], vs[u], k0 + u < r_n);
             }
         } else {
         bool pending = r_n != 0;
@@ -1238,7 +1255,8 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         // group that is not settled here - with a record slot (a window whose haplotypes are carried into a splice merge) or without
         const uint32_t na = simple ? nhash : 0u;
         const uint32_t nb = simple ? (nneed - nhash) + (trivial ? 0u : ng - nneed) : 0u;
-        const uint32_t nc = simple ? 0u : ng;   // (a window that is not simple is never trivial: all its groups are listed)
+        const uint32_t nc = (simple || walk) ? 0u : ng;   // (a window that is not simple is never trivial: all its groups are listed)
+        const uint32_t nd = walk ? ng : 0u;
         uint32_t scanb = na | (nb << 16);   // (both sums stay below 2^16)
 #pragma unroll
         for (uint32_t off = 1; off < 64; off <<= 1) {
@@ -1246,34 +1264,38 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
             if (lane >= off) scanb += up;
         }
         const uint32_t tot_a = rdlane(scanb, 63) & 0xFFFFu, tot_b = rdlane(scanb, 63) >> 16;
-        uint32_t scanc = nc, tot_c = 0;
-        if (__ballot(nc != 0)) {   // (wave-uniform: most tiles hold simple windows only)
+        uint32_t scanc = nc | (nd << 16), tot_c = 0, tot_d = 0;
+        if (__ballot((nc | nd) != 0)) {   // (wave-uniform: most tiles hold simple windows only)
 #pragma unroll
             for (uint32_t off = 1; off < 64; off <<= 1) {
                 const uint32_t up = __shfl_up(scanc, off);
                 if (lane >= off) scanc += up;
             }
-            tot_c = rdlane(scanc, 63);
+            tot_c = rdlane(scanc, 63) & 0xFFFFu; tot_d = rdlane(scanc, 63) >> 16;
         }
         // the tile's four allocations - group slots, record slots, entries of K3's two lists - in ONE atomic instruction: lanes 0..3 each
         // add to their own cursor (one after the other, each under its own condition, they were dependent round trips to L2)
         unsigned long long got = 0;
-        if (lane < 5) {
-            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : lane == 2 ? gcur + 8 : lane == 3 ? gcur + 12 : gcur + 20;
-            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : lane == 2 ? tot_a : lane == 3 ? tot_b : tot_c));
+        if (lane < 6) {
+            unsigned long long* const cur = lane == 0 ? gcur : lane == 1 ? rcur : lane == 2 ? gcur + 8 : lane == 3 ? gcur + 12 : lane == 4 ? gcur + 20 : gcur + 28;
+            got = atomicAdd(cur, (unsigned long long)(lane == 0 ? tot_g : lane == 1 ? tot_r : lane == 2 ? tot_a : lane == 3 ? tot_b : lane == 4 ? tot_c : tot_d));
         }
         const uint64_t gbase = (uint64_t(rdlane(uint32_t(got >> 32), 0)) << 32) | rdlane(uint32_t(got), 0);
         const uint64_t rbase = (uint64_t(rdlane(uint32_t(got >> 32), 1)) << 32) | rdlane(uint32_t(got), 1);
         const uint64_t la_base = (uint64_t(rdlane(uint32_t(got >> 32), 2)) << 32) | rdlane(uint32_t(got), 2);
         const uint64_t lb_base = (uint64_t(rdlane(uint32_t(got >> 32), 3)) << 32) | rdlane(uint32_t(got), 3);
         const uint64_t lc_base = (uint64_t(rdlane(uint32_t(got >> 32), 4)) << 32) | rdlane(uint32_t(got), 4);
+        const uint64_t ld_base = (uint64_t(rdlane(uint32_t(got >> 32), 5)) << 32) | rdlane(uint32_t(got), 5);
         // list A: upwards from the sub-range's first entry; list C: upwards in the second array (a lane needs one of the two)
-        uint64_t up_slot = simple ? gpart_lo + la_base + ((scanb & 0xFFFFu) - na) : d.group_cap + gpart_lo + lc_base + (scanc - nc);
-        uint64_t lb_slot = gpart_lo + gpart_size - 1 - (lb_base + ((scanb >> 16) - nb));      // list B: downwards from its last
+        uint64_t up_slot = simple ? gpart_lo + la_base + ((scanb & 0xFFFFu) - na) : d.group_cap + gpart_lo + lc_base + ((scanc & 0xFFFFu) - nc);
+        // list B: downwards from the sub-range's last entry; list D: downwards in the second array (again one of the two per lane)
+        uint64_t lb_slot = walk ? d.group_cap + gpart_lo + gpart_size - 1 - (ld_base + ((scanc >> 16) - nd))
+                                : gpart_lo + gpart_size - 1 - (lb_base + ((scanb >> 16) - nb));
         // (the list cursors also count the entries of tiles that could not write - they leave holes -, so a tile whose groups fit can
         //  still find a list run past the sub-range: such a tile writes nothing either; K3 never walks a list with holes, the error
         //  word makes it leave and the pass is run again with larger arenas. The two lists cannot meet unless the groups overflow.)
-        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_a <= gpart_size && lb_base + tot_b <= gpart_size && lc_base + tot_c <= gpart_size;
+        const bool can_write = gbase + tot_g <= gpart_size && la_base + tot_a <= gpart_size && lb_base + tot_b <= gpart_size && lc_base + tot_c <= gpart_size &&
+                               ld_base + tot_d <= gpart_size;
         const bool rec_ok = rbase + tot_r <= rpart_size;
         uint32_t werr = 0;
         if (!can_write) werr |= WD_GROUP_OVERFLOW;
@@ -1294,7 +1316,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
                     //  in a dynamically indexed scratch array - 0.3 GB of private-memory traffic per pass)
                     const bool hashes = (uint64_t(key) & som_mask) != 0 || (need_all && all_ids);   // its id will be hashed
                     // (a lane's window is simple or it is not: the lane walks list A or list C - one upward cursor - and list B)
-                    const bool to_up = !simple || hashes, to_b = simple && !hashes && !settled;
+                    const bool to_up = simple ? hashes : !walk, to_b = simple ? (!hashes && !settled) : walk;
                     const uint64_t at = to_up ? up_slot : lb_slot;
                     if (to_up || to_b) d.k3_items[at] = make_uint4(uint32_t(gslot), win, (need && rec_ok) ? uint32_t(rslot) : 0xFFFFFFFFu, 0u);
                     up_slot += to_up ? 1u : 0u;
@@ -2529,11 +2551,12 @@ __device__ __forceinline__ uint64_t haplotype_id60(const DeviceBatch& d, bool ac
 // slot when the id is hashed, so the record is written once, complete, and never read again on the device (a separate id kernel re-read
 // 0.5 GB of records per config C pass and ran at 9 % of the HBM roofline; here its ALU work overlaps the other waves' gathers).
 // !LIST_A: list B - flags, and the record where the window kernel reserved a slot (haplotypes carried into a splice merge); no id.
-template <int SEQ_CAP, int LIST, int THREADS, int K3_ITEMS>   // LIST: 0 = A, 1 = B, 2 = C; THREADS: workgroup size; K3_ITEMS: list entries per lane, loaded together
+template <int SEQ_CAP, int LIST, int THREADS, int K3_ITEMS>   // LIST: 0 = A, 1 = B, 2 = C, 3 = D; THREADS: workgroup size; K3_ITEMS: list entries per lane, loaded together
 __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(DeviceBatch d) {   // (the message buffers of A and C allow < 3 waves per SIMD anyway: registers are free there)
     constexpr int K3_THREADS = THREADS;
-    constexpr bool LIST_A = LIST != 1;        // this launch hashes ids (lists A and C)
-    constexpr bool GENERAL = LIST == 2;       // ... and carries the general sequence walk (list C only: A and B hold simple windows)
+    constexpr bool LIST_A = LIST != 1;        // this launch hashes ids (lists A, C and D)
+    constexpr bool STOPSCAN = LIST >= 2;      // ... scans for stop codons (lists C and D: A and B hold windows that cannot have one)
+    constexpr bool WALK = LIST == 3;          // ... and carries the general sequence walk (list D only: the others hold simple windows)
     // the lane's LDS slot: ref | seq | germ while the sequences are built; list A re-uses it as the SHA-1 message buffer afterwards (the
     // sequences are in registers by then), so it is at least K3B_BUF_WORDS + 1 dwords there (odd stride: bank-conflict free)
     constexpr int K3_SLOT_DW = LIST_A ? ((K3Cfg<SEQ_CAP>::SLOT_DW > int(K3B_BUF_WORDS + 1) ? K3Cfg<SEQ_CAP>::SLOT_DW : int(K3B_BUF_WORDS + 1)) | 1) : K3Cfg<SEQ_CAP>::SLOT_DW;
@@ -2547,7 +2570,7 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
     const uint64_t part_size = 1ull << d.group_part_log2;
     // (the list's length and the pass's error word are needed only to VALIDATE entries: the first entries are fetched beside them, at
     //  addresses that depend on the workgroup's indices alone - one dependent load level less for every wave)
-    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST == 0 ? 8 : LIST == 1 ? 12 : 20)], (unsigned long long)part_size);
+    const uint64_t n_slots = min((unsigned long long)d.cursors[lpart * 32 + (LIST == 0 ? 8 : LIST == 1 ? 12 : LIST == 2 ? 20 : 28)], (unsigned long long)part_size);
     // Every wave takes K3_ITEMS tiles at once - K3_ITEMS list entries per lane - and issues the loads of ALL of them level by level (entry,
     // then window record + haplotype word, then reference bytes + columns + transcript, then the id's characters) before it works through
     // them one after the other: the kernel's time without the SHA-1 arithmetic was 0.91 of 1.42 ms, all of it dependent-load latency at
@@ -2570,7 +2593,7 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
         const uint64_t li = tile * K3_THREADS + tid;   // index into this allocator's list of items (k3_enqueue: A upwards, B downwards)
         I.li = li;
         const uint64_t lidx = li < part_size ? li : part_size - 1;   // (inside the allocator's sub-range whatever the list's length: validated in load_window)
-        const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + (LIST == 1 ? part_size - 1 - lidx : lidx) + (LIST == 2 ? d.group_cap : 0ull);
+        const uint64_t lpos = (uint64_t(lpart) << d.group_part_log2) + ((LIST & 1) ? part_size - 1 - lidx : lidx) + (LIST >= 2 ? d.group_cap : 0ull);
         // the item K2 listed: group slot, window, reserved record slot (one 16-byte load)
         const uint4 item = d.k3_items[lpos];
         I.g = item.x; I.w = item.y; I.rec_pre = item.z;
@@ -2687,8 +2710,8 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
                 if ((hap >> (ncols - 1 - k)) & 1) { const WinCol wc = d.win_cols[ws.col_off + k]; substitute(k, wc.pos, wc.info); }
             ns = ngm = ws.wlen;
             j = vis;
-        } else if constexpr (!GENERAL) {
-            atomicOr(d.err, WD_INTERNAL);   // a window that needs the general walk in list A / B (the window kernels send those to list C)
+        } else if constexpr (!WALK) {
+            atomicOr(d.err, WD_INTERNAL);   // a window that needs the general walk in list A / B / C (the window kernels send those to list D)
         } else {
             uint32_t pos_j = 0xFFFFFFFFu, info_j = 0, f_j = 0;
             // the first 8 columns (in walk order) are fetched up front so their loads overlap instead of forming a dependent chain
@@ -2792,7 +2815,7 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
         else if (ws.splice_pos == 0 && !insertion) nhi = this_len;
         bool stop = false;
         uint32_t nlen = nhi - nlo;
-        if constexpr (!GENERAL) {   // lists A / B hold windows for which the planner proved that no haplotype can hold a stop (WSF_NOSTOP): no codon loop in these kernels
+        if constexpr (!STOPSCAN) {   // lists A / B hold windows for which the planner proved that no haplotype can hold a stop (WSF_NOSTOP): no codon loop in these kernels
             if (!(ws.flags & WSF_NOSTOP)) atomicOr(d.err, WD_INTERNAL);
         } else if (nlen >= 3 && !(ws.flags & WSF_NOSTOP)) {   // WSF_NOSTOP: planner proved that no haplotype of this window can hold a stop
             if (!is_rev) {
@@ -2804,7 +2827,7 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
             }
         }
         bool differs;
-        if (!GENERAL || (ws.flags & WSF_SIMPLE)) differs = nsom > 0;   // a set somatic SNV always changes its byte (base or case)
+        if (!WALK || (ws.flags & WSF_SIMPLE)) differs = nsom > 0;   // a set somatic SNV always changes its byte (base or case)
         else {
             differs = seq_len != germ_len;
             if (!differs)
@@ -3244,12 +3267,16 @@ template void launch_k3_list<0>(const DeviceBatch&, uint64_t, hipStream_t);
 template void launch_k3_list<1>(const DeviceBatch&, uint64_t, hipStream_t);
 extern template void launch_k3_list<0>(const DeviceBatch&, uint64_t, hipStream_t);
 extern template void launch_k3_list<2>(const DeviceBatch&, uint64_t, hipStream_t);
+extern template void launch_k3_list<3>(const DeviceBatch&, uint64_t, hipStream_t);
 #elif MP_KPART == 5
 template void launch_k3_list<2>(const DeviceBatch&, uint64_t, hipStream_t);
+#elif MP_KPART == 6
+template void launch_k3_list<3>(const DeviceBatch&, uint64_t, hipStream_t);
 #endif
 #endif
 #if MP_IN_PART(4)
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c) {
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, uint64_t max_list_d,
+                          hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c, hipStream_t stream_d) {
     if (d.normal) {   // `microphaser normal`: every group has a record (all of them are in list A); ids by k3b_haplotype_ids afterwards
         if (max_list_a == 0) return;
         const uint64_t per_list = max_list_a / NPART + max_list_a / (4 * NPART) + K3_THREADS;
@@ -3266,7 +3293,8 @@ void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t ma
     }
     launch_k3_list<0>(d, max_list_a, stream_a);   // simple windows: sequences + records + ids
     launch_k3_list<1>(d, max_list_b, stream_b);   // simple windows: flags, carried records; independent of list A's groups, may run beside it
-    launch_k3_list<2>(d, max_list_c, stream_c);   // windows that need the general walk: everything
+    launch_k3_list<2>(d, max_list_c, stream_c);   // simple windows that may hold a stop codon: the same + the codon scan
+    launch_k3_list<3>(d, max_list_d, stream_d);   // windows that need the general walk: everything
 }
 
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream) {

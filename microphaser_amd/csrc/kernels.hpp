@@ -53,6 +53,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const WinW* winw;
     const uint32_t* lane_win;
     const uint32_t* win_trivial;    // bit per window: WSF_SIMPLE && WSF_NOSTOP and no record demand of its own (plan.hpp WW_TRIVIAL)
+    const uint32_t* win_walk;       // bit per window: !WSF_SIMPLE (needs the general sequence walk: list D)
     const uint32_t* win_simple;     // bit per window: WSF_SIMPLE && WSF_NOSTOP
     uint32_t n_lane_small, n_lane_all, lane_on, n_lane_mid;   // winw[0, small): <= 6 columns, [small, mid): 7-8, [mid, all): 9-16 (hash form)
     const WChunk* achunks;          // work items of k2a_admission: (exon, first read of the exon's range, count <= 64)
@@ -106,7 +107,8 @@ void launch_k2_window_lanes(const DeviceBatch& d, hipStream_t stream_small, hipS
 // somatic: three launches - list A (simple windows: sequences, records AND their SHA-1 ids), list B (simple windows: flags, carried records) and list C
 // (windows that need the general sequence walk: everything) - independent, may go to three streams;
 // normal: k3_window_seq_normal over list A on stream_a, ids by launch_k3b_haplotype_ids afterwards
-void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c);
+void launch_k3_window_seq(const DeviceBatch& d, uint64_t max_list_a, uint64_t max_list_b, uint64_t max_list_c, uint64_t max_list_d,
+                          hipStream_t stream_a, hipStream_t stream_b, hipStream_t stream_c, hipStream_t stream_d);
 void launch_k3b_haplotype_ids(const DeviceBatch& d, uint64_t max_recs, hipStream_t stream);   // `microphaser normal` only
 
 }  // namespace mp

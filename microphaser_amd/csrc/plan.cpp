@@ -2,6 +2,7 @@
 // reference: the data-independent part of phase_gene (src/microphasing.rs:905-942 loading,
 // :944-1342 scheduler) - see walk.hpp for the shared control flow.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <functional>
 #include <chrono>
@@ -473,11 +474,24 @@ static void route_lane_windows(Batch& b) {
     b.n_lane_mid = 0;
     b.win_trivial.assign(b.wins.size() / 32 + 2, 0u);
     b.win_simple.assign(b.wins.size() / 32 + 2, 0u);
-    for (size_t w = 0; w < b.wins.size(); w++) {
-        const WinStatic& ws = b.wins[w];
-        if ((ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP)) b.win_simple[w >> 5] |= 1u << (w & 31);
-        if (!b.normal && (ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP) && !(ws.need_recs & WS_MASK) && !(b.steps[ws.step].flags & SF_NEED_RECS))
-            b.win_trivial[w >> 5] |= 1u << (w & 31);
+    b.win_walk.assign(b.wins.size() / 32 + 2, 0u);
+    auto on_threads = [](size_t n, const std::function<void(size_t)>& f) {
+        if (n == 1) { f(0); return; }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < n; t++) th.emplace_back(f, t);
+        for (auto& x : th) x.join();
+    };
+    {   // the two per-window bitmaps, a range of whole words per thread
+        const size_t words = (b.wins.size() + 31) / 32, nt = std::max<size_t>(1, std::min<size_t>(host_threads(), words / 4096 + 1));
+        on_threads(nt, [&](size_t t) {
+            for (size_t w = words * t / nt * 32, we = std::min(b.wins.size(), words * (t + 1) / nt * 32); w < we; w++) {
+                const WinStatic& ws = b.wins[w];
+                if ((ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP)) b.win_simple[w >> 5] |= 1u << (w & 31);
+                if (!(ws.flags & WSF_SIMPLE)) b.win_walk[w >> 5] |= 1u << (w & 31);
+                if (!b.normal && (ws.flags & WSF_SIMPLE) && (ws.flags & WSF_NOSTOP) && !(ws.need_recs & WS_MASK) && !(b.steps[ws.step].flags & SF_NEED_RECS))
+                    b.win_trivial[w >> 5] |= 1u << (w & 31);
+            }
+        });
     }
     if (!b.lane_on) return;
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>(host_threads(), b.exons_w.size() / 64 + 1));
@@ -498,7 +512,8 @@ static void route_lane_windows(Batch& b) {
                 w.rr_lo = rn ? e.adm_off + (b.step_rlo[si] - e.read_lo) : 0;
                 const bool trivial = (b.win_trivial[st.win >> 5] >> (st.win & 31)) & 1u;
                 w.pack = rn | (nc << 10) | (rev ? 0u : WW_FWD) | ((st.flags & SF_NEED_RECS) ? WW_NEED_ALL : 0u) | (trivial ? WW_TRIVIAL : 0u) |
-                         ((b.wins[st.win].need_recs & WS_ALL_IDS) ? WW_ALL_IDS : 0u) | (((b.wins[st.win].flags & WSF_SIMPLE) && (b.wins[st.win].flags & WSF_NOSTOP)) ? WW_SIMPLE : 0u);
+                         ((b.wins[st.win].need_recs & WS_ALL_IDS) ? WW_ALL_IDS : 0u) | (((b.wins[st.win].flags & WSF_SIMPLE) && (b.wins[st.win].flags & WSF_NOSTOP)) ? WW_SIMPLE : 0u) |
+                         ((b.wins[st.win].flags & WSF_SIMPLE) ? 0u : WW_WALK);
                 w.wkey = rev ? ~st.sso : st.sso + uint32_t(st.wlen);
                 w.step = si;
                 w.col_hi = st.col_hi;
@@ -522,27 +537,27 @@ static void route_lane_windows(Batch& b) {
             }
         }
     };
-    if (nthreads == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nthreads; t++) th.emplace_back(work, t);
-        for (auto& x : th) x.join();
-    }
+    on_threads(nthreads, work);
     size_t n[3] = {0, 0, 0};
     for (const Part& P : parts) { n[0] += P.w[0].size(); n[1] += P.w[1].size(); n[2] += P.w[2].size(); }
     b.winw.resize(n[0] + n[1] + n[2]);
     b.lane_win.resize(n[0] + n[1] + n[2]);
     b.n_lane_small = uint32_t(n[0]);
     b.n_lane_mid = uint32_t(n[0] + n[1]);
-    size_t at[3] = {0, n[0], n[0] + n[1]};
-    for (const Part& P : parts)
+    // every part copies its three runs to their places (class by class, the parts in exon order)
+    std::vector<std::array<size_t, 3>> at(nthreads);
+    size_t run[3] = {0, n[0], n[0] + n[1]};
+    for (size_t t = 0; t < nthreads; t++)
+        for (int c = 0; c < 3; c++) { at[t][c] = run[c]; run[c] += parts[t].w[c].size(); }
+    on_threads(nthreads, [&](size_t t) {
+        Part& P = parts[t];
         for (int c = 0; c < 3; c++) {
-            if (!P.w[c].empty()) {
-                std::memcpy(static_cast<void*>(b.winw.data() + at[c]), P.w[c].data(), P.w[c].size() * sizeof(WinW));
-                std::memcpy(b.lane_win.data() + at[c], P.id[c].data(), P.id[c].size() * 4);
-            }
-            at[c] += P.w[c].size();
+            if (P.w[c].empty()) continue;
+            std::memcpy(static_cast<void*>(b.winw.data() + at[t][c]), P.w[c].data(), P.w[c].size() * sizeof(WinW));
+            std::memcpy(b.lane_win.data() + at[t][c], P.id[c].data(), P.id[c].size() * 4);
+            P.w[c] = PodVec<WinW>(); P.id[c] = PodVec<uint32_t>();
         }
+    });
 }
 
 // Decide which single-exon segments go to the window-parallel replay (plan.hpp ExonW) and cut them into work items.
@@ -614,6 +629,9 @@ static void route_window_parallel(Batch& b) {
             if (T.strand) { while (u < g.n_steps && b.steps[g.step_off + u].sso + u == e.sso0) u++; }
             else { while (u < g.n_steps && b.steps[g.step_off + u].sso == e.sso1 + (u - 1)) u++; }
             e.unit_steps = u;
+            uint32_t wmin = 255;
+            for (uint32_t k = 0; k < g.n_steps; k++) wmin = std::min<uint32_t>(wmin, b.steps[g.step_off + k].wlen);
+            e.wlen_min = wmin;
         }
         const uint32_t ei = uint32_t(P.exons.size());   // (range-local)
         P.exons.push_back(e);

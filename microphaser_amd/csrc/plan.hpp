@@ -67,6 +67,8 @@ struct ExonW {
     uint32_t unit_steps;            // steps [0, unit_steps) move by exactly one nt each: '+' sso(t) = sso1 + (t - 1) for t >= 1, '-' sso(t) = sso0 - t -
                                     // K2a then finds a read's first candidate step by arithmetic alone, without looking at the steps
     uint32_t consumers;             // EW_*: which kernels read K2a's outputs for this exon (it writes only what somebody reads)
+    uint32_t wlen_min;              // the shortest window (Step::wlen) of the exon's steps: on '-' K2a skips, by arithmetic, the steps at which even such a
+                                    // window would stick out beyond the read's end (a read becomes a candidate R steps before a window can lie inside it)
 };
 enum : uint32_t { EW_WAVE = 1,      // a wave-per-window kernel has a window here: AdmEntry
                   EW_LANE = 2 };    // the lane-per-window kernel has one: RowRec
@@ -76,7 +78,7 @@ struct ExonA {
     uint32_t step_off, n_steps, unit_steps, sso0;
     uint32_t sso1, first_key_lo, range, tr0;
     uint32_t f0, sl_f_lo, sl_f_hi, flags;      // flags: strand | consumers << 8
-    uint32_t adm_off, read0, pad0, pad1;       // read0: batch index of the first read of the exon's range
+    uint32_t adm_off, read0, wlen_min, pad1;   // read0: batch index of the first read of the exon's range
 };
 static_assert(sizeof(ExonA) == 64, "ExonA layout");
 struct AdmMap { uint32_t exon, read; };        // per admission-table entry: its exon and the batch index of its read
@@ -120,6 +122,8 @@ enum : uint32_t { WW_FWD = 1u << 16, WW_NEED_ALL = 1u << 17,
                   WW_TRIVIAL = 1u << 18,     // WSF_SIMPLE && WSF_NOSTOP and no record demand of its own: a group without a somatic column is settled by K2l
                   WW_SIMPLE = 1u << 20,      // WSF_SIMPLE && WSF_NOSTOP: K3 builds the window's sequences by byte substitution and needs no stop scan; the groups of
                                              // other windows go to K3's list C (one such lane would make its whole K3 wave run the per-base walk / the codon loop)
+                  WW_WALK = 1u << 21,        // !WSF_SIMPLE: the window's sequences need the general walk - its groups go to K3's list D (the other windows that are
+                                             // not WW_SIMPLE - simple, but a stop codon is possible - to list C)
                   WW_ALL_IDS = 1u << 19 };   // WS_ALL_IDS: every haplotype of the window gets an id (indel / frameshift context); without it only a
                                              // haplotype that sets a somatic column is hashed - the others go to K3's list B even when they need a record
 struct RowRecA {         // K2a output per (ExonW, read), first half (the second is the 64-bit support mask)
