@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64) void k2a_admission_flat(DeviceBatch d) {
 // table in its LDS column instead (entry = haplotype word << 8 | count; linear probing; at most 63 distinct words, so a probe always ends
 // at a free slot): one dependent LDS round trip per row instead of the wave-per-window kernel's ballots and readlanes (470 wave
 // instructions per WINDOW there, ~40 here); the keys come out ascending by repeated minimum over the lane's occupied slots.
-template <int HB, int STAGE_>   // STAGE_: RowRecs staged in LDS per pass (24 bytes each); 0 = gather from memory (experiments)
+template <int HB, int STAGE_, int GATHER_ = 8>   // STAGE_: RowRecs staged in LDS per pass (24 bytes each); 0 = straight from memory, GATHER_ rows at a time
 __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t first, uint32_t count) {
     constexpr bool HASH = HB > 8;
     constexpr uint32_t NW = HASH ? 64u : (1u << HB) / 4;   // table words per lane (direct: four 8-bit counters each; hash: one entry each); NW <= 64
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(64) void k2l_window_lanes(DeviceBatch d, uint32_t f
         if constexpr (STAGE_ == 0) {
             // (rows straight from memory: the loads of GATHER_BLK rows go out together, at clamped indices and unconditionally - a lane
             //  walks ~30 rows, and with one or two rows in flight every few rows cost a full memory round trip)
-            constexpr uint32_t GATHER_BLK = 8;
+            constexpr uint32_t GATHER_BLK = GATHER_;
             const uint32_t rn_max = wave_max(r_n);
             const uint32_t r_last = r_n ? r_n - 1 : 0u;
             const uint4* const ra = reinterpret_cast<const uint4*>(d.rr_a) + rr_lo;
@@ -3199,6 +3199,7 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream
     const uint32_t n_small = d.n_lane_small, n_wide = d.n_lane_mid - d.n_lane_small, n_hash = d.n_lane_all - d.n_lane_mid;
     const uint32_t lds_small = 4096 + 24 * STAGE, lds_wide = 16384 + 24 * STAGE;
     static const bool persistent = std::getenv("MP_K2L_PERSISTENT") != nullptr;   // experiments: a fixed grid that walks the tiles
+    static const bool gather16 = [] { const char* e = std::getenv("MP_K2L_GATHER"); return e && std::atoi(e) == 16; }();   // rows fetched together by the gather forms (default 8)
     if (n_small) {
         const uint32_t tiles = (n_small + 63) / 64, waves = min(32u, 163840u / lds_small);
         hipLaunchKernelGGL((k2l_window_lanes<K2L_SMALL_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_small, d, 0u, n_small);
@@ -3210,7 +3211,8 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream
         // config C, same box); MP_K2L_WIDE_STAGED=1 brings the staged form back for comparisons.
         static const bool wide_gather = std::getenv("MP_K2L_WIDE_STAGED") == nullptr;
         const uint32_t tiles = (n_wide + 63) / 64, waves = min(32u, 163840u / lds_wide);
-        if (wide_gather) hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, 0>), dim3(tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
+        if (wide_gather && gather16) hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, 0, 16>), dim3(tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
+        else if (wide_gather) hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, 0>), dim3(tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
         else hipLaunchKernelGGL((k2l_window_lanes<K2L_MAX_COLS, STAGE>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_wide, d, n_small, n_wide);
         HIP_CHECK_LAUNCH();
     }
@@ -3219,7 +3221,8 @@ static void launch_k2l(const DeviceBatch& d, hipStream_t stream_small, hipStream
         // not overlap, and staging them through LDS took one pass - barrier, reductions, a round of loads - per WINDOW (1.36 ms for
         // 0.66 M windows). Every lane reads its own window's records straight from memory instead (two loads in flight ahead).
         const uint32_t tiles = (n_hash + 63) / 64, waves = min(32u, 163840u / 16384u);
-        hipLaunchKernelGGL((k2l_window_lanes<K2L_HASH_COLS, 0>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_hash, d, d.n_lane_mid, n_hash);
+        if (gather16) hipLaunchKernelGGL((k2l_window_lanes<K2L_HASH_COLS, 0, 16>), dim3(tiles), dim3(64), 0, stream_hash, d, d.n_lane_mid, n_hash);
+        else hipLaunchKernelGGL((k2l_window_lanes<K2L_HASH_COLS, 0>), dim3(persistent ? min(tiles, 256u * waves) : tiles), dim3(64), 0, stream_hash, d, d.n_lane_mid, n_hash);
         HIP_CHECK_LAUNCH();
     }
 }

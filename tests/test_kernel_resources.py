@@ -16,7 +16,7 @@ HOT = [
     r"_ZN2mp14k1_pileup_bitsILi[12]E",
     r"_ZN2mp13k2a_admissionILi[12]E",
     r"_ZN2mp18k2a_admission_flatILi[12]ELi[12]E",
-    r"_ZN2mp16k2l_window_lanesILi(6|8|16)ELi(0|256)E",
+    r"_ZN2mp16k2l_window_lanesILi(6|8|16)ELi(0|256)ELi(8|16)E",
     r"_ZN2mp15k2w_window_rowsE",
     r"_ZN2mp21k2w_window_rows_multiILi\dELi[12]E",
     r"_ZN2mp13k3_window_seqILi(32|48)ELi[0123]ELi64ELi[12]E",
