@@ -3248,7 +3248,10 @@ void launch_k3_list(const DeviceBatch& d, uint64_t max_items, hipStream_t stream
     // phase on gather phase; the instantiations were dropped again.)
     static const int items = [] { const char* e = std::getenv("MP_K3_ITEMS"); return e && std::atoi(e) == 1 ? 1 : 2; }();   // list entries per lane (1: the round-2 form)
     const int T = K3_THREADS;
-    const int U = d.seq_cap <= 48 ? items : 1;
+    // (two entries per lane pay where the list fills the chip several times over - 7 M entries of list A at config C: 1.45 -> 1.37 ms; a
+    //  short list - list D, every list of a small batch - is a single round of waves, whose length two entries per lane would double:
+    //  config B 0.41 -> 0.46 ms when lists C and D arrived with two)
+    const int U = d.seq_cap <= 48 && max_items >= 640 * 1024 ? items : 1;
     const uint64_t per_wave = uint64_t(T) * uint64_t(U);
     const uint64_t per_list = max_items / NPART + max_items / (4 * NPART) + per_wave;
     dim3 grid(uint32_t(std::min<uint64_t>((per_list + per_wave - 1) / per_wave, 0x7FFFFFFFull)), NPART), block(T);
