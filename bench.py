@@ -275,7 +275,10 @@ def main():
                                    % (n_tx, depth, spacing, args.config, seed,
                                       "" if world == 1 else ", its genes dealt to the %d GPUs by estimated cost (LPT on CDS nt x depth)" % world),
                        "windows_total": int(total_windows), "windows_rank0": int(windows), "reads_rank0": int(st.n_reads), "variants_rank0": int(st.n_variants),
-                       "transcripts_rank0": int(st.n_transcripts), "window_len": 27, "sharding": "genes (LPT on cost), no data-path collective"},
+                       "transcripts_rank0": int(st.n_transcripts), "window_len": 27,
+                       "windows_counted_by": ("the consumer (main-ORF print_haplotypes calls of the reference, = the oracle's count)" if not args.no_consume else
+                                              "the PLANNER (--no-consume: includes the speculative windows past a stop codon, ~13 % more than the reference makes - "
+                                              "a kernel-timing run, its `value` is not the metric)"), "sharding": "genes (LPT on cost), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms, "rocprof_kernels": dom_kernels,
