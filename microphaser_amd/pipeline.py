@@ -44,3 +44,81 @@ def config_e_rank(ctx, ds, local_genes, global_genes, peptide_len=9, dist=None, 
     merged = merge_by_gene(shards)
     filtered = ctx.filter(merged["tsv"], peptidome) if merged["tsv"] else None
     return merged, peptidome, filtered
+
+
+def cost_ranges(costs, n_chunks):
+    """Contiguous gene ranges [lo, hi) of about equal estimated cost (at most n_chunks of them, none empty), in gene order."""
+    n, total = len(costs), sum(costs)
+    bounds, acc, k = [0], 0, 1
+    for g, c in enumerate(costs):
+        acc += c
+        if k < n_chunks and acc * n_chunks >= total * k and g + 1 < n:
+            bounds.append(g + 1)
+            k += 1
+    bounds.append(n)
+    bounds = sorted(set(bounds))
+    return [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i + 1] > bounds[i]]
+
+
+def phase_chunked(ds, n_chunks=4, device=0, window_len=27, contexts=None):
+    """`somatic` on ONE GPU in gene chunks whose legs overlap: while chunk i is phased, downloaded and consumed (host threads + the
+    download DMA), chunk i + 1 is planned, packed and uploaded on a second context of the same GPU (host threads + the upload DMA) -
+    the transfers and the GPU pass of one chunk hide behind the host work of the other (chunked, overlapped
+    transfers). Genes are independent (src/microphasing.rs:895-942), so the chunks' streams concatenate into the single-batch
+    output (TSV header once: shard.merge_streams). Returns (list of Results in gene order, windows); the caller reads or merges
+    the streams (the Results copy their text out of the library only when asked)."""
+    import ctypes
+    import queue
+    import threading
+    from . import Batch, Context, lib
+    ranges = cost_ranges(ds.gene_costs(), n_chunks)
+    own = contexts is None
+    ctxs = [Context(device), Context(device)] if own else list(contexts)
+    free = [threading.Semaphore(1) for _ in ctxs]
+    ready = queue.Queue()
+    errors = []
+
+    def producer():
+        try:
+            for i, (lo, hi) in enumerate(ranges):
+                c = i % len(ctxs)
+                free[c].acquire()   # the context holds one batch at a time: wait until its previous chunk has been consumed
+                if errors:
+                    break
+                h = ctypes.c_void_p()
+                ctxs[c]._check(lib().mp_batch_create(ctxs[c]._h, ds._h, MODE_SOMATIC, window_len, lo, hi, ctypes.byref(h)))
+                ready.put((c, Batch(ctxs[c], h, ds)))
+        except Exception as e:   # noqa: BLE001 - handed to the caller's thread
+            errors.append(e)
+        finally:
+            ready.put(None)
+
+    t = threading.Thread(target=producer, name="mp-chunk-planner")
+    t.start()
+    results, windows = [], 0
+    try:
+        while True:
+            item = ready.get()
+            if item is None:
+                break
+            c, b = item
+            try:
+                b.run()
+                r = b.results()
+                results.append(r)
+                windows += r.windows
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+            finally:
+                b.close()
+                free[c].release()
+    finally:
+        for s in free:   # (a producer blocked on a context after an error must be able to leave)
+            s.release()
+        t.join()
+        if own:
+            for c in ctxs:
+                c.close()
+    if errors:
+        raise errors[0]
+    return results, windows

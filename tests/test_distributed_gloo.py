@@ -62,6 +62,23 @@ dist.destroy_process_group()
 '''
 
 
+def test_cost_ranges_tile_the_genes_in_order():
+    """pipeline.cost_ranges: contiguous chunks of about equal cost, none empty, covering every gene once (phase_chunked's chunks)."""
+    import random
+    from microphaser_amd.pipeline import cost_ranges
+    rnd = random.Random(5)
+    for n in (0, 1, 2, 7, 100, 1000):
+        costs = [rnd.randrange(1, 1000) for _ in range(n)]
+        for k in (1, 2, 4, 8, 200):
+            r = cost_ranges(costs, k)
+            assert len(r) <= max(1, k) and all(hi > lo for lo, hi in r)
+            assert [lo for lo, _ in r] == ([0] + [hi for _, hi in r][:-1] if r else [])
+            assert (r[-1][1] if r else 0) == n
+            if n >= 100 and k <= 8:
+                total = sum(costs)
+                assert max(sum(costs[lo:hi]) for lo, hi in r) <= total / k + 1000
+
+
 def test_shard_range_tiles_in_order():
     from microphaser_amd.shard import shard_range
     for n in (0, 1, 7, 8, 20000):

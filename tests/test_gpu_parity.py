@@ -743,6 +743,21 @@ def test_gpu_flat_and_per_exon_admission_agree(ctx, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
+def test_gpu_chunked_overlapped_phasing_equals_the_single_batch(ctx):
+    """pipeline.phase_chunked: gene chunks planned + uploaded on a second context of the GPU while the previous chunk is phased, downloaded
+    and consumed - the concatenated streams are the single batch's bytes (genes are independent, src/microphasing.rs:895-942)."""
+    from microphaser_amd.pipeline import phase_chunked
+    from microphaser_amd.shard import merge_streams
+    ds = ctx.synth(6262, 90, 30.0, 5.4)
+    whole = ds.phase()
+    for chunks in (2, 5):
+        parts, windows = phase_chunked(ds, n_chunks=chunks)
+        assert len(parts) == chunks and windows == whole.windows
+        got = merge_streams([dict(fasta=r.fasta, normal_fasta=r.normal_fasta, tsv=r.tsv) for r in parts])
+        assert (got["fasta"], got["normal_fasta"], got["tsv"]) == (whole.fasta, whole.normal_fasta, whole.tsv)
+    assert whole.tsv.count(b"\n") > 500
+
+
 # ---- the phase_gene-level boundary, cost-balanced shards and the multi-rank config E driver
 @pytest.mark.parametrize("name", ["test_reverse", "splice_reverse_test", "splice_forward_test"])
 def test_gpu_decoded_records_in_reference_output_out(ctx, name):
