@@ -1,4 +1,7 @@
 #include "device.hpp"
+#include <chrono>
+#include <cstdio>
+#include <algorithm>
 
 #include <algorithm>
 #include <cstdlib>
@@ -52,7 +55,14 @@ void* DeviceContext::dalloc(size_t bytes) {
     void* p = nullptr;
     if (const char* lim = std::getenv("MP_TEST_ALLOC_LIMIT"))   // tests: allocations above this many bytes fail like an exhausted HBM
         if (bytes > std::strtoull(lim, nullptr, 10)) throw_hip(hipErrorOutOfMemory, __FILE__, __LINE__);
+    static const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+    if (dbg) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        alloc_ms_ += ms; alloc_calls_++;
+        if (ms > 5.0) std::fprintf(stderr, "[mp]     hipMalloc of %.1f MB took %.1f ms\n", double(bytes) / 1e6, ms);
+    }
     hbm_bytes_ += bytes;
     return p;
 }
@@ -167,19 +177,17 @@ void DeviceContext::upload(const Batch& b) {
 
 void DeviceContext::upload_impl(const Batch& b) {
     HIP_OK(hipSetDevice(device_));
+    const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    const auto t_up0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     free_batch();
-    // per read, for K1: the absolute index of the first variant at / after the read's start and the number of the gene's variants from
-    // there on - one load instead of the hops read -> gene -> variant range
-    PodVec<uint2> r_var(b.r_pos.size());
-    for (size_t g = 0; g + 1 < b.g_read_off.size(); g++) {
-        const uint32_t vb = b.g_var_off[g], nv = b.g_var_off[g + 1] - vb;
-        for (uint32_t i = b.g_read_off[g]; i < b.g_read_off[g + 1]; i++) r_var[i] = make_uint2(vb + b.r_varlo[i], nv - b.r_varlo[i]);
-    }
+    const double ms_free = ms_since(t_up0);
     d_.g_read_off = up(b.g_read_off);
     d_.g_var_off = up(b.g_var_off);
     d_.g_start = up(b.g_start);
     d_.g_ref_off = up(b.g_ref_off);
-    d_.r_var = up(r_var);
+    d_.n_genes = b.g_read_off.size() > 1 ? uint32_t(b.g_read_off.size() - 1) : 0u;
+    d_.r_var = static_cast<uint2*>(dalloc((b.r_pos.size() + 1) * sizeof(uint2))); allocs_.push_back(d_.r_var);   // filled by k0_read_variants below
     d_.r_pos = up(b.r_pos);
     d_.r_end = up(b.r_end);
     d_.r_lseq = up(b.r_lseq);
@@ -282,10 +290,32 @@ void DeviceContext::upload_impl(const Batch& b) {
         d_.exons_a = static_cast<ExonA*>(dalloc(size_t(d_.n_exons_w) * sizeof(ExonA))); allocs_.push_back(d_.exons_a);
         d_.adm_map = static_cast<AdmMap*>(dalloc(size_t(b.n_adm) * sizeof(AdmMap))); allocs_.push_back(d_.adm_map);
     }
+    const double ms_inputs = ms_since(t_up0);
     alloc_outputs();
+    const double ms_alloc = ms_since(t_up0);
+    uint64_t up_bytes = 0;
+    for (const XferSeg& sgm : pending_up_) up_bytes += sgm.bytes;
+    if (dbg) {   // the largest uploads
+        std::vector<uint64_t> sz;
+        for (const XferSeg& sgm : pending_up_) sz.push_back(sgm.bytes);
+        std::sort(sz.rbegin(), sz.rend());
+        std::fprintf(stderr, "[mp]   upload: %zu arrays, %.2f GB; the largest (MB):", pending_up_.size(), double(up_bytes) / 1e9);
+        for (size_t k = 0; k < sz.size() && k < 14; k++) std::fprintf(stderr, " %.0f", double(sz[k]) / 1e6);
+        std::fprintf(stderr, "\n[mp]   upload sizes (MB): reads fields %.0f, seq pool %.0f, cigar %.0f, ref %.0f, steps %.0f (+ side arrays %.0f), wins %.0f, win_cols %.0f, winw %.0f\n",
+                     double(b.r_pos.size()) * (4 * 7 + 8 * 3) / 1e6, double(b.seq_pool.size()) / 1e6, double(b.cigar_pool.size()) * 4 / 1e6, double(b.ref_pool.size()) / 1e6,
+                     double(b.steps.size()) * sizeof(Step) / 1e6, double(b.steps.size()) * 13 / 1e6 + double(b.step_aux.size()) * sizeof(b.step_aux[0]) / 1e6,
+                     double(b.wins.size()) * sizeof(WinStatic) / 1e6, double(b.win_cols.size()) * sizeof(WinCol) / 1e6, double(b.winw.size()) * (sizeof(WinW) + 4) / 1e6);
+    }
     xfer(pending_up_, true);
     pending_up_.clear();
+    // (One allocation for everything upload() places was tried: the ~60 hipMalloc calls then cost 24 instead of 170 ms - and the result
+    //  arenas and the copies behind them 60 + 75 ms more: what costs is making ~14 GB of fresh device memory usable, not the calls.)
+    if (dbg) std::fprintf(stderr, "[mp]   upload: %u hipMalloc calls took %.1f ms in all\n", alloc_calls_, alloc_ms_);
+    if (dbg)
+        std::fprintf(stderr, "[mp]   upload: release of the previous batch %.1f ms, per-read table + input allocations %.1f ms, result arenas %.1f ms, copies %.1f ms\n",
+                     ms_free, ms_inputs - ms_free, ms_alloc - ms_inputs, ms_since(t_up0) - ms_alloc);
     achunk_exons_ = PodVec<ExonW>();
+    launch_k0_read_variants(d_, stream_);
     if (d_.k2a_flat) launch_k0_pack_admission(d_, stream_);
     if (d_.win_blobs) launch_k0_pack_windows(d_, stream_);   // (once per batch: K3's per-window records, plan.hpp WinBlob)
     HIP_OK(hipStreamSynchronize(stream_));

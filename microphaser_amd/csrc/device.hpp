@@ -65,6 +65,7 @@ class DeviceContext {
     void* pin_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pin_ev_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t xfer_stream_ = nullptr;
+    double alloc_ms_ = 0; unsigned alloc_calls_ = 0;   // MP_DEBUG: time spent in hipMalloc
     std::vector<XferSeg> pending_up_;     // upload(): the arrays to copy once everything is allocated
     PodVec<ExonW> achunk_exons_;          // upload(): staging of DeviceBatch::achunk_exons
     void xfer(const std::vector<XferSeg>& segs, bool to_device);

@@ -32,6 +32,25 @@ namespace mp {
 
 // ====================================================================== K0 (layout, once per batch)
 #if MP_IN_PART(0)
+// per read, for K1: the absolute index of the first variant at / after the read's start and the number of the gene's variants from
+// there on - one load instead of the hops read -> gene -> variant range (was a serial host loop over all reads at upload: ~100 ms)
+__global__ __launch_bounds__(256) void k0_read_variants(DeviceBatch d) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= d.n_reads) return;
+    uint32_t lo = 0, hi = d.n_genes;   // g_read_off[lo] <= i < g_read_off[hi] (offsets ascend; genes without reads share their successor's)
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (d.g_read_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t vb = d.g_var_off[lo], nv = d.g_var_off[lo + 1] - vb, vl = d.r_varlo[i];
+    d.r_var[i] = make_uint2(vb + vl, nv - vl);
+}
+void launch_k0_read_variants(const DeviceBatch& d, hipStream_t stream) {
+    if (!d.n_reads || !d.n_genes) return;
+    hipLaunchKernelGGL(k0_read_variants, dim3((d.n_reads + 255) / 256), dim3(256), 0, stream, d);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__);
+}
 __global__ __launch_bounds__(256) void k0_pack_windows(DeviceBatch d) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= d.n_wins) return;

@@ -13,7 +13,8 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
     const uint32_t *g_read_off, *g_var_off, *g_start;
     const uint64_t* g_ref_off;
     // reads
-    const uint2* r_var;           // per read: {absolute index of its first variant (g_var_off + r_varlo), variants of the gene from there on}
+    uint32_t n_genes, n_genes_pad_;
+    uint2* r_var;                 // per read: {absolute index of its first variant (g_var_off + r_varlo), variants of the gene from there on}
     const uint32_t *r_pos, *r_end, *r_lseq, *r_ncig, *r_dup;
     const uint64_t *r_cigoff, *r_seqoff;
     const uint32_t* cigar_pool;
@@ -95,6 +96,7 @@ struct DeviceBatch {  // device pointers (all hipMalloc'ed by DeviceContext)
 
 // rows_per_lane in {1,2,4,8,16}. All launches are asynchronous on `stream`.
 void launch_k0_pack_admission(const DeviceBatch& d, hipStream_t stream); // once per batch, after the upload: fills exons_a and adm_map
+void launch_k0_read_variants(const DeviceBatch& d, hipStream_t stream);  // once per batch, after the upload: fills r_var
 void launch_k0_pack_windows(const DeviceBatch& d, hipStream_t stream);   // once per batch, after the upload: fills win_blobs
 void launch_k1_pileup_bits(const DeviceBatch& d, hipStream_t stream);
 void launch_k2_window_replay(const DeviceBatch& d, int rows_per_lane, hipStream_t stream);
