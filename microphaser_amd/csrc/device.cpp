@@ -36,6 +36,7 @@ DeviceContext::DeviceContext(int device) : device_(device) {
 DeviceContext::~DeviceContext() {
     hipSetDevice(device_);
     free_batch();
+    pool_trim(true);
     for (auto& p : pin_) if (p) (void)hipHostFree(p);
     for (auto& ev : pin_ev_) if (ev) (void)hipEventDestroy(ev);
     if (xfer_stream_) (void)hipStreamDestroy(xfer_stream_);
@@ -56,8 +57,25 @@ void* DeviceContext::dalloc(size_t bytes) {
     if (const char* lim = std::getenv("MP_TEST_ALLOC_LIMIT"))   // tests: allocations above this many bytes fail like an exhausted HBM
         if (bytes > std::strtoull(lim, nullptr, 10)) throw_hip(hipErrorOutOfMemory, __FILE__, __LINE__);
     static const bool dbg = std::getenv("MP_DEBUG") != nullptr;
+    static const bool pooled = std::getenv("MP_NO_POOL") == nullptr;
+    const size_t want = std::max<size_t>(bytes, 256);
+    if (pooled) {   // the smallest free block that holds the request (and is not absurdly larger), cleared like a fresh allocation
+        PoolBlock* best = nullptr;
+        for (PoolBlock& k : pool_)
+            if (!k.in_use && k.cap >= want && k.cap <= 2 * want + (size_t(16) << 20) && (!best || k.cap < best->cap)) best = &k;
+        if (best) {
+            best->in_use = best->used_now = true;
+            HIP_OK(hipMemsetAsync(best->p, 0, want, stream_));
+            hbm_bytes_ += bytes;
+            alloc_reused_++;
+            return best->p;
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+    hipError_t me = hipMalloc(&p, want);
+    if (me == hipErrorOutOfMemory && pooled) { (void)hipGetLastError(); pool_trim(true); me = hipMalloc(&p, want); }   // (give the idle blocks back first)
+    HIP_OK(me);
+    if (pooled) pool_.push_back(PoolBlock{p, want, true, true});
     if (dbg) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         alloc_ms_ += ms; alloc_calls_++;
@@ -132,28 +150,57 @@ void DeviceContext::xfer(const std::vector<XferSeg>& segs, bool to_device) {
         }
         HIP_OK(hipStreamSynchronize(xfer_stream_));
     } else {
-        // DMA into slots up to XFER_SLOTS ahead; drain a slot (host threads) as soon as its DMA has completed
+        // DMA into slots up to XFER_SLOTS ahead; drain a slot (host threads) as soon as its DMA has completed. A slot takes a RUN of
+        // pieces whose host destinations follow one another (the used prefixes of the 64 allocators' sub-ranges of one array: separate
+        // ranges on the device, one array on the host): one DMA per piece, ONE drain of the whole slot by all the threads - a slot per
+        // 12 MB segment had left the drain to three threads at a time.
+        struct Run { size_t first, count, len; char* host; };   // pieces chunks[first, first + count)
+        std::vector<Run> runs;
+        for (size_t i = 0; i < n; i++) {
+            const Chunk& c = chunks[i];
+            char* const h = segs[c.seg].host + c.off;
+            if (!runs.empty() && runs.back().host + runs.back().len == h && runs.back().len + c.len <= XFER_SLOT_BYTES) { runs.back().count++; runs.back().len += c.len; }
+            else runs.push_back(Run{i, 1, c.len, h});
+        }
+        const size_t nr = runs.size();
         size_t issued = 0;
         auto issue = [&] {
-            const Chunk& c = chunks[issued];
+            const Run& r = runs[issued];
             const size_t k = issued % XFER_SLOTS;
-            HIP_OK(hipMemcpyAsync(pin_[k], segs[c.seg].dev + c.off, c.len, hipMemcpyDeviceToHost, xfer_stream_));
+            size_t at = 0;
+            for (size_t j = r.first; j < r.first + r.count; j++) {
+                const Chunk& c = chunks[j];
+                HIP_OK(hipMemcpyAsync(static_cast<char*>(pin_[k]) + at, segs[c.seg].dev + c.off, c.len, hipMemcpyDeviceToHost, xfer_stream_));
+                at += c.len;
+            }
             HIP_OK(hipEventRecord(pin_ev_[k], xfer_stream_));
             issued++;
         };
-        while (issued < n && issued < XFER_SLOTS) issue();
-        for (size_t i = 0; i < n; i++) {
+        while (issued < nr && issued < XFER_SLOTS) issue();
+        for (size_t i = 0; i < nr; i++) {
             const size_t k = i % XFER_SLOTS;
             HIP_OK(hipEventSynchronize(pin_ev_[k]));
-            const Chunk& c = chunks[i];
-            copy_parallel(segs[c.seg].host + c.off, static_cast<const char*>(pin_[k]), c.len, nthreads);
-            if (issued < n) issue();   // (slot k is free again: chunk i + XFER_SLOTS goes there)
+            copy_parallel(runs[i].host, static_cast<const char*>(pin_[k]), runs[i].len, nthreads);
+            if (issued < nr) issue();   // (slot k is free again: run i + XFER_SLOTS goes there)
         }
     }
 }
 
+void DeviceContext::dfree(void* p) {
+    for (PoolBlock& k : pool_)
+        if (k.p == p) { k.in_use = false; return; }
+    (void)hipFree(p);   // (not pooled: MP_NO_POOL)
+}
+void DeviceContext::pool_trim(bool all) {   // frees the idle blocks (all of them, or those the current batch did not take)
+    std::vector<PoolBlock> keep;
+    for (PoolBlock& k : pool_) {
+        if (!k.in_use && (all || !k.used_now)) (void)hipFree(k.p);
+        else keep.push_back(k);
+    }
+    pool_.swap(keep);
+}
 void DeviceContext::free_outputs() {
-    for (void* p : out_allocs_) (void)hipFree(p);
+    for (void* p : out_allocs_) dfree(p);
     out_allocs_.clear();
     hbm_bytes_ -= out_bytes_;
     out_bytes_ = 0;
@@ -163,7 +210,7 @@ void DeviceContext::free_outputs() {
 void DeviceContext::free_batch() {
     pending_up_.clear();
     free_outputs();
-    for (void* p : allocs_) (void)hipFree(p);
+    for (void* p : allocs_) dfree(p);
     allocs_.clear();
     hbm_bytes_ = 0;
     out_bytes_ = 0;
@@ -181,6 +228,8 @@ void DeviceContext::upload_impl(const Batch& b) {
     const auto t_up0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     free_batch();
+    for (PoolBlock& k : pool_) k.used_now = false;
+    alloc_ms_ = 0; alloc_calls_ = alloc_reused_ = 0;
     const double ms_free = ms_since(t_up0);
     d_.g_read_off = up(b.g_read_off);
     d_.g_var_off = up(b.g_var_off);
@@ -310,7 +359,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     pending_up_.clear();
     // (One allocation for everything upload() places was tried: the ~60 hipMalloc calls then cost 24 instead of 170 ms - and the result
     //  arenas and the copies behind them 60 + 75 ms more: what costs is making ~14 GB of fresh device memory usable, not the calls.)
-    if (dbg) std::fprintf(stderr, "[mp]   upload: %u hipMalloc calls took %.1f ms in all\n", alloc_calls_, alloc_ms_);
+    if (dbg) std::fprintf(stderr, "[mp]   upload: %u hipMalloc calls took %.1f ms in all; %u blocks came from the context's pool\n", alloc_calls_, alloc_ms_, alloc_reused_);
     if (dbg)
         std::fprintf(stderr, "[mp]   upload: release of the previous batch %.1f ms, per-read table + input allocations %.1f ms, result arenas %.1f ms, copies %.1f ms\n",
                      ms_free, ms_inputs - ms_free, ms_alloc - ms_inputs, ms_since(t_up0) - ms_alloc);
@@ -319,6 +368,7 @@ void DeviceContext::upload_impl(const Batch& b) {
     if (d_.k2a_flat) launch_k0_pack_admission(d_, stream_);
     if (d_.win_blobs) launch_k0_pack_windows(d_, stream_);   // (once per batch: K3's per-window records, plan.hpp WinBlob)
     HIP_OK(hipStreamSynchronize(stream_));
+    pool_trim(false);   // idle blocks this batch had no use for go back to the device
 }
 
 void DeviceContext::alloc_outputs() {
@@ -503,14 +553,15 @@ void DeviceContext::download(HostResults& r) {
     for (uint32_t p = 0; p < NPART; p++) {   // the used prefix of every allocator's sub-range, back to back
         r.group_prefix[p] = go;
         r.rec_prefix[p] = ro;
-        seg(r.groups.data() + go, d_.groups + (uint64_t(p) << glog_), used_g_[p] * sizeof(Group));
-        seg(r.gsum.data() + go, d_.gsum + (uint64_t(p) << glog_), used_g_[p] * sizeof(GroupSum));
-        seg(r.recs.data() + ro * d_.rec_stride, d_.recs + (uint64_t(p) << rlog_) * d_.rec_stride, used_r_[p] * d_.rec_stride);
         go += used_g_[p];
         ro += used_r_[p];
     }
     r.group_prefix[NPART] = go;
     r.rec_prefix[NPART] = ro;
+    // array by array: consecutive segments then have consecutive host destinations, and xfer() packs them into full staging slots
+    for (uint32_t p = 0; p < NPART; p++) seg(r.groups.data() + r.group_prefix[p], d_.groups + (uint64_t(p) << glog_), used_g_[p] * sizeof(Group));
+    for (uint32_t p = 0; p < NPART; p++) seg(r.gsum.data() + r.group_prefix[p], d_.gsum + (uint64_t(p) << glog_), used_g_[p] * sizeof(GroupSum));
+    for (uint32_t p = 0; p < NPART; p++) seg(r.recs.data() + r.rec_prefix[p] * d_.rec_stride, d_.recs + (uint64_t(p) << rlog_) * d_.rec_stride, used_r_[p] * d_.rec_stride);
     xfer(segs, false);   // pipelined through the pinned ring: DMA of one slot beside the host threads draining the others
 }
 

@@ -65,7 +65,17 @@ class DeviceContext {
     void* pin_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pin_ev_[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t xfer_stream_ = nullptr;
-    double alloc_ms_ = 0; unsigned alloc_calls_ = 0;   // MP_DEBUG: time spent in hipMalloc
+    double alloc_ms_ = 0; unsigned alloc_calls_ = 0, alloc_reused_ = 0;   // MP_DEBUG: time spent in hipMalloc; blocks taken from the pool
+    // Device memory is kept by the context across batches: making ~14 GB of FRESH device memory usable costs ~170 ms at config C (the
+    // allocations, then the first copies and kernels that touch it), a fifth of batch_create, for every batch - a service, the gene
+    // chunks of config E or of phase_chunked, the shards of a multi-GPU run phase batch after batch on one context. A block a batch
+    // gives back stays in the pool; the next batch takes the smallest free block that holds its request and clears it (a fresh
+    // allocation reads as zeros; a few ms for a whole batch at HBM speed). Blocks the next batch did not take are freed after its upload,
+    // so the pool never holds more than one batch's working set beside the resident one. MP_NO_POOL=1: plain hipMalloc / hipFree.
+    struct PoolBlock { void* p; size_t cap; bool in_use; bool used_now; };
+    std::vector<PoolBlock> pool_;
+    void dfree(void* p);
+    void pool_trim(bool all);
     std::vector<XferSeg> pending_up_;     // upload(): the arrays to copy once everything is allocated
     PodVec<ExonW> achunk_exons_;          // upload(): staging of DeviceBatch::achunk_exons
     void xfer(const std::vector<XferSeg>& segs, bool to_device);
