@@ -288,10 +288,11 @@ struct ConsumerHooks {
             }
             double frame_frequency = freq;  // :605-631
             if (shift_is_set && frame == 0) frame = shift_in_window;
-            fsf.emplace(frame, std::make_pair(0.0, false));
-            if (shift_in_window == 0) frame_frequency = freq * fsf.at(frame).first;
+            // (try_emplace: `emplace` builds its node before it looks the key up - a heap allocation per haplotype for an entry that nearly always exists)
+            const std::pair<double, bool>& fs_entry = fsf.try_emplace(frame, 0.0, false).first->second;
+            if (shift_in_window == 0) frame_frequency = freq * fs_entry.first;
             if (shift_in_window == 0 && key.hframe > 0 && frame == 0) frame_frequency = 0.0;
-            const bool germ_cleared = (indel && insertion) || (shift_in_window == 0 && (fsf.at(frame).second || (has_frameshift && differs)));
+            const bool germ_cleared = (indel && insertion) || (shift_in_window == 0 && (fs_entry.second || (has_frameshift && differs)));
             const uint64_t seq_len = rec ? rec->seq_len : ws.wlen;
             const uint64_t germ_len = germ_cleared ? 0 : (rec ? rec->germ_len : ws.wlen);
             const bool germ_ne_seq = germ_cleared ? (seq_len != 0) : differs;
