@@ -166,7 +166,7 @@ struct ConsumerHooks {
     }
 
     std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame_in, FsFreq fsf,
-                                                 bool is_first_exon_window) {
+                                                 bool is_first_exon_window, std::vector<HapSeq>&& recycled) {
         PROF(1);
         const Step& st = b.steps[cur_step];
         if (!(st.flags & SF_PRINT)) throw Error("internal error: print_haplotypes at a step the planner did not schedule");
@@ -256,7 +256,8 @@ struct ConsumerHooks {
         const uint64_t offset = sg.sso, splice_pos = sg.splice_pos, splice_gap = sg.splice_gap;
         const uint64_t wl = eg.ewl;  // print_haplotypes' window_len parameter (:1421)
         const bool boundary = (ws.need_recs & WS_CARRY) != 0;  // haplotypes feed a splice-side merge
-        std::vector<HapSeq> haplotypes_vec;
+        std::vector<HapSeq> haplotypes_vec(std::move(recycled));   // (the buffer of the vector the last result replaced)
+        haplotypes_vec.clear();
         haplotypes_vec.reserve(keys.size());
         uint64_t shift_in_window = 0;
         for (const Key& key : keys) {
@@ -712,7 +713,7 @@ struct NormalConsumerHooks {
     }
 
     // print_haplotypes (reference: src/normal_microphasing.rs:341-647)
-    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
+    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool, std::vector<HapSeq>&& recycled) {
         const Step& st = b.steps[cur_step];
         if (!(st.flags & SF_PRINT)) throw Error("internal error: print_haplotypes at a step the planner did not schedule");
         const WinStatic& ws = b.wins[st.win];
@@ -730,7 +731,8 @@ struct NormalConsumerHooks {
         const uint64_t wl = eg.ewl;
         const bool boundary = (ws.need_recs & WS_CARRY) != 0;
         const uint32_t nrows = wd.nrows;
-        std::vector<HapSeq> haplotypes_vec;
+        std::vector<HapSeq> haplotypes_vec(std::move(recycled));
+        haplotypes_vec.clear();
         bool any_counted = false;
         for (uint32_t k = 0; k < wd.ngroups; k++) any_counted |= res.grp(uint64_t(wd.group_off) + k).count != 0;
         for (uint32_t k = 0; k < wd.ngroups; k++) {

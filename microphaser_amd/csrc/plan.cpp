@@ -356,13 +356,15 @@ struct PlannerHooksT {
         if (fs_seen) ensure_window(eg, sg);
     }
 
-    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool) {
+    std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom& eg, const StepGeom& sg, uint64_t frame, FsFreq fsf, bool, std::vector<HapSeq>&& recycled) {
         ensure_window(eg, sg);
         last_print_win = b.steps[cur_step].win;
         last_print_frame = frame;
         if (frame == 0) b.n_main_windows++;
-        fsf.emplace(frame, std::make_pair(1.0, false));
-        std::vector<HapSeq> v(1);
+        fsf.try_emplace(frame, 1.0, false);   // (no node is built when the entry exists)
+        std::vector<HapSeq> v(std::move(recycled));
+        v.clear();
+        v.resize(1);
         return {std::move(v), std::move(fsf)};
     }
 

@@ -120,7 +120,8 @@ struct VarIndex {
 //   void on_exon(const ExonGeom&);
 //   void on_step(const ExonGeom&, const StepGeom&, const std::vector<size_t>& new_cols_fwd_idx);
 //       called once per step after the column delta is known (columns are appended in the given order)
-//   std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom&, const StepGeom&, uint64_t frame, FsFreq, bool is_first_exon_window);
+//   std::pair<std::vector<HapSeq>, FsFreq> print(const ExonGeom&, const StepGeom&, uint64_t frame, FsFreq, bool is_first_exon_window,
+//                                                std::vector<HapSeq>&& recycled);   // recycled: a vector whose buffer the result may take over
 //   void begin_step();                   // top of every window-loop iteration (the previous step is complete)
 //   void routed(bool to_prev_hap_vec);   // which carry-over vector the last print's haplotypes went to
 //   void splice_merge(const ExonGeom&, const StepGeom&, uint64_t exon_rest, std::map<uint64_t,uint64_t>& frameshifts,
@@ -136,6 +137,7 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
     if (is_fwd) frameshifts[0] = 0; else frameshifts[gene.end()] = 0;
     uint64_t exon_rest = 0;
     std::vector<HapSeq> prev_hap_vec, hap_vec;
+    std::vector<HapSeq> spare;   // the vector the last print's result replaced: its buffer goes to the next print (a heap allocation per window otherwise)
     FsFreq frameshift_frequencies;
     frameshift_frequencies[0] = {1.0, false};
     size_t last_window_vars = 0;
@@ -285,7 +287,7 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
                         exon_rest = sg.rest;
                         if (eg.ewl < 3) exon_rest = eg.ewl;
                     }
-                    auto res = hooks.print(eg, sg, frameshift, std::move(frameshift_frequencies), is_first_exon_window);
+                    auto res = hooks.print(eg, sg, frameshift, std::move(frameshift_frequencies), is_first_exon_window, std::move(spare));
                     frameshift_frequencies = std::move(res.second);
                     bool to_prev;
                     if constexpr (Hooks::kNormal) {  // src/normal_microphasing.rs:1113-1122
@@ -295,8 +297,9 @@ void walk_transcript(const Gene& gene, const Transcript& transcript, const VarIn
                         if (res.first.empty() || !frameshift_frequencies.count(frameshift)) stopped_frameshift = key;
                         to_prev = exon_rest < 3 && (!eg.is_short || eg.is_first) && !has_frameshift;  // :1445-1454
                     }
-                    if (to_prev) prev_hap_vec = std::move(res.first);
-                    else hap_vec = std::move(res.first);
+                    if (to_prev) std::swap(prev_hap_vec, res.first);
+                    else std::swap(hap_vec, res.first);
+                    spare = std::move(res.first);
                     hooks.routed(to_prev);
                     if constexpr (!Hooks::kNormal) {
                         if (frameshift != 0 && frameshift_frequencies.count(frameshift) && frameshift_frequencies.at(frameshift).first == 0.0)
