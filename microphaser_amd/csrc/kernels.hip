@@ -2729,6 +2729,33 @@ __global__ __launch_bounds__(THREADS, LIST != 1 ? 2 : 4) void k3_window_seq(Devi
                 if ((hap >> (ncols - 1 - k)) & 1) { const WinCol wc = d.win_cols[ws.col_off + k]; substitute(k, wc.pos, wc.info); }
             ns = ngm = ws.wlen;
             j = vis;
+            // The walk's inner loop has no window bound (:479): a set SNV at the window's LAST base moves the cursor to window_end, where a
+            // column sitting exactly there is applied too (one more base), and so on along a gap-free run of columns; the run ends at its
+            // first column the haplotype does not set (visited, not applied). The planner leaves such windows "simple" only when the run is
+            // SNVs at consecutive positions (plan.cpp); no other simple window has a column at window_end behind one at the last base.
+            if (STOPSCAN && vis > 0 && vis < ncols) {   // (such a window is never WSF_NOSTOP: lists C / D only)
+                const uint32_t dq_last = is_rev ? ncols - vis : vis - 1;   // the last column of the prefix, in deque order
+                const WinCol lc = d.win_cols[ws.col_off + dq_last];
+                if (lc.pos + 1 == window_end && ((hap >> (ncols - 1 - dq_last)) & 1)) {
+                    uint32_t cnt = 0;
+                    for (uint32_t wi = vis; wi < ncols; wi++) {
+                        const uint32_t dq = is_rev ? ncols - 1 - wi : wi;
+                        const WinCol wc = d.win_cols[ws.col_off + dq];
+                        if (wc.pos != window_end + cnt) break;
+                        j = wi + 1;
+                        if (!((hap >> (ncols - 1 - dq)) & 1)) break;
+                        const uint32_t off = uint32_t(ws.wlen) + cnt;
+                        const uint8_t r = ref_at(wc.pos);
+                        const uint8_t alt = uint8_t(wc.info >> VI_ALT_SHIFT);
+                        const uint8_t sw = is_upper(r) ? to_lower(alt) : alt;
+                        if (off < uint32_t(SEQ_CAP)) { seq[off] = sw; germ[off] = (wc.info & VI_GERMLINE) ? sw : r; }
+                        ns++; ngm++; cnt++;
+                        if (!(wc.info & VI_GERMLINE)) nsom++;
+                        nvar++;
+                        prof_set |= 1ull << wi;
+                    }
+                }
+            }
         } else if constexpr (!WALK) {
             atomicOr(d.err, WD_INTERNAL);   // a window that needs the general walk in list A / B / C (the window kernels send those to list D)
         } else {

@@ -134,6 +134,7 @@ struct PlannerHooksT {
             auto col = [&](size_t k) -> const Variant& { return vars[is_fwd ? cols[k] : cols[cols.size() - 1 - k]]; };
             uint64_t prev = 0;
             size_t e = 0;
+            bool tail = false;   // a run of columns right behind the window that a set SNV at the window's last base pulls in (below)
             for (; e < cols.size(); e++) {
                 const Variant& v = col(e);
                 if (v.kind != VK_SNV || v.pos < st.sso || v.pos >= uint64_t(st.sso) + st.wlen || (e > 0 && v.pos <= prev)) break;
@@ -146,7 +147,17 @@ struct PlannerHooksT {
                 if (!beyond && !behind) simple = false;
                 // the inner loop of the walk (`while j < ncols && i == pos_j`, :479) has no window bound: an applied SNV at the
                 // window's last base moves the cursor to window_end, where a column sitting exactly there is applied too
-                if (beyond && e > 0 && v.pos == uint64_t(st.sso) + st.wlen && prev + 1 == v.pos) simple = false;
+                // - still byte substitution when the columns from there on are SNVs at consecutive positions (one more base per applied column,
+                // the run ends at its first column the haplotype does not set) and what follows the run lies strictly beyond it; the window
+                // may then hold more than wlen bases, so it is never WSF_NOSTOP (K3's list C: substitution + codon scan). At a variant every
+                // 1.35 nt (config D) most windows are of this kind; they used to take the general per-base walk.
+                if (beyond && e > 0 && v.pos == uint64_t(st.sso) + st.wlen && prev + 1 == v.pos) {
+                    size_t t = e;
+                    uint64_t expect = uint64_t(st.sso) + st.wlen;
+                    while (t < cols.size() && col(t).kind == VK_SNV && col(t).pos == expect) { t++; expect++; }
+                    if (t < cols.size() && col(t).pos <= expect) simple = false;   // an indel at the run's end, or a second ALT of one of its sites: the general walk
+                    else tail = true;
+                }
             }
             walk_prefix = uint32_t(e);
             if (!simple && !NORMAL && std::getenv("MP_DEBUG_SIMPLE")) {
@@ -155,7 +166,7 @@ struct PlannerHooksT {
                 std::fprintf(stderr, "nonsimple %s sso %u wlen %u cols:%s\n", is_fwd ? "+" : "-", st.sso, unsigned(st.wlen), m.c_str());
             }
             if (simple) w.flags |= WSF_SIMPLE;
-            if (simple) {   // WSF_NOSTOP: has_stop_codon (:42-76) on the reference slice, which no SNV haplotype can extend
+            if (simple && !tail) {   // WSF_NOSTOP: has_stop_codon (:42-76) on the reference slice, which no SNV haplotype can extend
                 const uint8_t* rw = gh.input->refseq.data() + (st.sso - gh.input->gene.start());
                 bool upper = true;
                 for (uint32_t k = 0; k < st.wlen; k++) upper &= rw[k] >= 'A' && rw[k] <= 'Z';
