@@ -190,7 +190,10 @@ constexpr uint8_t WSF_NOSTOP = 2;     // (replaces SF_FULL_RANGE) simple window 
 constexpr uint8_t WSF_SIMPLE = 1;     // (replaces SF_PRINT, always set for a window) wlen <= 32 and the walk of :473-601 can only ever visit a
                                       // prefix of the columns (walk order), all SNVs at strictly increasing positions inside the window - the
                                       // next column, if any, lies behind the cursor or beyond the window (a stale column, :1159) and blocks
-                                      // everything after it: K3 builds the sequences by byte substitution instead of walking
+                                      // everything after it: K3 builds the sequences by byte substitution instead of walking. Also simple:
+                                      // a prefix that ends at the window's last base followed by SNVs at window_end, window_end + 1, ... without
+                                      // a gap (the walk's inner loop has no window bound, :479: a set SNV at the last base pulls that run in, one
+                                      // more base per applied column) - such a window is never WSF_NOSTOP (plan.cpp)
 // What K3 reads per listed haplotype, in ONE 128-byte record per window (built on the device once per batch by k0_pack_windows from wins, the
 // reference bytes, win_cols and the transcripts: a layout transformation, not part of the pass). K3 was bound by the number of scattered
 // loads and their dependent levels - entry -> window record -> reference bytes / columns / transcript -> id text; with the record the
